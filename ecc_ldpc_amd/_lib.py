@@ -1,0 +1,219 @@
+"""ctypes binding of libldpc_hip.so (include/ldpc_hip.h).  The library is the product; there is
+no Python or CPU fallback: if the shared object is missing or a call fails this module raises."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(HERE, "libldpc_hip.so")
+
+OK, EINVAL, ENOMEM, EHIP, ENODEVICE, EUNSUPPORTED, EDEGREE, EFORMAT, ENOTFOUND = 0, -1, -2, -3, -4, -5, -6, -7, -8
+TANH, MINSUM = 0, 1
+F32, F64, F16 = 0, 1, 2
+PATH_AUTO, PATH_FLOOD, PATH_FUSED = 0, 1, 2
+
+# every symbol include/ldpc_hip.h declares (tests/test_abi.py checks the library exports them all)
+ABI_SYMBOLS = [
+    "ldpc_init", "ldpc_shutdown", "ldpc_last_error", "ldpc_last_error_code", "ldpc_abi_version", "ldpc_device_count",
+    "ldpc_code_create_qc", "ldpc_code_create_csr", "ldpc_code_destroy", "ldpc_code_dims", "ldpc_code_csr",
+    "ldpc_ctx_create", "ldpc_ctx_create_ex", "ldpc_ctx_destroy", "ldpc_ctx_path", "ldpc_ctx_synchronize",
+    "ldpc_decode_one", "ldpc_decode_batch", "ldpc_decode_batch_f64", "ldpc_decode_batch_dev",
+    "ldpc_debug_step", "ldpc_decode_trace",
+]
+
+
+class LdpcError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"libldpc_hip error {code}: {msg}")
+        self.code = code
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(SO_PATH):
+        raise ImportError(f"{SO_PATH} is missing: build it with `python ecc_ldpc_amd/build.py` "
+                          "(the HIP library is the only decode path; there is no fallback)")
+    L = C.CDLL(SO_PATH)
+    vp, i32p, u8p, f64p, f32p, ip = C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_uint8), C.POINTER(C.c_double), C.POINTER(C.c_float), C.POINTER(C.c_int)
+    L.ldpc_last_error.restype = C.c_char_p
+    L.ldpc_init.argtypes = [C.c_int]
+    L.ldpc_code_create_qc.restype = vp
+    L.ldpc_code_create_qc.argtypes = [C.c_int, C.c_int, C.c_int, i32p]
+    L.ldpc_code_create_csr.restype = vp
+    L.ldpc_code_create_csr.argtypes = [C.c_int, C.c_int, i32p, i32p]
+    L.ldpc_code_destroy.restype = None
+    L.ldpc_code_destroy.argtypes = [vp]
+    L.ldpc_code_dims.argtypes = [vp, ip, ip, ip]
+    L.ldpc_code_csr.argtypes = [vp, i32p, i32p]
+    L.ldpc_ctx_create.restype = vp
+    L.ldpc_ctx_create.argtypes = [vp, C.c_int, C.c_int, C.c_int]
+    L.ldpc_ctx_create_ex.restype = vp
+    L.ldpc_ctx_create_ex.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int]
+    L.ldpc_ctx_destroy.restype = None
+    L.ldpc_ctx_destroy.argtypes = [vp]
+    L.ldpc_ctx_path.argtypes = [vp]
+    L.ldpc_ctx_synchronize.argtypes = [vp]
+    L.ldpc_decode_one.argtypes = [vp, C.c_int, f64p, u8p, ip, ip]
+    L.ldpc_decode_batch.argtypes = [vp, C.c_int, C.c_int, f32p, u8p, i32p, u8p]
+    L.ldpc_decode_batch_f64.argtypes = [vp, C.c_int, C.c_int, f64p, u8p, i32p, u8p, f64p]
+    L.ldpc_decode_batch_dev.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp, vp, vp]
+    L.ldpc_debug_step.argtypes = [vp, C.c_int, f64p, f64p, f64p, f64p, f64p, u8p]
+    L.ldpc_decode_trace.argtypes = [vp, C.c_int, C.c_int, f64p, u8p, i32p, u8p, f64p]
+    _lib = L
+    return L
+
+
+def last_error() -> str:
+    return lib().ldpc_last_error().decode()
+
+
+def check(rc):
+    if rc != OK:
+        raise LdpcError(rc, last_error())
+
+
+def ptr(a, ctype):
+    return a.ctypes.data_as(C.POINTER(ctype)) if a is not None else None
+
+
+def init(device: int = 0):
+    check(lib().ldpc_init(int(device)))
+
+
+_VARIANTS = {"tanh": TANH, "min": MINSUM, "minsum": MINSUM, "min-sum": MINSUM, TANH: TANH, MINSUM: MINSUM}
+_DTYPES = {"f32": F32, "f64": F64, "f16": F16, F32: F32, F64: F64, F16: F16}
+_PATHS = {"auto": PATH_AUTO, "flood": PATH_FLOOD, "fused": PATH_FUSED, 0: 0, 1: 1, 2: 2}
+
+
+class Code:
+    """Parity-check graph handle (ldpc_code)."""
+
+    def __init__(self, handle):
+        if not handle:
+            raise LdpcError(lib().ldpc_last_error_code(), last_error())
+        self._h = handle
+        M, N, E = C.c_int(), C.c_int(), C.c_int()
+        check(lib().ldpc_code_dims(self._h, C.byref(M), C.byref(N), C.byref(E)))
+        self.M, self.N, self.E = M.value, N.value, E.value
+
+    @classmethod
+    def from_qc(cls, sz, offsets):
+        off = np.ascontiguousarray(offsets, dtype=np.int32)
+        assert off.ndim == 2
+        return cls(lib().ldpc_code_create_qc(int(sz), off.shape[0], off.shape[1], ptr(off, C.c_int32)))
+
+    @classmethod
+    def from_csr(cls, row_ptr, col_idx, N):
+        rp = np.ascontiguousarray(row_ptr, dtype=np.int32)
+        ci = np.ascontiguousarray(col_idx, dtype=np.int32)
+        return cls(lib().ldpc_code_create_csr(len(rp) - 1, int(N), ptr(rp, C.c_int32), ptr(ci, C.c_int32)))
+
+    @classmethod
+    def from_dense(cls, H):
+        H = np.asarray(H)
+        M, N = H.shape
+        rp = np.zeros(M + 1, np.int32)
+        rp[1:] = np.cumsum(H.astype(bool).sum(1))
+        ci = np.nonzero(H)[1].astype(np.int32)
+        return cls.from_csr(rp, ci, N)
+
+    def csr(self):
+        rp = np.zeros(self.M + 1, np.int32)
+        ci = np.zeros(self.E, np.int32)
+        check(lib().ldpc_code_csr(self._h, ptr(rp, C.c_int32), ptr(ci, C.c_int32)))
+        return rp, ci
+
+    def close(self):
+        if self._h:
+            lib().ldpc_code_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Decoder:
+    """One decoder replica (ldpc_ctx): the object behind the reference's per-frame closure."""
+
+    def __init__(self, code: Code, variant="min", dtype="f32", max_batch=64, path="auto"):
+        self.code = code
+        self.max_batch = int(max_batch)
+        self._h = lib().ldpc_ctx_create_ex(code._h, _VARIANTS[variant], _DTYPES[dtype], int(max_batch), _PATHS[path])
+        if not self._h:
+            raise LdpcError(lib().ldpc_last_error_code(), last_error())
+        self.path = {PATH_FLOOD: "flood", PATH_FUSED: "fused"}[lib().ldpc_ctx_path(self._h)]
+
+    def decode_one(self, llr, max_iters):
+        llr = np.ascontiguousarray(llr, np.float64)
+        assert llr.shape == (self.code.N,)
+        bits = np.zeros(self.code.N, np.uint8)
+        it, cv = C.c_int(), C.c_int()
+        check(lib().ldpc_decode_one(self._h, int(max_iters), ptr(llr, C.c_double), ptr(bits, C.c_uint8), C.byref(it), C.byref(cv)))
+        return bits, it.value, bool(cv.value)
+
+    def decode_batch(self, llr, max_iters, want_lam=False):
+        """llr [F][N] float32 or float64 (host).  -> bits [F][N], iters [F], converged [F] (, lam)"""
+        llr = np.asarray(llr)
+        F = llr.shape[0]
+        assert llr.shape == (F, self.code.N)
+        bits = np.zeros((F, self.code.N), np.uint8)
+        iters = np.zeros(F, np.int32)
+        conv = np.zeros(F, np.uint8)
+        if llr.dtype == np.float32 and not want_lam:
+            llr = np.ascontiguousarray(llr)
+            check(lib().ldpc_decode_batch(self._h, int(max_iters), F, ptr(llr, C.c_float), ptr(bits, C.c_uint8), ptr(iters, C.c_int32), ptr(conv, C.c_uint8)))
+            return bits, iters, conv
+        llr = np.ascontiguousarray(llr, np.float64)
+        lam = np.zeros((F, self.code.N), np.float64) if want_lam else None
+        check(lib().ldpc_decode_batch_f64(self._h, int(max_iters), F, ptr(llr, C.c_double), ptr(bits, C.c_uint8), ptr(iters, C.c_int32), ptr(conv, C.c_uint8), ptr(lam, C.c_double)))
+        return (bits, iters, conv, lam) if want_lam else (bits, iters, conv)
+
+    def decode_batch_dev(self, d_llr_ptr, d_bits_ptr, batch, max_iters, d_iters_ptr=None, d_conv_ptr=None, stream=None):
+        check(lib().ldpc_decode_batch_dev(self._h, int(max_iters), int(batch), d_llr_ptr, d_bits_ptr, d_iters_ptr, d_conv_ptr, stream))
+
+    def synchronize(self):
+        check(lib().ldpc_ctx_synchronize(self._h))
+
+    def decode_trace(self, llr, max_iters):
+        llr = np.ascontiguousarray(llr, np.float64)
+        F = llr.shape[0]
+        bits = np.zeros((F, self.code.N), np.uint8)
+        iters = np.zeros(F, np.int32)
+        conv = np.zeros(F, np.uint8)
+        trace = np.zeros((F, max_iters + 1, self.code.N), np.float64)
+        check(lib().ldpc_decode_trace(self._h, int(max_iters), F, ptr(llr, C.c_double), ptr(bits, C.c_uint8), ptr(iters, C.c_int32), ptr(conv, C.c_uint8), ptr(trace, C.c_double)))
+        return bits, iters, conv, trace
+
+    def debug_step(self, orig, lam, ne):
+        orig = np.ascontiguousarray(orig, np.float64)
+        lam = np.ascontiguousarray(lam, np.float64)
+        ne = np.ascontiguousarray(ne, np.float64)
+        F = orig.shape[0]
+        assert orig.shape == lam.shape == (F, self.code.N) and ne.shape == (F, self.code.E)
+        ne2 = np.zeros_like(ne)
+        lam2 = np.zeros_like(lam)
+        syn = np.zeros(F, np.uint8)
+        check(lib().ldpc_debug_step(self._h, F, ptr(orig, C.c_double), ptr(lam, C.c_double), ptr(ne, C.c_double), ptr(ne2, C.c_double), ptr(lam2, C.c_double), ptr(syn, C.c_uint8)))
+        return ne2, lam2, syn.astype(bool)
+
+    def close(self):
+        if self._h:
+            lib().ldpc_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

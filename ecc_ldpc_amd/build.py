@@ -1,0 +1,58 @@
+"""Builds ecc_ldpc_amd/libldpc_hip.so in-tree with hipcc for gfx950 (no JIT cache: the built .so
+travels to the GPU box with the repository snapshot)."""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OUT = os.path.join(HERE, "libldpc_hip.so")
+SOURCES = ["api.cc", "flood.hip", "fused.hip"]
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-Wall", "-Wno-unused-function", "-Wno-unused-value",
+         "-ffp-contract=off",  # parity: a*b+c must round twice, like the reference's Double/float_ty ops
+         "-fno-fast-math"]
+
+
+def _headers():
+    hs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    hs.append(os.path.join(HERE, "..", "include", "ldpc_hip.h"))
+    return hs
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+
+
+def build(force: bool = False, verbose: bool = True) -> str:
+    objdir = os.path.join(HERE, "build")
+    os.makedirs(objdir, exist_ok=True)
+    hdrs = _headers()
+    objs, procs = [], []
+    for s in SOURCES:
+        src = os.path.join(CSRC, s)
+        obj = os.path.join(objdir, s + ".o")
+        objs.append(obj)
+        if force or _stale(obj, [src] + hdrs):
+            cmd = [HIPCC] + FLAGS + ["-x", "hip", "-c", src, "-o", obj]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            procs.append((s, subprocess.Popen(cmd)))
+    for s, p in procs:
+        if p.wait() != 0:
+            raise RuntimeError(f"hipcc failed on {s}")
+    if force or procs or _stale(OUT, objs):
+        cmd = [HIPCC, "-shared", "-fPIC", "--offload-arch=gfx950", "-o", OUT] + objs
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    return OUT
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)

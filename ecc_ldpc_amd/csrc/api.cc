@@ -1,0 +1,446 @@
+// api.cc -- the C ABI of include/ldpc_hip.h: graph objects, decoder replicas, host<->device plumbing.
+// No C++ exception leaves this file; every failure becomes an LDPC_E* code + thread-local message.
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <mutex>
+#include <new>
+
+#include "internal.h"
+#include "fused.h"
+
+namespace ldpc {
+static thread_local char g_err[512] = "";
+static thread_local int g_err_code = 0;
+int set_error(int code, const char *fmt, ...) {
+    g_err_code = code;
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+}  // namespace ldpc
+using ldpc::set_error;
+
+#define HIPCHK(x)                                                                                \
+    do {                                                                                         \
+        hipError_t e_ = (x);                                                                     \
+        if (e_ != hipSuccess) return set_error(LDPC_EHIP, "%s: %s", #x, hipGetErrorString(e_)); \
+    } while (0)
+#define HIPCHK_NULL(x)                                                               \
+    do {                                                                             \
+        hipError_t e_ = (x);                                                         \
+        if (e_ != hipSuccess) {                                                      \
+            set_error(LDPC_EHIP, "%s: %s", #x, hipGetErrorString(e_));               \
+            return nullptr;                                                          \
+        }                                                                            \
+    } while (0)
+
+struct ldpc_ctx {
+    const ldpc_code *code = nullptr;
+    int variant = 0, dtype = 0, max_batch = 0, Bp = 0, path = LDPC_PATH_FLOOD, device = 0;
+    hipStream_t stream = nullptr;
+    ldpc::FloodState flood;
+    ldpc::FusedState *fused = nullptr;
+    void *d_in = nullptr;        // staging: [max_batch][N] float or double
+    uint8_t *d_bits = nullptr;   // [max_batch][N]
+    int32_t *d_iters = nullptr;  // fused path output staging [max_batch]
+    uint8_t *d_conv = nullptr;
+};
+
+static std::mutex g_mu;
+static int g_device = -1;
+
+extern "C" {
+
+const char *ldpc_last_error(void) { return ldpc::g_err; }
+int ldpc_last_error_code(void) { return ldpc::g_err_code; }
+int ldpc_abi_version(void) { return 1; }
+
+int ldpc_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int ldpc_init(int device) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return set_error(LDPC_ENODEVICE, "no HIP device visible (%s); the HIP path has no CPU fallback",
+                         e == hipSuccess ? "count = 0" : hipGetErrorString(e));
+    if (device < 0 || device >= n) return set_error(LDPC_EINVAL, "device %d out of range [0,%d)", device, n);
+    HIPCHK(hipSetDevice(device));
+    hipDeviceProp_t p;
+    HIPCHK(hipGetDeviceProperties(&p, device));
+    if (strncmp(p.gcnArchName, "gfx950", 6) != 0)
+        return set_error(LDPC_ENODEVICE, "device %d is %s; libldpc_hip.so carries gfx950 code objects only", device, p.gcnArchName);
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_device = device;
+    return LDPC_OK;
+}
+
+int ldpc_shutdown(void) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_device = -1;
+    return LDPC_OK;
+}
+
+// ------------------------------------------------------------------------------- graph
+static int finish_code(ldpc_code *c) {
+    c->E = c->row_ptr[c->M];
+    c->col_ptr.assign((size_t)c->N + 1, 0);
+    c->max_row_deg = 0;
+    c->min_row_deg = c->M > 0 ? (1 << 30) : 0;
+    for (int m = 0; m < c->M; m++) {
+        int b = c->row_ptr[m], e = c->row_ptr[m + 1];
+        if (e < b) return set_error(LDPC_EINVAL, "row_ptr not monotone at row %d", m);
+        c->max_row_deg = std::max(c->max_row_deg, e - b);
+        c->min_row_deg = std::min(c->min_row_deg, e - b);
+        for (int q = b; q < e; q++) {
+            int col = c->col_idx[q];
+            if (col < 0 || col >= c->N) return set_error(LDPC_EINVAL, "column %d out of range in row %d", col, m);
+            if (q > b && c->col_idx[q - 1] >= col) return set_error(LDPC_EINVAL, "columns of row %d not strictly ascending", m);
+            c->col_ptr[col + 1]++;
+        }
+    }
+    c->max_col_deg = 0;
+    for (int j = 0; j < c->N; j++) {
+        c->max_col_deg = std::max(c->max_col_deg, c->col_ptr[j + 1]);
+        c->col_ptr[j + 1] += c->col_ptr[j];
+    }
+    c->csc_edge.assign((size_t)c->E, 0);
+    std::vector<int32_t> fill(c->col_ptr.begin(), c->col_ptr.end() - 1);
+    for (int m = 0; m < c->M; m++)
+        for (int q = c->row_ptr[m]; q < c->row_ptr[m + 1]; q++) c->csc_edge[fill[c->col_idx[q]]++] = q;
+    return LDPC_OK;
+}
+
+ldpc_code *ldpc_code_create_csr(int M, int N, const int32_t *row_ptr, const int32_t *col_idx) {
+    if (M <= 0 || N <= 0 || !row_ptr || !col_idx || row_ptr[0] != 0 || row_ptr[M] < 0) {
+        set_error(LDPC_EINVAL, "ldpc_code_create_csr: bad arguments (M=%d N=%d)", M, N);
+        return nullptr;
+    }
+    ldpc_code *c = new (std::nothrow) ldpc_code();
+    if (!c) { set_error(LDPC_ENOMEM, "out of host memory"); return nullptr; }
+    try {
+        c->M = M; c->N = N;
+        c->row_ptr.assign(row_ptr, row_ptr + M + 1);
+        c->col_idx.assign(col_idx, col_idx + row_ptr[M]);
+        if (finish_code(c) != LDPC_OK) { delete c; return nullptr; }
+    } catch (...) { delete c; set_error(LDPC_ENOMEM, "out of host memory"); return nullptr; }
+    return c;
+}
+
+ldpc_code *ldpc_code_create_qc(int sz, int block_rows, int block_cols, const int32_t *offsets) {
+    if (sz <= 0 || block_rows <= 0 || block_cols <= 0 || !offsets) {
+        set_error(LDPC_EINVAL, "ldpc_code_create_qc: bad arguments (sz=%d %dx%d)", sz, block_rows, block_cols);
+        return nullptr;
+    }
+    for (int i = 0; i < block_rows * block_cols; i++)
+        if (offsets[i] < -1 || offsets[i] >= sz) {
+            set_error(LDPC_EINVAL, "offset %d at block %d outside [-1,%d)", offsets[i], i, sz);
+            return nullptr;
+        }
+    ldpc_code *c = new (std::nothrow) ldpc_code();
+    if (!c) { set_error(LDPC_ENOMEM, "out of host memory"); return nullptr; }
+    try {
+        c->sz = sz; c->block_rows = block_rows; c->block_cols = block_cols;
+        c->offsets.assign(offsets, offsets + (size_t)block_rows * block_cols);
+        c->M = sz * block_rows; c->N = sz * block_cols;
+        c->row_ptr.assign((size_t)c->M + 1, 0);
+        // row r of block-row br: one entry per non-empty block, column bc*sz + (r+off) mod sz
+        // (QuasiCyclic.hs:19-25); block columns ascend, so columns ascend.
+        for (int br = 0; br < block_rows; br++)
+            for (int r = 0; r < sz; r++) {
+                int m = br * sz + r;
+                for (int bc = 0; bc < block_cols; bc++) {
+                    int off = offsets[(size_t)br * block_cols + bc];
+                    if (off >= 0) c->col_idx.push_back(bc * sz + (r + off) % sz);
+                }
+                c->row_ptr[m + 1] = (int32_t)c->col_idx.size();
+            }
+        if (finish_code(c) != LDPC_OK) { delete c; return nullptr; }
+    } catch (...) { delete c; set_error(LDPC_ENOMEM, "out of host memory"); return nullptr; }
+    return c;
+}
+
+static void code_free_device(ldpc_code *c) {
+    if (c->device >= 0) {
+        hipFree(c->d_row_ptr); hipFree(c->d_col_idx); hipFree(c->d_col_ptr); hipFree(c->d_csc_edge);
+        c->d_row_ptr = c->d_col_idx = c->d_col_ptr = c->d_csc_edge = nullptr;
+        c->device = -1;
+    }
+}
+
+void ldpc_code_destroy(ldpc_code *code) {
+    if (!code) return;
+    code_free_device(code);
+    delete code;
+}
+
+int ldpc_code_dims(const ldpc_code *code, int *M, int *N, int *E) {
+    if (!code) return set_error(LDPC_EINVAL, "null code");
+    if (M) *M = code->M;
+    if (N) *N = code->N;
+    if (E) *E = code->E;
+    return LDPC_OK;
+}
+
+int ldpc_code_csr(const ldpc_code *code, int32_t *row_ptr, int32_t *col_idx) {
+    if (!code || !row_ptr || !col_idx) return set_error(LDPC_EINVAL, "null argument");
+    memcpy(row_ptr, code->row_ptr.data(), sizeof(int32_t) * ((size_t)code->M + 1));
+    memcpy(col_idx, code->col_idx.data(), sizeof(int32_t) * (size_t)code->E);
+    return LDPC_OK;
+}
+
+static int code_upload(ldpc_code *c, int device) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (c->device == device) return LDPC_OK;
+    if (c->device >= 0) return set_error(LDPC_EUNSUPPORTED, "code already bound to device %d", c->device);
+    auto up = [&](int32_t **dst, const std::vector<int32_t> &v) -> int {
+        size_t bytes = sizeof(int32_t) * std::max<size_t>(v.size(), 1);
+        HIPCHK(hipMalloc((void **)dst, bytes));
+        if (!v.empty()) HIPCHK(hipMemcpy(*dst, v.data(), sizeof(int32_t) * v.size(), hipMemcpyHostToDevice));
+        return LDPC_OK;
+    };
+    int rc;
+    if ((rc = up(&c->d_row_ptr, c->row_ptr)) || (rc = up(&c->d_col_idx, c->col_idx)) ||
+        (rc = up(&c->d_col_ptr, c->col_ptr)) || (rc = up(&c->d_csc_edge, c->csc_edge)))
+        return rc;
+    c->device = device;
+    return LDPC_OK;
+}
+
+// ------------------------------------------------------------------------------- contexts
+void ldpc_ctx_destroy(ldpc_ctx *ctx) {
+    if (!ctx) return;
+    if (ctx->stream) hipStreamSynchronize(ctx->stream);
+    hipFree(ctx->flood.msg); hipFree(ctx->flood.scratch); hipFree(ctx->flood.lam); hipFree(ctx->flood.orig);
+    hipFree(ctx->flood.dev.unsat); hipFree(ctx->flood.dev.iters); hipFree(ctx->flood.dev.conv); hipFree(ctx->flood.dev.done);
+    hipFree(ctx->d_in); hipFree(ctx->d_bits); hipFree(ctx->d_iters); hipFree(ctx->d_conv);
+    if (ctx->fused) ldpc::fused_destroy(ctx->fused);
+    if (ctx->stream) hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+ldpc_ctx *ldpc_ctx_create_ex(const ldpc_code *code_c, int variant, int dtype, int max_batch, int path) {
+    ldpc_code *code = const_cast<ldpc_code *>(code_c);
+    if (!code || max_batch <= 0 || (variant != LDPC_TANH && variant != LDPC_MINSUM) ||
+        (dtype != LDPC_F32 && dtype != LDPC_F64 && dtype != LDPC_F16) ||
+        (path != LDPC_PATH_AUTO && path != LDPC_PATH_FLOOD && path != LDPC_PATH_FUSED)) {
+        set_error(LDPC_EINVAL, "ldpc_ctx_create: bad arguments (variant=%d dtype=%d max_batch=%d path=%d)", variant, dtype, max_batch, path);
+        return nullptr;
+    }
+    if (variant == LDPC_MINSUM && code->min_row_deg == 1) {
+        set_error(LDPC_EDEGREE, "min-sum on a check row of degree 1 (the reference's foldr1 min' fails on [], Min.hs:79)");
+        return nullptr;
+    }
+    int device;
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        device = g_device;
+    }
+    if (device < 0) {
+        set_error(LDPC_ENODEVICE, "ldpc_init() has not succeeded: no GPU bound (there is no CPU fallback)");
+        return nullptr;
+    }
+    HIPCHK_NULL(hipSetDevice(device));
+    if (code_upload(code, device) != LDPC_OK) return nullptr;
+
+    const bool fused_ok = ldpc::fused_supported(*code, variant, dtype);
+    if (path == LDPC_PATH_FUSED && !fused_ok) {
+        set_error(LDPC_EUNSUPPORTED, "no fused kernel for this code/variant/dtype (%s)", ldpc::fused_why_not(*code, variant, dtype));
+        return nullptr;
+    }
+    ldpc_ctx *ctx = new (std::nothrow) ldpc_ctx();
+    if (!ctx) { set_error(LDPC_ENOMEM, "out of host memory"); return nullptr; }
+    ctx->code = code; ctx->variant = variant; ctx->dtype = dtype; ctx->max_batch = max_batch; ctx->device = device;
+    ctx->Bp = (max_batch + 63) / 64 * 64;
+    ctx->path = (path == LDPC_PATH_AUTO) ? (fused_ok ? LDPC_PATH_FUSED : LDPC_PATH_FLOOD) : path;
+
+#define CTX_HIP(x)                                                       \
+    do {                                                                 \
+        hipError_t e_ = (x);                                             \
+        if (e_ != hipSuccess) {                                          \
+            set_error(e_ == hipErrorOutOfMemory ? LDPC_ENOMEM : LDPC_EHIP, "%s: %s", #x, hipGetErrorString(e_)); \
+            ldpc_ctx_destroy(ctx);                                       \
+            return nullptr;                                              \
+        }                                                                \
+    } while (0)
+
+    CTX_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    const size_t es = ldpc::flood_elem_size(dtype);
+    const size_t Bp = (size_t)ctx->Bp;
+    ldpc::FloodDev &d = ctx->flood.dev;
+    d.M = code->M; d.N = code->N; d.E = code->E; d.Bp = ctx->Bp;
+    d.row_ptr = code->d_row_ptr; d.col_idx = code->d_col_idx; d.col_ptr = code->d_col_ptr; d.csc_edge = code->d_csc_edge;
+    d.unsat = nullptr; d.iters = nullptr; d.conv = nullptr; d.done = nullptr;
+    ctx->flood.variant = variant; ctx->flood.dtype = dtype;
+    CTX_HIP(hipMalloc((void **)&ctx->d_in, (size_t)max_batch * code->N * sizeof(double)));
+    CTX_HIP(hipMalloc((void **)&ctx->d_bits, (size_t)max_batch * code->N));
+    CTX_HIP(hipMalloc((void **)&ctx->d_iters, sizeof(int32_t) * (size_t)max_batch));
+    CTX_HIP(hipMalloc((void **)&ctx->d_conv, (size_t)max_batch));
+    if (ctx->path == LDPC_PATH_FLOOD) {
+        CTX_HIP(hipMalloc(&ctx->flood.msg, std::max<size_t>((size_t)code->E, 1) * Bp * es));
+        // scratch is only touched by rows whose degree has no register kernel
+        bool need_scratch = false;
+        for (int m = 0; m < code->M; m++) {
+            int dg = code->row_ptr[m + 1] - code->row_ptr[m];
+            if (!(dg <= 8 || dg == 18)) need_scratch = true;
+        }
+        if (need_scratch) CTX_HIP(hipMalloc(&ctx->flood.scratch, std::max<size_t>((size_t)code->E, 1) * Bp * es));
+        CTX_HIP(hipMalloc(&ctx->flood.lam, (size_t)code->N * Bp * es));
+        CTX_HIP(hipMalloc(&ctx->flood.orig, (size_t)code->N * Bp * es));
+        CTX_HIP(hipMalloc((void **)&d.unsat, sizeof(int32_t) * Bp));
+        CTX_HIP(hipMalloc((void **)&d.iters, sizeof(int32_t) * Bp));
+        CTX_HIP(hipMalloc((void **)&d.conv, Bp));
+        CTX_HIP(hipMalloc((void **)&d.done, Bp));
+    } else {
+        ctx->fused = ldpc::fused_create(*code, variant, dtype, max_batch);
+        if (!ctx->fused) { ldpc_ctx_destroy(ctx); return nullptr; }
+    }
+    return ctx;
+}
+
+ldpc_ctx *ldpc_ctx_create(const ldpc_code *code, int variant, int dtype, int max_batch) {
+    return ldpc_ctx_create_ex(code, variant, dtype, max_batch, LDPC_PATH_AUTO);
+}
+
+int ldpc_ctx_path(const ldpc_ctx *ctx) { return ctx ? ctx->path : set_error(LDPC_EINVAL, "null ctx"); }
+
+int ldpc_ctx_synchronize(ldpc_ctx *ctx) {
+    if (!ctx) return set_error(LDPC_EINVAL, "null ctx");
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return LDPC_OK;
+}
+
+// ------------------------------------------------------------------------------- decode
+static int check_call(ldpc_ctx *ctx, int max_iters, int batch) {
+    if (!ctx) return set_error(LDPC_EINVAL, "null ctx");
+    if (max_iters < 0) return set_error(LDPC_EINVAL, "max_iters %d < 0", max_iters);
+    if (batch < 0 || batch > ctx->max_batch) return set_error(LDPC_EINVAL, "batch %d outside [0,%d]", batch, ctx->max_batch);
+    HIPCHK(hipSetDevice(ctx->device));
+    return LDPC_OK;
+}
+
+// device-side core: d_llr is float32 or float64 [batch][N]; outputs device pointers (may be null)
+static int decode_dev(ldpc_ctx *ctx, hipStream_t st, int max_iters, int batch, const void *d_llr, int is_f64,
+                      uint8_t *d_bits, int32_t *d_iters, uint8_t *d_conv, double *d_final, double *d_trace) {
+    if (batch == 0) return LDPC_OK;
+    if (ctx->path == LDPC_PATH_FUSED)
+        return ldpc::fused_decode(*ctx->fused, st, max_iters, batch, d_llr, is_f64, d_bits, d_iters, d_conv, d_final, d_trace);
+    int rc = ldpc::flood_decode(ctx->flood, st, max_iters, batch, d_llr, is_f64, d_bits, d_final, d_trace);
+    if (rc != LDPC_OK) return rc;
+    if (d_iters) HIPCHK(hipMemcpyAsync(d_iters, ctx->flood.dev.iters, sizeof(int32_t) * (size_t)batch, hipMemcpyDeviceToDevice, st));
+    if (d_conv) HIPCHK(hipMemcpyAsync(d_conv, ctx->flood.dev.conv, (size_t)batch, hipMemcpyDeviceToDevice, st));
+    return LDPC_OK;
+}
+
+static int decode_host(ldpc_ctx *ctx, int max_iters, int batch, const void *llr, int is_f64, uint8_t *bits,
+                       int32_t *iters, uint8_t *converged, double *final_lam, double *trace_lam) {
+    int rc = check_call(ctx, max_iters, batch);
+    if (rc != LDPC_OK) return rc;
+    if (batch == 0) return LDPC_OK;
+    if (!llr || !bits) return set_error(LDPC_EINVAL, "null llr/bits");
+    const size_t N = (size_t)ctx->code->N;
+    hipStream_t st = ctx->stream;
+    double *d_final = nullptr, *d_trace = nullptr;
+    HIPCHK(hipMemcpyAsync(ctx->d_in, llr, (size_t)batch * N * (is_f64 ? 8 : 4), hipMemcpyHostToDevice, st));
+    if (final_lam) HIPCHK(hipMalloc((void **)&d_final, (size_t)batch * N * sizeof(double)));
+    if (trace_lam) {
+        size_t tb = (size_t)batch * (max_iters + 1) * N * sizeof(double);
+        hipError_t e = hipMalloc((void **)&d_trace, tb);
+        if (e != hipSuccess) { hipFree(d_final); return set_error(LDPC_ENOMEM, "trace buffer of %zu bytes: %s", tb, hipGetErrorString(e)); }
+        hipMemsetAsync(d_trace, 0, tb, st);
+    }
+    rc = decode_dev(ctx, st, max_iters, batch, ctx->d_in, is_f64, ctx->d_bits, ctx->d_iters, ctx->d_conv, d_final, d_trace);
+    if (rc == LDPC_OK) {
+        hipError_t e = hipMemcpyAsync(bits, ctx->d_bits, (size_t)batch * N, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess && iters) e = hipMemcpyAsync(iters, ctx->d_iters, sizeof(int32_t) * (size_t)batch, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess && converged) e = hipMemcpyAsync(converged, ctx->d_conv, (size_t)batch, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess && final_lam) e = hipMemcpyAsync(final_lam, d_final, (size_t)batch * N * sizeof(double), hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess && trace_lam) e = hipMemcpyAsync(trace_lam, d_trace, (size_t)batch * (max_iters + 1) * N * sizeof(double), hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        if (e != hipSuccess) rc = set_error(LDPC_EHIP, "decode: %s", hipGetErrorString(e));
+    } else {
+        hipStreamSynchronize(st);
+    }
+    hipFree(d_final);
+    hipFree(d_trace);
+    return rc;
+}
+
+int ldpc_decode_batch(ldpc_ctx *ctx, int max_iters, int batch, const float *llr, uint8_t *bits, int32_t *iters,
+                      uint8_t *converged) {
+    return decode_host(ctx, max_iters, batch, llr, 0, bits, iters, converged, nullptr, nullptr);
+}
+
+int ldpc_decode_batch_f64(ldpc_ctx *ctx, int max_iters, int batch, const double *llr, uint8_t *bits, int32_t *iters,
+                          uint8_t *converged, double *final_lam) {
+    return decode_host(ctx, max_iters, batch, llr, 1, bits, iters, converged, final_lam, nullptr);
+}
+
+int ldpc_decode_trace(ldpc_ctx *ctx, int max_iters, int batch, const double *llr, uint8_t *bits, int32_t *iters,
+                      uint8_t *converged, double *trace_lam) {
+    if (!trace_lam) return set_error(LDPC_EINVAL, "null trace_lam");
+    return decode_host(ctx, max_iters, batch, llr, 1, bits, iters, converged, nullptr, trace_lam);
+}
+
+int ldpc_decode_one(ldpc_ctx *ctx, int max_iters, const double *llr, uint8_t *bits, int *iters, int *converged) {
+    int32_t it = 0;
+    uint8_t cv = 0;
+    int rc = decode_host(ctx, max_iters, 1, llr, 1, bits, &it, &cv, nullptr, nullptr);
+    if (rc != LDPC_OK) return rc;
+    if (iters) *iters = it;
+    if (converged) *converged = cv;
+    return LDPC_OK;
+}
+
+int ldpc_decode_batch_dev(ldpc_ctx *ctx, int max_iters, int batch, const float *d_llr, uint8_t *d_bits,
+                          int32_t *d_iters, uint8_t *d_converged, void *stream) {
+    int rc = check_call(ctx, max_iters, batch);
+    if (rc != LDPC_OK) return rc;
+    if (batch == 0) return LDPC_OK;
+    if (!d_llr || !d_bits) return set_error(LDPC_EINVAL, "null d_llr/d_bits");
+    hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+    return decode_dev(ctx, st, max_iters, batch, d_llr, 0, d_bits, d_iters, d_converged, nullptr, nullptr);
+}
+
+int ldpc_debug_step(ldpc_ctx *ctx, int batch, const double *orig, const double *lam, const double *ne, double *ne_out,
+                    double *lam_out, uint8_t *syndrome_zero) {
+    int rc = check_call(ctx, 0, batch);
+    if (rc != LDPC_OK) return rc;
+    if (batch == 0) return LDPC_OK;
+    if (!orig || !lam || !ne || !ne_out || !lam_out) return set_error(LDPC_EINVAL, "null argument");
+    const size_t N = (size_t)ctx->code->N, E = (size_t)ctx->code->E, B = (size_t)batch;
+    double *buf = nullptr;
+    uint8_t *d_syn = nullptr;
+    const size_t total = B * (3 * N + 2 * E);
+    HIPCHK(hipMalloc((void **)&buf, total * sizeof(double)));
+    if (hipMalloc((void **)&d_syn, B) != hipSuccess) { hipFree(buf); return set_error(LDPC_ENOMEM, "hipMalloc"); }
+    double *d_orig = buf, *d_lam = buf + B * N, *d_lam_out = buf + 2 * B * N, *d_ne = buf + 3 * B * N, *d_ne_out = d_ne + B * E;
+    hipStream_t st = ctx->stream;
+    hipMemcpyAsync(d_orig, orig, B * N * 8, hipMemcpyHostToDevice, st);
+    hipMemcpyAsync(d_lam, lam, B * N * 8, hipMemcpyHostToDevice, st);
+    hipMemcpyAsync(d_ne, ne, B * E * 8, hipMemcpyHostToDevice, st);
+    if (ctx->path == LDPC_PATH_FUSED)
+        rc = ldpc::fused_step(*ctx->fused, st, batch, d_orig, d_lam, d_ne, d_ne_out, d_lam_out, d_syn);
+    else
+        rc = ldpc::flood_step(ctx->flood, st, batch, d_orig, d_lam, d_ne, d_ne_out, d_lam_out, d_syn);
+    if (rc == LDPC_OK) {
+        hipMemcpyAsync(ne_out, d_ne_out, B * E * 8, hipMemcpyDeviceToHost, st);
+        hipMemcpyAsync(lam_out, d_lam_out, B * N * 8, hipMemcpyDeviceToHost, st);
+        if (syndrome_zero) hipMemcpyAsync(syndrome_zero, d_syn, B, hipMemcpyDeviceToHost, st);
+    }
+    hipError_t e = hipStreamSynchronize(st);
+    if (rc == LDPC_OK && e != hipSuccess) rc = set_error(LDPC_EHIP, "debug_step: %s", hipGetErrorString(e));
+    hipFree(buf);
+    hipFree(d_syn);
+    return rc;
+}
+
+}  // extern "C"

@@ -1,0 +1,396 @@
+// flood.hip -- generic flooding BP path: state resident in HBM, two kernels per iteration.
+//
+// Works for ANY parity-check matrix given as CSR (the `Matrix Bool` decoders of the reference:
+// Reference/Orig.hs:30-31, Reference/Min.hs:33-34) and is the fallback for codes the fused
+// on-chip kernel (fused.hip) does not cover.
+//
+// Data layout (batch-major, "one codeword per wavefront lane"):
+//   lam  [N][Bp]   a-posteriori LLRs          orig [N][Bp]  channel LLRs
+//   msg  [E][Bp]   check->variable messages (ne), CSR edge order
+//   Bp = batch padded to a multiple of 64.  Lane l of a wave owns codeword 64*slab + l, so every
+//   global access of a wave is one contiguous 256-byte (fp32) segment and every graph index
+//   (row_ptr / col_idx / csc tables) is wave-uniform -> scalar loads.
+//
+// One loop turn n of Reference/Orig.hs:67-71:
+//   flood_cn : per (row, 64 codewords): t_j = lam[col_j] - msg[e_j]; row parity of hard(lam)
+//              (the syndrome, Orig.hs:73-78) -> unsat stamp; ne' (Orig.hs:81-92 / Min.hs:75-87)
+//              written in place.
+//   flood_vn : per (column, 64 codewords): if the frame's syndrome was zero it is frozen
+//              (done, iters = n: Orig.hs:69 "return lam"); else lam' = foldr (+) orig (col of
+//              ne') in the reference's order (Orig.hs:96): descending row.
+// Algorithmic HBM bytes per frame per turn: CN reads msg (E) + lam (N, given L2 reuse of the
+// slab), writes msg (E); VN reads msg (E) + orig (N), writes lam (N)  => (3E + 3N) * sizeof(ST),
+// the B_iter of SURVEY.md section 8d.
+#include "ldpc_math.h"
+#include "internal.h"
+
+namespace ldpc {
+
+constexpr int kWave = 64;
+constexpr int kCnWaves = 4; // rows per CN block
+
+// ------------------------------------------------------------------ CN + syndrome
+template <typename ST, int VARIANT, int DEG>
+__device__ __forceinline__ void cn_row_regs(const FloodDev &d, ST *__restrict__ msg,
+                                            const ST *__restrict__ lam, int ebeg, size_t b,
+                                            int stamp, bool syndrome_only) {
+    using CT = typename Store<ST>::CT;
+    CT t[DEG];
+    unsigned par = 0;
+#pragma unroll
+    for (int k = 0; k < DEG; k++) {
+        int col = d.col_idx[ebeg + k]; // wave-uniform
+        CT l = Store<ST>::ld(lam + (size_t)col * d.Bp + b);
+        par ^= hard(l) ? 1u : 0u;
+        if (!syndrome_only) {
+            CT m = Store<ST>::ld(msg + (size_t)(ebeg + k) * d.Bp + b);
+            t[k] = l - m;
+        }
+    }
+    if (par) d.unsat[b] = stamp; // benign race: every writer stores the same value
+    if (syndrome_only) return;
+    cn_update<CT, VARIANT, DEG>(t);
+#pragma unroll
+    for (int k = 0; k < DEG; k++) Store<ST>::st(msg + (size_t)(ebeg + k) * d.Bp + b, t[k]);
+}
+
+// any degree: O(deg^2) re-reads (served by L1/L2); correctness path for unusual row weights.
+template <typename ST, int VARIANT>
+__device__ void cn_row_generic(const FloodDev &d, ST *__restrict__ msg, ST *__restrict__ scratch,
+                               const ST *__restrict__ lam, int ebeg, int deg, size_t b, int stamp,
+                               bool syndrome_only) {
+    using CT = typename Store<ST>::CT;
+    unsigned par = 0;
+    for (int k = 0; k < deg; k++) {
+        int col = d.col_idx[ebeg + k];
+        par ^= hard(Store<ST>::ld(lam + (size_t)col * d.Bp + b)) ? 1u : 0u;
+    }
+    if (par) d.unsat[b] = stamp;
+    if (syndrome_only) return;
+    // new messages go to scratch[e] first (old ones are still needed by the other outputs)
+    for (int k = 0; k < deg; k++) {
+        CT out;
+        if constexpr (VARIANT == LDPC_V_MINSUM) {
+            CT mag = CT(INFINITY);
+            unsigned neg = 0;
+            for (int j = 0; j < deg; j++) {
+                if (j == k) continue;
+                int col = d.col_idx[ebeg + j];
+                CT tj = Store<ST>::ld(lam + (size_t)col * d.Bp + b) - Store<ST>::ld(msg + (size_t)(ebeg + j) * d.Bp + b);
+                CT a = fabs(tj);
+                mag = a < mag ? a : mag;
+                neg ^= (tj > CT(0)) ? 1u : 0u;
+            }
+            out = CT(-0.75) * (neg ? -mag : mag);
+        } else if constexpr (sizeof(CT) == 8) {
+            double prod = 1.0;
+            for (int j = 0; j < deg; j++) {
+                if (j == k) continue;
+                int col = d.col_idx[ebeg + j];
+                double tj = Store<ST>::ld(lam + (size_t)col * d.Bp + b) - Store<ST>::ld(msg + (size_t)(ebeg + j) * d.Bp + b);
+                prod = prod * tanh(-(tj / 2.0));
+            }
+            double y = 0.5 * log((1.0 + prod) / (1.0 - prod));
+            if (isinf(y)) y = (prod > 0.0 ? 1.0 : -1.0) * kAtanhClamp;
+            out = -2.0 * y;
+        } else {
+            float S = 0.f;
+            unsigned neg = 0;
+            for (int j = 0; j < deg; j++) {
+                if (j == k) continue;
+                int col = d.col_idx[ebeg + j];
+                float tj = Store<ST>::ld(lam + (size_t)col * d.Bp + b) - Store<ST>::ld(msg + (size_t)(ebeg + j) * d.Bp + b);
+                S += phi_f32(fabsf(tj));
+                neg ^= (tj > 0.f) ? 1u : 0u;
+            }
+            float mag = fminf(phi_f32(S), (float)kNeClamp);
+            out = neg ? mag : -mag;
+        }
+        Store<ST>::st(scratch + (size_t)(ebeg + k) * d.Bp + b, out);
+    }
+    for (int k = 0; k < deg; k++)
+        msg[(size_t)(ebeg + k) * d.Bp + b] = scratch[(size_t)(ebeg + k) * d.Bp + b];
+}
+
+// grid: 1-D, (Bp/64) slabs x ceil(M/kCnWaves) row groups, remapped so that all row groups of one
+// codeword slab run back to back on ONE XCD (blocks are dealt round-robin over the 8 XCDs, so
+// block ids congruent mod 8 share an L2): lam[col] of the slab is then re-read from that L2.
+template <typename ST, int VARIANT>
+__global__ __launch_bounds__(kWave *kCnWaves) void flood_cn_kernel(FloodDev d, ST *msg, ST *scratch,
+                                                                   const ST *lam, int stamp,
+                                                                   int syndrome_only, int force) {
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int row_groups = (d.M + kCnWaves - 1) / kCnWaves;
+    const int slabs = d.Bp / kWave;
+    // XCD-aware remap of the linear block id
+    int L = blockIdx.x;
+    int slab, rg;
+    {
+        const int per_xcd_slabs = slabs / 8; // slabs handled "8 at a time" (one per XCD)
+        const int full = per_xcd_slabs * 8 * row_groups;
+        if (L < full) {
+            int xcd = L & 7, j = L >> 3;
+            slab = (j / row_groups) * 8 + xcd;
+            rg = j % row_groups;
+        } else { // tail: slabs that do not fill a group of 8
+            int j = L - full;
+            slab = per_xcd_slabs * 8 + j / row_groups;
+            rg = j % row_groups;
+        }
+    }
+    const int row = rg * kCnWaves + wave;
+    if (row >= d.M) return;
+    const size_t b = (size_t)slab * kWave + lane;
+    const bool active = force ? true : (d.done[b] == 0);
+    if (!active) return; // lanes of finished (or padding) frames drop out; an all-done wave exits
+    const int ebeg = d.row_ptr[row];
+    const int deg = d.row_ptr[row + 1] - ebeg;
+    const bool so = syndrome_only != 0;
+    switch (deg) {
+        case 0: break;
+        case 1:
+            if constexpr (VARIANT == LDPC_V_TANH) cn_row_regs<ST, VARIANT, 1>(d, msg, lam, ebeg, b, stamp, so);
+            else cn_row_generic<ST, VARIANT>(d, msg, scratch, lam, ebeg, deg, b, stamp, true); // rejected at ctx_create
+            break;
+        case 2: cn_row_regs<ST, VARIANT, 2>(d, msg, lam, ebeg, b, stamp, so); break;
+        case 3: cn_row_regs<ST, VARIANT, 3>(d, msg, lam, ebeg, b, stamp, so); break;
+        case 4: cn_row_regs<ST, VARIANT, 4>(d, msg, lam, ebeg, b, stamp, so); break;
+        case 5: cn_row_regs<ST, VARIANT, 5>(d, msg, lam, ebeg, b, stamp, so); break;
+        case 6: cn_row_regs<ST, VARIANT, 6>(d, msg, lam, ebeg, b, stamp, so); break;
+        case 7: cn_row_regs<ST, VARIANT, 7>(d, msg, lam, ebeg, b, stamp, so); break;
+        case 8: cn_row_regs<ST, VARIANT, 8>(d, msg, lam, ebeg, b, stamp, so); break;
+        case 18: cn_row_regs<ST, VARIANT, 18>(d, msg, lam, ebeg, b, stamp, so); break;
+        default: cn_row_generic<ST, VARIANT>(d, msg, scratch, lam, ebeg, deg, b, stamp, so); break;
+    }
+}
+
+// ------------------------------------------------------------------ VN update
+// grid: (Bp/64) x ceil(N/4) blocks of 4 waves; wave = (column, 64 codewords).
+template <typename ST>
+__global__ __launch_bounds__(256) void flood_vn_kernel(FloodDev d, const ST *__restrict__ msg,
+                                                       const ST *__restrict__ orig, ST *__restrict__ lam,
+                                                       int n, int force) {
+    using CT = typename Store<ST>::CT;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int col = blockIdx.y * 4 + wave;
+    if (col >= d.N) return;
+    const size_t b = (size_t)blockIdx.x * kWave + lane;
+    if (!force) {
+        if (d.done[b]) return;
+        if (d.unsat[b] != n + 1) { // syndrome of hard(lam_n) was zero: Orig.hs:69, return lam
+            if (col == 0) { d.done[b] = 1; d.iters[b] = n; d.conv[b] = 1; }
+            return;
+        }
+    }
+    CT acc = Store<ST>::ld(orig + (size_t)col * d.Bp + b);
+    const int qb = d.col_ptr[col], qe = d.col_ptr[col + 1];
+    for (int q = qe - 1; q >= qb; q--) { // Orig.hs:96: foldr => last row first
+        int e = d.csc_edge[q];
+        acc = Store<ST>::ld(msg + (size_t)e * d.Bp + b) + acc;
+    }
+    Store<ST>::st(lam + (size_t)col * d.Bp + b, acc);
+}
+
+// after the last turn: frames still open get the n = max_iters syndrome verdict (Orig.hs:69-70)
+__global__ void flood_finalize_kernel(FloodDev d, int max_iters) {
+    size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= (size_t)d.Bp || d.done[b]) return;
+    d.done[b] = 1;
+    d.iters[b] = max_iters;
+    d.conv[b] = (d.unsat[b] != max_iters + 1) ? 1 : 0;
+}
+
+__global__ void flood_reset_kernel(FloodDev d, int batch) {
+    size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= (size_t)d.Bp) return;
+    d.unsat[b] = 0;
+    d.iters[b] = 0;
+    d.conv[b] = 0;
+    d.done[b] = (b < (size_t)batch) ? 0 : 1; // padding lanes are born finished
+}
+
+// ------------------------------------------------------------------ layout changes
+// in [batch][N] (frame-major) -> orig, lam [N][Bp]; 64x64 tiles through LDS.
+template <typename IT, typename ST>
+__global__ __launch_bounds__(256) void load_llr_kernel(const IT *__restrict__ in, ST *__restrict__ orig,
+                                                       ST *__restrict__ lam, int batch, int N, int Bp) {
+    __shared__ float tile[64][65];
+    __shared__ double tiled[sizeof(IT) == 8 ? 64 : 1][65];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int n0 = blockIdx.x * 64, b0 = blockIdx.y * 64;
+    for (int r = ty; r < 64; r += 4) {
+        int b = b0 + r, n = n0 + tx;
+        IT v = (b < batch && n < N) ? in[(size_t)b * N + n] : IT(0);
+        if constexpr (sizeof(IT) == 8) tiled[r][tx] = v; else tile[r][tx] = v;
+    }
+    __syncthreads();
+    for (int r = ty; r < 64; r += 4) {
+        int n = n0 + r, b = b0 + tx;
+        if (n < N && b < Bp) {
+            typename Store<ST>::CT v;
+            if constexpr (sizeof(IT) == 8) v = (typename Store<ST>::CT)tiled[tx][r]; else v = (typename Store<ST>::CT)tile[tx][r];
+            Store<ST>::st(orig + (size_t)n * Bp + b, v);
+            Store<ST>::st(lam + (size_t)n * Bp + b, v);
+        }
+    }
+}
+
+// result: frames that converged output hard(lam), the others hard(orig) (Orig.hs:59,69-70);
+// bits [batch][N] bytes, optional final LLRs [batch][N] double.
+template <typename ST>
+__global__ __launch_bounds__(256) void store_bits_kernel(FloodDev d, const ST *__restrict__ orig,
+                                                         const ST *__restrict__ lam, uint8_t *__restrict__ bits,
+                                                         double *__restrict__ final_lam, int batch) {
+    __shared__ float tile[64][65];
+    __shared__ double tiled[sizeof(ST) == 8 ? 64 : 1][65];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int n0 = blockIdx.x * 64, b0 = blockIdx.y * 64;
+    for (int r = ty; r < 64; r += 4) {
+        int n = n0 + r, b = b0 + tx;
+        typename Store<ST>::CT v = 0;
+        if (n < d.N && b < d.Bp) v = Store<ST>::ld((d.conv[b] ? lam : orig) + (size_t)n * d.Bp + b);
+        if constexpr (sizeof(ST) == 8) tiled[r][tx] = v; else tile[r][tx] = v;
+    }
+    __syncthreads();
+    for (int r = ty; r < 64; r += 4) {
+        int b = b0 + r, n = n0 + tx;
+        if (b < batch && n < d.N) {
+            double v;
+            if constexpr (sizeof(ST) == 8) v = tiled[tx][r]; else v = tile[tx][r];
+            bits[(size_t)b * d.N + n] = v > 0.0 ? 1 : 0;
+            if (final_lam) final_lam[(size_t)b * d.N + n] = v;
+        }
+    }
+}
+
+// trace: lam at the top of loop turn n for frames still open -> trace[b][n][:] (double)
+template <typename ST>
+__global__ __launch_bounds__(256) void trace_store_kernel(FloodDev d, const ST *__restrict__ lam,
+                                                          double *__restrict__ trace, int n, int turns, int batch) {
+    __shared__ double tile[64][65];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int n0 = blockIdx.x * 64, b0 = blockIdx.y * 64;
+    for (int r = ty; r < 64; r += 4) {
+        int col = n0 + r, b = b0 + tx;
+        tile[r][tx] = (col < d.N && b < d.Bp) ? (double)Store<ST>::ld(lam + (size_t)col * d.Bp + b) : 0.0;
+    }
+    __syncthreads();
+    for (int r = ty; r < 64; r += 4) {
+        int b = b0 + r, col = n0 + tx;
+        if (b < batch && col < d.N && !d.done[b]) trace[((size_t)b * turns + n) * d.N + col] = tile[tx][r];
+    }
+}
+
+// generic 2-D transposing copy between frame-major double host images and batch-major device
+// arrays (debug entry points only).
+template <typename ST>
+__global__ void upload_rows_kernel(const double *__restrict__ in, ST *__restrict__ out, int batch, int R, int Bp) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; // over R*Bp, b fastest
+    if (i >= (size_t)R * Bp) return;
+    int b = (int)(i % Bp);
+    size_t r = i / Bp;
+    typename Store<ST>::CT v = (b < batch) ? (typename Store<ST>::CT)in[(size_t)b * R + r] : 0;
+    Store<ST>::st(out + i, v);
+}
+template <typename ST>
+__global__ void download_rows_kernel(const ST *__restrict__ in, double *__restrict__ out, int batch, int R, int Bp) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)R * Bp) return;
+    int b = (int)(i % Bp);
+    size_t r = i / Bp;
+    if (b < batch) out[(size_t)b * R + r] = (double)Store<ST>::ld(in + i);
+}
+__global__ void syndrome_flags_kernel(FloodDev d, uint8_t *out, int batch, int stamp) {
+    int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < batch) out[b] = d.unsat[b] != stamp ? 1 : 0;
+}
+
+// ------------------------------------------------------------------ host-side launch sequences
+#define HIPCHK(x)                                                             \
+    do {                                                                      \
+        hipError_t e_ = (x);                                                  \
+        if (e_ != hipSuccess) return set_error(LDPC_EHIP, "%s: %s", #x, hipGetErrorString(e_)); \
+    } while (0)
+
+template <typename ST, int VARIANT>
+static int run_turns(FloodState &s, hipStream_t st, int max_iters, int batch, double *d_trace) {
+    FloodDev d = s.dev;
+    ST *msg = (ST *)s.msg, *scr = (ST *)s.scratch, *lam = (ST *)s.lam, *orig = (ST *)s.orig;
+    const int slabs = d.Bp / kWave;
+    const int row_groups = (d.M + kCnWaves - 1) / kCnWaves;
+    const dim3 cn_grid(slabs * row_groups), cn_block(kWave * kCnWaves);
+    const dim3 vn_grid(slabs, (d.N + 3) / 4), vn_block(256);
+    const dim3 tr_grid((d.N + 63) / 64, (d.Bp + 63) / 64);
+    for (int n = 0; n < max_iters; n++) {
+        if (d_trace) hipLaunchKernelGGL((trace_store_kernel<ST>), tr_grid, dim3(256), 0, st, d, lam, d_trace, n, max_iters + 1, batch);
+        hipLaunchKernelGGL((flood_cn_kernel<ST, VARIANT>), cn_grid, cn_block, 0, st, d, msg, scr, lam, n + 1, 0, 0);
+        hipLaunchKernelGGL((flood_vn_kernel<ST>), vn_grid, vn_block, 0, st, d, msg, orig, lam, n, 0);
+    }
+    if (d_trace) hipLaunchKernelGGL((trace_store_kernel<ST>), tr_grid, dim3(256), 0, st, d, lam, d_trace, max_iters, max_iters + 1, batch);
+    hipLaunchKernelGGL((flood_cn_kernel<ST, VARIANT>), cn_grid, cn_block, 0, st, d, msg, scr, lam, max_iters + 1, 1, 0);
+    hipLaunchKernelGGL(flood_finalize_kernel, dim3((d.Bp + 255) / 256), dim3(256), 0, st, d, max_iters);
+    HIPCHK(hipGetLastError());
+    return LDPC_OK;
+}
+
+template <typename ST, int VARIANT>
+static int decode_impl(FloodState &s, hipStream_t st, int max_iters, int batch, const void *d_llr,
+                       int llr_is_f64, uint8_t *d_bits, double *d_final, double *d_trace) {
+    FloodDev d = s.dev;
+    hipLaunchKernelGGL(flood_reset_kernel, dim3((d.Bp + 255) / 256), dim3(256), 0, st, d, batch);
+    HIPCHK(hipMemsetAsync(s.msg, 0, (size_t)d.E * d.Bp * sizeof(ST), st)); // Orig.hs:64-65 orig_ne = 0
+    const dim3 tgrid((d.N + 63) / 64, (d.Bp + 63) / 64);
+    if (llr_is_f64)
+        hipLaunchKernelGGL((load_llr_kernel<double, ST>), tgrid, dim3(256), 0, st, (const double *)d_llr, (ST *)s.orig, (ST *)s.lam, batch, d.N, d.Bp);
+    else
+        hipLaunchKernelGGL((load_llr_kernel<float, ST>), tgrid, dim3(256), 0, st, (const float *)d_llr, (ST *)s.orig, (ST *)s.lam, batch, d.N, d.Bp);
+    int rc = run_turns<ST, VARIANT>(s, st, max_iters, batch, d_trace);
+    if (rc != LDPC_OK) return rc;
+    hipLaunchKernelGGL((store_bits_kernel<ST>), tgrid, dim3(256), 0, st, d, (const ST *)s.orig, (const ST *)s.lam, d_bits, d_final, batch);
+    HIPCHK(hipGetLastError());
+    return LDPC_OK;
+}
+
+template <typename ST, int VARIANT>
+static int step_impl(FloodState &s, hipStream_t st, int batch, const double *d_orig, const double *d_lam,
+                     const double *d_ne, double *d_ne_out, double *d_lam_out, uint8_t *d_syn) {
+    FloodDev d = s.dev;
+    ST *msg = (ST *)s.msg, *scr = (ST *)s.scratch, *lam = (ST *)s.lam, *orig = (ST *)s.orig;
+    hipLaunchKernelGGL(flood_reset_kernel, dim3((d.Bp + 255) / 256), dim3(256), 0, st, d, batch);
+    auto blocks = [&](size_t n) { return dim3((unsigned)((n + 255) / 256)); };
+    hipLaunchKernelGGL((upload_rows_kernel<ST>), blocks((size_t)d.N * d.Bp), dim3(256), 0, st, d_orig, orig, batch, d.N, d.Bp);
+    hipLaunchKernelGGL((upload_rows_kernel<ST>), blocks((size_t)d.N * d.Bp), dim3(256), 0, st, d_lam, lam, batch, d.N, d.Bp);
+    hipLaunchKernelGGL((upload_rows_kernel<ST>), blocks((size_t)d.E * d.Bp), dim3(256), 0, st, d_ne, msg, batch, d.E, d.Bp);
+    const int slabs = d.Bp / kWave;
+    const int row_groups = (d.M + kCnWaves - 1) / kCnWaves;
+    hipLaunchKernelGGL((flood_cn_kernel<ST, VARIANT>), dim3(slabs * row_groups), dim3(kWave * kCnWaves), 0, st, d, msg, scr, lam, 1, 0, 1);
+    hipLaunchKernelGGL((flood_vn_kernel<ST>), dim3(slabs, (d.N + 3) / 4), dim3(256), 0, st, d, msg, orig, lam, 0, 1);
+    hipLaunchKernelGGL((download_rows_kernel<ST>), blocks((size_t)d.E * d.Bp), dim3(256), 0, st, msg, d_ne_out, batch, d.E, d.Bp);
+    hipLaunchKernelGGL((download_rows_kernel<ST>), blocks((size_t)d.N * d.Bp), dim3(256), 0, st, lam, d_lam_out, batch, d.N, d.Bp);
+    hipLaunchKernelGGL(syndrome_flags_kernel, dim3((batch + 255) / 256), dim3(256), 0, st, d, d_syn, batch, 1);
+    HIPCHK(hipGetLastError());
+    return LDPC_OK;
+}
+
+#define DISPATCH(FN, ...)                                                                   \
+    switch (s.dtype) {                                                                      \
+        case LDPC_F32: return s.variant == LDPC_MINSUM ? FN<float, LDPC_V_MINSUM>(__VA_ARGS__) : FN<float, LDPC_V_TANH>(__VA_ARGS__);   \
+        case LDPC_F64: return s.variant == LDPC_MINSUM ? FN<double, LDPC_V_MINSUM>(__VA_ARGS__) : FN<double, LDPC_V_TANH>(__VA_ARGS__); \
+        case LDPC_F16: return s.variant == LDPC_MINSUM ? FN<__half, LDPC_V_MINSUM>(__VA_ARGS__) : FN<__half, LDPC_V_TANH>(__VA_ARGS__); \
+        default: return set_error(LDPC_EINVAL, "bad dtype %d", s.dtype);                    \
+    }
+
+int flood_decode(FloodState &s, hipStream_t st, int max_iters, int batch, const void *d_llr, int llr_is_f64,
+                 uint8_t *d_bits, double *d_final, double *d_trace) {
+    DISPATCH(decode_impl, s, st, max_iters, batch, d_llr, llr_is_f64, d_bits, d_final, d_trace)
+}
+int flood_step(FloodState &s, hipStream_t st, int batch, const double *d_orig, const double *d_lam,
+               const double *d_ne, double *d_ne_out, double *d_lam_out, uint8_t *d_syn) {
+    DISPATCH(step_impl, s, st, batch, d_orig, d_lam, d_ne, d_ne_out, d_lam_out, d_syn)
+}
+
+size_t flood_elem_size(int dtype) { return dtype == LDPC_F64 ? 8 : (dtype == LDPC_F16 ? 2 : 4); }
+
+}  // namespace ldpc

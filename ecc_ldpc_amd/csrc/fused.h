@@ -1,0 +1,17 @@
+// fused.h -- interface of the fused on-chip decoder (fused.hip): one launch decodes a batch,
+// all BP state stays in LDS/registers between iterations.
+#pragma once
+#include "internal.h"
+
+namespace ldpc {
+struct FusedState;
+bool fused_supported(const ldpc_code &code, int variant, int dtype);
+const char *fused_why_not(const ldpc_code &code, int variant, int dtype);
+FusedState *fused_create(const ldpc_code &code, int variant, int dtype, int max_batch);
+void fused_destroy(FusedState *s);
+// d_llr [batch][N] float32/float64; outputs may be null except d_bits
+int fused_decode(FusedState &s, hipStream_t st, int max_iters, int batch, const void *d_llr, int llr_is_f64,
+                 uint8_t *d_bits, int32_t *d_iters, uint8_t *d_conv, double *d_final, double *d_trace);
+int fused_step(FusedState &s, hipStream_t st, int batch, const double *d_orig, const double *d_lam,
+               const double *d_ne, double *d_ne_out, double *d_lam_out, uint8_t *d_syn);
+}  // namespace ldpc

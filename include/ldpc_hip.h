@@ -1,0 +1,140 @@
+/*
+ * ldpc_hip.h -- C ABI of libldpc_hip.so: the MI355X (gfx950) LDPC belief-propagation decoder
+ * that replaces the decoder slot of ku-fpg/ecc-ldpc's `Code`/`ECC` record.
+ *
+ * Every entry point names the reference interface it replaces (paths relative to the
+ * reference repository).  The Haskell side keeps its contract: a plug-in is a `Code` built by
+ *   mkLDPC_CodeIO name maxThreadCount encoder decoder initialize finalize
+ *                                                   (src/ECC/Code/LDPC/Utils.hs:91-108)
+ * and everything the CUDA plug-ins do behind that record -- loadFile ptx, getFun, mallocArray,
+ * launchKernel, peekListArray (src/ECC/Code/LDPC/GPU/CUDA/Arraylet2.hs:88-297) -- lives behind
+ * this header instead.  INTEGRATION.md shows the `foreign import ccall` binding.
+ *
+ * Conventions
+ *   - plain C types only; no C++ exception crosses the ABI.
+ *   - every `int` function returns LDPC_OK (0) or a negative LDPC_E* code; the message for the
+ *     last failure on the calling thread is ldpc_last_error().
+ *   - pointer-returning functions return NULL on failure (message in ldpc_last_error()).
+ *   - LLR sign convention of the reference: LLR > 0 <=> bit 1 (`hard x = x > 0`,
+ *     src/ECC/Code/LDPC/GPU/Reference.hs:59-60, cudabits/common.h:180-182).
+ *   - decoder semantics are exactly the loop of src/ECC/Code/LDPC/Reference/Orig.hs:67-71:
+ *     (1) syndrome of hard(lam) zero -> return lam; (2) n >= max_iters -> return the CHANNEL
+ *     LLRs (orig_lam); (3) otherwise update.  So bits = hard(lam_n) for a frame that converged
+ *     after n updates and hard(channel LLR) for one that did not.
+ *   - a context is NOT thread-safe: one ldpc_ctx per calling thread (the reference's CUDA
+ *     plug-ins keep mutable device buffers in the closure the same way, Arraylet2.hs:61,118-144).
+ */
+#ifndef LDPC_HIP_H
+#define LDPC_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LDPC_OK 0
+#define LDPC_EINVAL (-1)       /* bad argument */
+#define LDPC_ENOMEM (-2)       /* host or device allocation failed */
+#define LDPC_EHIP (-3)         /* a HIP runtime call failed (message has the HIP error string) */
+#define LDPC_ENODEVICE (-4)    /* no usable gfx950 device / ldpc_init not called */
+#define LDPC_EUNSUPPORTED (-5) /* valid request this build has no kernel for */
+#define LDPC_EDEGREE (-6)      /* min-sum on a degree-1 check row (Haskell: foldr1 on [], Min.hs:79) */
+#define LDPC_EFORMAT (-7)      /* matrix file does not parse */
+#define LDPC_ENOTFOUND (-8)    /* matrix file / code name not found */
+
+typedef struct ldpc_code ldpc_code; /* immutable parity-check graph, host + device tables */
+typedef struct ldpc_ctx ldpc_ctx;   /* one decoder replica: device buffers + stream          */
+
+/* check-node rule.  LDPC_TANH: Reference/Orig.hs:81-92 ; LDPC_MINSUM: Reference/Min.hs:75-87 */
+typedef enum { LDPC_TANH = 0, LDPC_MINSUM = 1 } ldpc_variant;
+/* arithmetic / storage type of LLRs and messages on the device.
+ * F32: the cudabits kernels' `typedef float float_ty` (cudabits/common.h:1).
+ * F64: parity mode, same type as the CPU reference (Double).
+ * F16: fp16 storage of messages/LLRs in HBM, fp32 arithmetic (BASELINE.json configs[3]). */
+typedef enum { LDPC_F32 = 0, LDPC_F64 = 1, LDPC_F16 = 2 } ldpc_dtype;
+/* which kernel family a context uses */
+typedef enum {
+    LDPC_PATH_AUTO = 0,  /* fused on-chip kernel when the code/variant/dtype has one, else flood */
+    LDPC_PATH_FLOOD = 1, /* generic two-kernels-per-iteration path, state in HBM, any H          */
+    LDPC_PATH_FUSED = 2  /* whole decode in one launch, state in LDS/registers (QC codes)        */
+} ldpc_path;
+
+/* ---- library life-cycle -------------------------------------------------------------------
+ * replaces  initialize :: IO CudaAllocations  (GPU/CUDA/Arraylet2.hs:287-293: dummy malloc to
+ * create the context + loadFile "cudabits/arraylet2.ptx") and finalize (:295-297).          */
+int ldpc_init(int device);          /* idempotent; selects the HIP device for the calling thread */
+int ldpc_shutdown(void);
+const char *ldpc_last_error(void);  /* thread-local, never NULL */
+int ldpc_last_error_code(void);     /* the LDPC_E* code that message belongs to (0 if none yet) */
+int ldpc_abi_version(void);         /* bumps when a signature in this header changes */
+int ldpc_device_count(void);        /* HIP devices visible; 0 when there is no GPU (no error) */
+
+/* ---- graph ---------------------------------------------------------------------------------
+ * replaces initMatrixlet (GPU/CUDA/Arraylet2.hs:299-331): the quasi-cyclic H as circulant size
+ * + a block_rows x block_cols table of rotations, -1 = empty block.  Rotation `off` at block
+ * (br,bc) means row r of the block has its 1 at column (r+off) mod sz
+ * (src/Data/Matrix/QuasiCyclic.hs:19-25, Fast/Arraylet.hs:34-43).  The library copies `offsets`. */
+ldpc_code *ldpc_code_create_qc(int sz, int block_rows, int block_cols, const int32_t *offsets);
+/* any H as CSR (what `Matrix Bool` decoders take, Reference/Orig.hs:30): row_ptr[M+1],
+ * col_idx[E] strictly ascending inside each row.  The library copies both arrays. */
+ldpc_code *ldpc_code_create_csr(int M, int N, const int32_t *row_ptr, const int32_t *col_idx);
+void ldpc_code_destroy(ldpc_code *code);
+/* M = checks, N = unpunctured code length (cols H), E = edges */
+int ldpc_code_dims(const ldpc_code *code, int *M, int *N, int *E);
+/* the CSR edge order the library uses for every per-edge array it exposes (debug entry points):
+ * row-major, ascending column inside a row == the order of Orig.hs:86-91.  Arrays caller-owned. */
+int ldpc_code_csr(const ldpc_code *code, int32_t *row_ptr /*M+1*/, int32_t *col_idx /*E*/);
+
+/* ---- decoder replica -------------------------------------------------------------------------
+ * replaces one `decoder vars h` call (Utils.hs:53 replicateM maxThreadCount; Arraylet2.hs:88-144:
+ * getFun x9, mallocArray of mLet/newMLet/lam/orig_lam/done, Stream.create).  Owns its device
+ * buffers and one HIP stream; sized for frames <= max_batch per call. */
+ldpc_ctx *ldpc_ctx_create(const ldpc_code *code, int variant, int dtype, int max_batch);
+ldpc_ctx *ldpc_ctx_create_ex(const ldpc_code *code, int variant, int dtype, int max_batch, int path);
+void ldpc_ctx_destroy(ldpc_ctx *ctx);
+/* LDPC_PATH_FLOOD or LDPC_PATH_FUSED: what the context resolved to */
+int ldpc_ctx_path(const ldpc_ctx *ctx);
+
+/* ---- decode ------------------------------------------------------------------------------------
+ * ldpc_decode_one replaces the per-frame closure
+ *   Rate -> Int -> U.Vector Double -> IO (Maybe (U.Vector Bool))     (Arraylet2.hs:151-273)
+ * llr: N doubles, already un-punctured (zeros appended, Utils.hs:55,69).  bits: N bytes 0/1.
+ * A non-zero return is the closure's `Nothing` (Utils.hs:70-71). Blocking. */
+int ldpc_decode_one(ldpc_ctx *ctx, int max_iters, const double *llr, uint8_t *bits, int *iters,
+                    int *converged);
+/* throughput path, host buffers: llr [batch][N] float32 frame-major, bits [batch][N] bytes,
+ * iters [batch] (updates run, = max_iters for a non-converged frame), converged [batch].
+ * iters / converged may be NULL.  Blocking. */
+int ldpc_decode_batch(ldpc_ctx *ctx, int max_iters, int batch, const float *llr, uint8_t *bits,
+                      int32_t *iters, uint8_t *converged);
+/* same with float64 LLRs in and (optionally) the returned LLR vector out -- `lam` of the frame
+ * that converged, the channel LLRs otherwise (what Orig.hs:69-70 returns before `map hard`).
+ * final_lam may be NULL. */
+int ldpc_decode_batch_f64(ldpc_ctx *ctx, int max_iters, int batch, const double *llr, uint8_t *bits,
+                          int32_t *iters, uint8_t *converged, double *final_lam);
+/* zero-copy path: every pointer is DEVICE memory on the context's device.  d_llr [batch][N]
+ * float32; d_bits [batch][N] bytes; d_iters, d_converged may be NULL.  Work is enqueued on
+ * `stream` (a hipStream_t; NULL = the context's own stream) and NOT synchronised. */
+int ldpc_decode_batch_dev(ldpc_ctx *ctx, int max_iters, int batch, const float *d_llr,
+                          uint8_t *d_bits, int32_t *d_iters, uint8_t *d_converged, void *stream);
+/* wait for everything enqueued on the context's stream */
+int ldpc_ctx_synchronize(ldpc_ctx *ctx);
+
+/* ---- verification entry points (used by tests/; not needed by a harness) ------------------------
+ * One teacher-forced update on the device in the context's dtype: from the state (lam, ne) at
+ * the top of loop turn n produce (ne', lam') exactly as Orig.hs:81-98 / Min.hs:75-104 would, and
+ * report whether the syndrome of hard(lam) is zero (Orig.hs:73-78).  All arrays host, float64,
+ * frame-major: orig/lam/lam_out [batch][N], ne/ne_out [batch][E] in ldpc_code_csr edge order. */
+int ldpc_debug_step(ldpc_ctx *ctx, int batch, const double *orig, const double *lam, const double *ne,
+                    double *ne_out, double *lam_out, uint8_t *syndrome_zero);
+/* free-running decode that also returns lam at the top of every loop turn:
+ * trace_lam [batch][max_iters+1][N] float64 (turns after a frame stopped are zero-filled). */
+int ldpc_decode_trace(ldpc_ctx *ctx, int max_iters, int batch, const double *llr, uint8_t *bits,
+                      int32_t *iters, uint8_t *converged, double *trace_lam);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LDPC_HIP_H */

@@ -1,0 +1,155 @@
+"""ctypes front-end of oracle/ldpc_oracle.c.  TEST INFRASTRUCTURE ONLY -- importable from tests/,
+__graft_entry__.smoke() and bench.py's cpu_baseline leg, never from ecc_ldpc_amd/."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "_build", "libldpc_oracle.so")
+TANH, MINSUM = 0, 1
+_lib = None
+
+
+def build(force: bool = False) -> str:
+    src = os.path.join(_HERE, "ldpc_oracle.c")
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-s", "-C", _HERE, "all"])
+    return _SO
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_SO):
+            build()
+        L = C.CDLL(_SO)
+        i32p, f64p, u8p = C.POINTER(C.c_int32), C.POINTER(C.c_double), C.POINTER(C.c_uint8)
+        ip = C.POINTER(C.c_int)
+        L.oracle_decode.argtypes = [C.c_int, C.c_int, i32p, i32p, C.c_int, C.c_int, f64p, u8p, ip, ip, f64p, f64p, f64p]
+        L.oracle_decode_dense.argtypes = [C.c_int, C.c_int, u8p, C.c_int, C.c_int, f64p, u8p, ip, ip, f64p]
+        L.oracle_step.argtypes = [C.c_int, C.c_int, i32p, i32p, C.c_int, f64p, f64p, f64p, f64p, f64p, ip]
+        L.oracle_decode_batch.argtypes = [C.c_int, C.c_int, i32p, i32p, C.c_int, C.c_int, C.c_int, f64p, u8p, i32p, u8p, C.c_int]
+        L.oracle_encode_dense.argtypes = [C.c_int, C.c_int, u8p, u8p, u8p]
+        L.oracle_encode_qc.argtypes = [C.c_int, C.c_int, C.c_int, u8p, u8p, u8p]
+        _lib = L
+    return _lib
+
+
+def _p(a, t):
+    return a.ctypes.data_as(C.POINTER(t)) if a is not None else None
+
+
+def _variant(v):
+    if v in (TANH, "tanh"):
+        return TANH
+    if v in (MINSUM, "min", "minsum", "min-sum"):
+        return MINSUM
+    raise ValueError(v)
+
+
+class Graph:
+    def __init__(self, row_ptr, col_idx, N):
+        self.row_ptr = np.ascontiguousarray(row_ptr, dtype=np.int32)
+        self.col_idx = np.ascontiguousarray(col_idx, dtype=np.int32)
+        self.M = len(self.row_ptr) - 1
+        self.N = int(N)
+        self.E = int(self.row_ptr[-1])
+
+    @classmethod
+    def from_dense(cls, H):
+        from .formats import dense_to_csr
+        rp, ci = dense_to_csr(np.asarray(H))
+        return cls(rp, ci, H.shape[1])
+
+
+def decode(g: Graph, variant, max_iters, llr, trace=False):
+    """-> dict(bits, iters, converged, lam[, trace_lam (iters+1,N), trace_ne (iters,E)])"""
+    llr = np.ascontiguousarray(llr, dtype=np.float64)
+    assert llr.shape == (g.N,)
+    bits = np.zeros(g.N, np.uint8)
+    it, cv = C.c_int(0), C.c_int(0)
+    lam = np.zeros(g.N, np.float64)
+    tl = np.zeros((max_iters + 1, g.N), np.float64) if trace else None
+    tn = np.zeros((max(max_iters, 1), g.E), np.float64) if trace else None
+    rc = lib().oracle_decode(g.M, g.N, _p(g.row_ptr, C.c_int32), _p(g.col_idx, C.c_int32), _variant(variant),
+                             int(max_iters), _p(llr, C.c_double), _p(bits, C.c_uint8), C.byref(it), C.byref(cv),
+                             _p(lam, C.c_double), _p(tl, C.c_double), _p(tn, C.c_double))
+    if rc != 0:
+        raise RuntimeError(f"oracle_decode rc={rc}")
+    out = dict(bits=bits, iters=it.value, converged=bool(cv.value), lam=lam)
+    if trace:
+        out["trace_lam"] = tl[: it.value + 1]
+        out["trace_ne"] = tn[: it.value]
+    return out
+
+
+def decode_dense(H, variant, max_iters, llr, trace=False):
+    H = np.ascontiguousarray(H, dtype=np.uint8)
+    M, N = H.shape
+    llr = np.ascontiguousarray(llr, dtype=np.float64)
+    bits = np.zeros(N, np.uint8)
+    it, cv = C.c_int(0), C.c_int(0)
+    tl = np.zeros((max_iters + 1, N), np.float64) if trace else None
+    rc = lib().oracle_decode_dense(M, N, _p(H, C.c_uint8), _variant(variant), int(max_iters), _p(llr, C.c_double),
+                                   _p(bits, C.c_uint8), C.byref(it), C.byref(cv), _p(tl, C.c_double))
+    if rc != 0:
+        raise RuntimeError(f"oracle_decode_dense rc={rc}")
+    out = dict(bits=bits, iters=it.value, converged=bool(cv.value))
+    if trace:
+        out["trace_lam"] = tl[: it.value + 1]
+    return out
+
+
+def step(g: Graph, variant, orig, lam, ne):
+    orig = np.ascontiguousarray(orig, np.float64)
+    lam = np.ascontiguousarray(lam, np.float64)
+    ne = np.ascontiguousarray(ne, np.float64)
+    ne2 = np.zeros(g.E, np.float64)
+    lam2 = np.zeros(g.N, np.float64)
+    sz = C.c_int(0)
+    rc = lib().oracle_step(g.M, g.N, _p(g.row_ptr, C.c_int32), _p(g.col_idx, C.c_int32), _variant(variant),
+                           _p(orig, C.c_double), _p(lam, C.c_double), _p(ne, C.c_double), _p(ne2, C.c_double),
+                           _p(lam2, C.c_double), C.byref(sz))
+    if rc != 0:
+        raise RuntimeError(f"oracle_step rc={rc}")
+    return ne2, lam2, bool(sz.value)
+
+
+def decode_batch(g: Graph, variant, max_iters, llr, nthreads=1):
+    llr = np.ascontiguousarray(llr, dtype=np.float64)
+    F = llr.shape[0]
+    assert llr.shape == (F, g.N)
+    bits = np.zeros((F, g.N), np.uint8)
+    iters = np.zeros(F, np.int32)
+    conv = np.zeros(F, np.uint8)
+    rc = lib().oracle_decode_batch(g.M, g.N, _p(g.row_ptr, C.c_int32), _p(g.col_idx, C.c_int32), _variant(variant),
+                                   int(max_iters), F, _p(llr, C.c_double), _p(bits, C.c_uint8), _p(iters, C.c_int32),
+                                   _p(conv, C.c_uint8), int(nthreads))
+    if rc != 0:
+        raise RuntimeError(f"oracle_decode_batch rc={rc}")
+    return bits, iters, conv
+
+
+def encode_dense(G, msg):
+    G = np.ascontiguousarray(G, np.uint8)
+    msg = np.ascontiguousarray(msg, np.uint8)
+    k, p = G.shape
+    par = np.zeros(p, np.uint8)
+    rc = lib().oracle_encode_dense(k, p, _p(G, C.c_uint8), _p(msg, C.c_uint8), _p(par, C.c_uint8))
+    assert rc == 0
+    return par
+
+
+def encode_qc(sz, gbits, msg):
+    gbits = np.ascontiguousarray(gbits, np.uint8)
+    R, Cc, s = gbits.shape
+    assert s == sz
+    msg = np.ascontiguousarray(msg, np.uint8)
+    par = np.zeros(Cc * sz, np.uint8)
+    rc = lib().oracle_encode_qc(sz, R, Cc, _p(gbits, C.c_uint8), _p(msg, C.c_uint8), _p(par, C.c_uint8))
+    assert rc == 0
+    return par

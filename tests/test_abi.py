@@ -1,0 +1,51 @@
+"""CPU: the C-ABI library loads, exports every symbol include/ldpc_hip.h declares, builds graphs on
+the host, and FAILS LOUDLY (no fallback) when no GPU is bound."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+import ecc_ldpc_amd as E
+from tests.helpers import ROOT, load
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "ldpc_hip.h")).read()
+    declared = set(re.findall(r"\b(ldpc_[a-z0-9_]+)\s*\(", hdr)) - {"ldpc_code", "ldpc_ctx"}
+    assert declared == set(E.ABI_SYMBOLS), declared ^ set(E.ABI_SYMBOLS)
+    L = ctypes.CDLL(E.SO_PATH)
+    for s in declared:
+        assert hasattr(L, s), s
+    assert E.lib().ldpc_abi_version() == 1
+
+
+def test_qc_graph_expansion_matches_oracle_parser():
+    for name in ("jpl.1024.4.5", "jpl.4096.4.5"):
+        c = load(name)
+        code = c.hip_code(E)
+        assert (code.M, code.N, code.E) == (c.M, c.N, c.E)
+        rp, ci = code.csr()
+        assert np.array_equal(rp, c.graph.row_ptr) and np.array_equal(ci, c.graph.col_idx)
+
+
+def test_csr_validation():
+    with pytest.raises(E.LdpcError) as e:
+        E.Code.from_csr([0, 2], [1, 1], 3)  # not strictly ascending
+    assert e.value.code == -1
+    with pytest.raises(E.LdpcError):
+        E.Code.from_csr([0, 1], [5], 3)  # column out of range
+    with pytest.raises(E.LdpcError):
+        E.Code.from_qc(8, np.array([[9]]))  # rotation >= sz
+
+
+@pytest.mark.skipif(E.lib().ldpc_device_count() > 0, reason="this check is for GPU-less hosts")
+def test_no_gpu_means_error_not_fallback():
+    with pytest.raises(E.LdpcError) as e:
+        E.init(0)
+    assert e.value.code == -4
+    c = load("moon.7.13").hip_code(E)
+    with pytest.raises(E.LdpcError) as e:
+        E.Decoder(c, "min", "f32", 4)
+    assert e.value.code == -4

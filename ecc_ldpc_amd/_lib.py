@@ -22,6 +22,13 @@ ABI_SYMBOLS = [
     "ldpc_ctx_create", "ldpc_ctx_create_ex", "ldpc_ctx_destroy", "ldpc_ctx_path", "ldpc_ctx_synchronize",
     "ldpc_decode_one", "ldpc_decode_batch", "ldpc_decode_batch_f64", "ldpc_decode_batch_dev",
     "ldpc_debug_step", "ldpc_decode_trace",
+    "ldpc_ctx_set_timing", "ldpc_ctx_kernel_time", "ldpc_ctx_kernel_name",
+    "ldpc_sim_create", "ldpc_sim_destroy", "ldpc_sim_generate", "ldpc_sim_tally", "ldpc_sim_encode_host",
+    "ldpc_matrix_load", "ldpc_matrix_load_mackay", "ldpc_matrix_destroy", "ldpc_matrix_info", "ldpc_matrix_dense",
+    "ldpc_matrix_qc_offsets", "ldpc_code_from_matrix",
+    "ldpc_ecc_create", "ldpc_ecc_destroy", "ldpc_ecc_name", "ldpc_ecc_message_length", "ldpc_ecc_codeword_length",
+    "ldpc_ecc_unpunctured_length", "ldpc_ecc_max_iters", "ldpc_ecc_encode", "ldpc_ecc_decode", "ldpc_ecc_ctx",
+    "ldpc_ecc_sim", "ldpc_ecc_code",
 ]
 
 
@@ -67,6 +74,44 @@ def lib():
     L.ldpc_decode_batch_dev.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp, vp, vp]
     L.ldpc_debug_step.argtypes = [vp, C.c_int, f64p, f64p, f64p, f64p, f64p, u8p]
     L.ldpc_decode_trace.argtypes = [vp, C.c_int, C.c_int, f64p, u8p, i32p, u8p, f64p]
+    L.ldpc_ctx_set_timing.argtypes = [vp, C.c_int]
+    L.ldpc_ctx_kernel_time.argtypes = [vp, ip, f64p]
+    L.ldpc_ctx_kernel_name.restype = C.c_char_p
+    L.ldpc_ctx_kernel_name.argtypes = [vp]
+    L.ldpc_sim_create.restype = vp
+    L.ldpc_sim_create.argtypes = [vp, C.c_int, C.c_int, C.c_int, u8p, C.c_int]
+    L.ldpc_sim_destroy.restype = None
+    L.ldpc_sim_destroy.argtypes = [vp]
+    L.ldpc_sim_generate.argtypes = [vp, C.c_uint64, C.c_uint64, C.c_int, C.c_double, vp, vp, vp]
+    L.ldpc_sim_tally.argtypes = [vp, C.c_int, vp, vp, vp, vp]
+    L.ldpc_sim_encode_host.argtypes = [vp, u8p, u8p]
+    L.ldpc_matrix_load.restype = vp
+    L.ldpc_matrix_load.argtypes = [C.c_char_p, C.c_char_p]
+    L.ldpc_matrix_load_mackay.restype = vp
+    L.ldpc_matrix_load_mackay.argtypes = [C.c_char_p]
+    L.ldpc_matrix_destroy.restype = None
+    L.ldpc_matrix_destroy.argtypes = [vp]
+    L.ldpc_matrix_info.argtypes = [vp, ip, ip, ip, ip, ip]
+    L.ldpc_matrix_dense.argtypes = [vp, u8p]
+    L.ldpc_matrix_qc_offsets.argtypes = [vp, i32p]
+    L.ldpc_code_from_matrix.restype = vp
+    L.ldpc_code_from_matrix.argtypes = [vp]
+    L.ldpc_ecc_create.restype = vp
+    L.ldpc_ecc_create.argtypes = [C.c_char_p, C.c_char_p, C.c_int]
+    L.ldpc_ecc_destroy.restype = None
+    L.ldpc_ecc_destroy.argtypes = [vp]
+    L.ldpc_ecc_name.restype = C.c_char_p
+    L.ldpc_ecc_name.argtypes = [vp]
+    for f in ("message_length", "codeword_length", "unpunctured_length", "max_iters"):
+        getattr(L, "ldpc_ecc_" + f).argtypes = [vp]
+    L.ldpc_ecc_encode.argtypes = [vp, u8p, u8p]
+    L.ldpc_ecc_decode.argtypes = [vp, f64p, u8p, ip]
+    L.ldpc_ecc_ctx.restype = vp
+    L.ldpc_ecc_ctx.argtypes = [vp]
+    L.ldpc_ecc_sim.restype = vp
+    L.ldpc_ecc_sim.argtypes = [vp]
+    L.ldpc_ecc_code.restype = vp
+    L.ldpc_ecc_code.argtypes = [vp]
     _lib = L
     return L
 
@@ -96,10 +141,11 @@ _PATHS = {"auto": PATH_AUTO, "flood": PATH_FLOOD, "fused": PATH_FUSED, 0: 0, 1: 
 class Code:
     """Parity-check graph handle (ldpc_code)."""
 
-    def __init__(self, handle):
+    def __init__(self, handle, owned=True):
         if not handle:
             raise LdpcError(lib().ldpc_last_error_code(), last_error())
         self._h = handle
+        self._owned = owned
         M, N, E = C.c_int(), C.c_int(), C.c_int()
         check(lib().ldpc_code_dims(self._h, C.byref(M), C.byref(N), C.byref(E)))
         self.M, self.N, self.E = M.value, N.value, E.value
@@ -131,10 +177,14 @@ class Code:
         check(lib().ldpc_code_csr(self._h, ptr(rp, C.c_int32), ptr(ci, C.c_int32)))
         return rp, ci
 
+    @classmethod
+    def from_matrix(cls, matrix: "Matrix"):
+        return cls(lib().ldpc_code_from_matrix(matrix._h))
+
     def close(self):
-        if self._h:
+        if self._h and self._owned:
             lib().ldpc_code_destroy(self._h)
-            self._h = None
+        self._h = None
 
     def __del__(self):
         try:
@@ -146,10 +196,12 @@ class Code:
 class Decoder:
     """One decoder replica (ldpc_ctx): the object behind the reference's per-frame closure."""
 
-    def __init__(self, code: Code, variant="min", dtype="f32", max_batch=64, path="auto"):
+    def __init__(self, code: Code, variant="min", dtype="f32", max_batch=64, path="auto", _handle=None):
         self.code = code
         self.max_batch = int(max_batch)
-        self._h = lib().ldpc_ctx_create_ex(code._h, _VARIANTS[variant], _DTYPES[dtype], int(max_batch), _PATHS[path])
+        self._owned = _handle is None
+        self._h = _handle if _handle is not None else lib().ldpc_ctx_create_ex(
+            code._h, _VARIANTS[variant], _DTYPES[dtype], int(max_batch), _PATHS[path])
         if not self._h:
             raise LdpcError(lib().ldpc_last_error_code(), last_error())
         self.path = {PATH_FLOOD: "flood", PATH_FUSED: "fused"}[lib().ldpc_ctx_path(self._h)]
@@ -207,9 +259,152 @@ class Decoder:
         check(lib().ldpc_debug_step(self._h, F, ptr(orig, C.c_double), ptr(lam, C.c_double), ptr(ne, C.c_double), ptr(ne2, C.c_double), ptr(lam2, C.c_double), ptr(syn, C.c_uint8)))
         return ne2, lam2, syn.astype(bool)
 
+    def set_timing(self, enabled=True):
+        check(lib().ldpc_ctx_set_timing(self._h, int(bool(enabled))))
+
+    def kernel_time(self):
+        """-> (launches, total_ms) of the dominant kernel since the last call (HIP events)."""
+        n, ms = C.c_int(), C.c_double()
+        check(lib().ldpc_ctx_kernel_time(self._h, C.byref(n), C.byref(ms)))
+        return n.value, ms.value
+
+    @property
+    def kernel_name(self):
+        return lib().ldpc_ctx_kernel_name(self._h).decode()
+
+    def close(self):
+        if self._h and self._owned:
+            lib().ldpc_ctx_destroy(self._h)
+        self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Matrix:
+    """A loaded matrix file (ldpc_matrix): the reference's LoaderMatrix (Data/BitMatrix/Loader.hs:49-52)."""
+
+    def __init__(self, handle):
+        if not handle:
+            raise LdpcError(lib().ldpc_last_error_code(), last_error())
+        self._h = handle
+        v = [C.c_int() for _ in range(5)]
+        check(lib().ldpc_matrix_info(self._h, *[C.byref(x) for x in v]))
+        self.rows, self.cols, self.sz, self.block_rows, self.block_cols = [x.value for x in v]
+
+    @classmethod
+    def load(cls, codes_dir, name):
+        return cls(lib().ldpc_matrix_load(str(codes_dir).encode(), name.encode()))
+
+    @classmethod
+    def load_mackay(cls, path):
+        return cls(lib().ldpc_matrix_load_mackay(str(path).encode()))
+
+    def dense(self):
+        out = np.zeros((self.rows, self.cols), np.uint8)
+        check(lib().ldpc_matrix_dense(self._h, ptr(out, C.c_uint8)))
+        return out
+
+    def qc_offsets(self):
+        out = np.zeros((self.block_rows, self.block_cols), np.int32)
+        check(lib().ldpc_matrix_qc_offsets(self._h, ptr(out, C.c_int32)))
+        return out
+
     def close(self):
         if self._h:
-            lib().ldpc_ctx_destroy(self._h)
+            lib().ldpc_matrix_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Sim:
+    """Device-side frame source + error tally (ldpc_sim)."""
+
+    def __init__(self, code: Code, k, n_tx, G=None, max_batch=64, _handle=None):
+        self.code, self.k, self.n_tx = code, int(k), int(n_tx)
+        self._owned = _handle is None
+        if _handle is None:
+            if G is not None:
+                G = np.ascontiguousarray(G, np.uint8)
+                assert G.shape[0] == k
+                _handle = lib().ldpc_sim_create(code._h, int(k), int(n_tx), G.shape[1], ptr(G, C.c_uint8), int(max_batch))
+            else:
+                _handle = lib().ldpc_sim_create(code._h, int(k), int(n_tx), 0, None, int(max_batch))
+        if not _handle:
+            raise LdpcError(lib().ldpc_last_error_code(), last_error())
+        self._h = _handle
+
+    def generate(self, seed, first_frame, batch, ebn0_db, d_llr_ptr, d_msg_ptr=None, stream=None):
+        check(lib().ldpc_sim_generate(self._h, int(seed), int(first_frame), int(batch), float(ebn0_db), d_llr_ptr, d_msg_ptr, stream))
+
+    def tally(self, batch, d_bits_ptr, d_iters_ptr, d_tally_ptr, stream=None):
+        check(lib().ldpc_sim_tally(self._h, int(batch), d_bits_ptr, d_iters_ptr, d_tally_ptr, stream))
+
+    def encode_host(self, msg, p):
+        msg = np.ascontiguousarray(msg, np.uint8)
+        par = np.zeros(p, np.uint8)
+        check(lib().ldpc_sim_encode_host(self._h, ptr(msg, C.c_uint8), ptr(par, C.c_uint8)))
+        return par
+
+    def close(self):
+        if self._h and self._owned:
+            lib().ldpc_sim_destroy(self._h)
+        self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class ECC:
+    """The plug-in record mkLDPC builds (src/ECC/Code/LDPC/Utils.hs:59-75), by code name:
+    ECC(codes_dir, "ldpc/hip-minsum/jpl.4096.4.5/50/4/5")."""
+
+    def __init__(self, codes_dir, code_name, max_batch=64):
+        self._h = lib().ldpc_ecc_create(str(codes_dir).encode(), code_name.encode(), int(max_batch))
+        if not self._h:
+            raise LdpcError(lib().ldpc_last_error_code(), last_error())
+        L = lib()
+        self.name = L.ldpc_ecc_name(self._h).decode()
+        self.message_length = L.ldpc_ecc_message_length(self._h)
+        self.codeword_length = L.ldpc_ecc_codeword_length(self._h)
+        self.unpunctured_length = L.ldpc_ecc_unpunctured_length(self._h)
+        self.max_iters = L.ldpc_ecc_max_iters(self._h)
+        self.code = Code(L.ldpc_ecc_code(self._h), owned=False)
+        self.decoder = Decoder(self.code, max_batch=max_batch, _handle=L.ldpc_ecc_ctx(self._h))
+        self.sim = Sim(self.code, self.message_length, self.codeword_length, _handle=L.ldpc_ecc_sim(self._h))
+
+    def encode(self, msg):
+        msg = np.ascontiguousarray(msg, np.uint8)
+        assert msg.shape == (self.message_length,)
+        cw = np.zeros(self.codeword_length, np.uint8)
+        check(lib().ldpc_ecc_encode(self._h, ptr(msg, C.c_uint8), ptr(cw, C.c_uint8)))
+        return cw
+
+    def decode(self, llr):
+        llr = np.ascontiguousarray(llr, np.float64)
+        assert llr.shape == (self.codeword_length,)
+        out = np.zeros(self.message_length, np.uint8)
+        ok = C.c_int()
+        check(lib().ldpc_ecc_decode(self._h, ptr(llr, C.c_double), ptr(out, C.c_uint8), C.byref(ok)))
+        return out, bool(ok.value)
+
+    def close(self):
+        if self._h:
+            self.decoder._h = None
+            self.sim._h = None
+            self.code._h = None
+            lib().ldpc_ecc_destroy(self._h)
             self._h = None
 
     def __del__(self):

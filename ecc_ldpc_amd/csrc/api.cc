@@ -10,6 +10,7 @@
 
 #include "internal.h"
 #include "fused.h"
+#include "sim.h"
 
 namespace ldpc {
 static thread_local char g_err[512] = "";
@@ -49,6 +50,7 @@ struct ldpc_ctx {
     uint8_t *d_bits = nullptr;   // [max_batch][N]
     int32_t *d_iters = nullptr;  // fused path output staging [max_batch]
     uint8_t *d_conv = nullptr;
+    ldpc::KernelTimer timer;
 };
 
 static std::mutex g_mu;
@@ -223,6 +225,7 @@ void ldpc_ctx_destroy(ldpc_ctx *ctx) {
     hipFree(ctx->flood.dev.unsat); hipFree(ctx->flood.dev.iters); hipFree(ctx->flood.dev.conv); hipFree(ctx->flood.dev.done);
     hipFree(ctx->d_in); hipFree(ctx->d_bits); hipFree(ctx->d_iters); hipFree(ctx->d_conv);
     if (ctx->fused) ldpc::fused_destroy(ctx->fused);
+    ctx->timer.destroy();
     if (ctx->stream) hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -279,7 +282,7 @@ ldpc_ctx *ldpc_ctx_create_ex(const ldpc_code *code_c, int variant, int dtype, in
     d.M = code->M; d.N = code->N; d.E = code->E; d.Bp = ctx->Bp;
     d.row_ptr = code->d_row_ptr; d.col_idx = code->d_col_idx; d.col_ptr = code->d_col_ptr; d.csc_edge = code->d_csc_edge;
     d.unsat = nullptr; d.iters = nullptr; d.conv = nullptr; d.done = nullptr;
-    ctx->flood.variant = variant; ctx->flood.dtype = dtype;
+    ctx->flood.variant = variant; ctx->flood.dtype = dtype; ctx->flood.timer = &ctx->timer;
     CTX_HIP(hipMalloc((void **)&ctx->d_in, (size_t)max_batch * code->N * sizeof(double)));
     CTX_HIP(hipMalloc((void **)&ctx->d_bits, (size_t)max_batch * code->N));
     CTX_HIP(hipMalloc((void **)&ctx->d_iters, sizeof(int32_t) * (size_t)max_batch));
@@ -441,6 +444,99 @@ int ldpc_debug_step(ldpc_ctx *ctx, int batch, const double *orig, const double *
     hipFree(buf);
     hipFree(d_syn);
     return rc;
+}
+
+
+// ------------------------------------------------------------------------------- timing
+int ldpc_ctx_set_timing(ldpc_ctx *ctx, int enabled) {
+    if (!ctx) return set_error(LDPC_EINVAL, "null ctx");
+    ctx->timer.enabled = enabled != 0;
+    ctx->timer.used = 0;
+    return LDPC_OK;
+}
+
+int ldpc_ctx_kernel_time(ldpc_ctx *ctx, int *launches, double *total_ms) {
+    if (!ctx) return set_error(LDPC_EINVAL, "null ctx");
+    if (ctx->timer.drain(launches, total_ms) != 0) return set_error(LDPC_EHIP, "event query failed");
+    return LDPC_OK;
+}
+
+const char *ldpc_ctx_kernel_name(const ldpc_ctx *ctx) {
+    if (!ctx) return "";
+    return ctx->path == LDPC_PATH_FUSED ? "fused_decode_kernel" : "flood_cn_kernel";
+}
+
+// ------------------------------------------------------------------------------- frame source
+}  // extern "C"
+struct ldpc_sim {
+    ldpc::SimDev dev{};
+    int p = 0, max_batch = 0, device = 0;
+    std::vector<uint32_t> gt_host;
+    uint32_t *d_gt = nullptr, *d_msgw = nullptr;
+};
+extern "C" {
+
+void ldpc_sim_destroy(ldpc_sim *sim) {
+    if (!sim) return;
+    hipFree(sim->d_gt);
+    hipFree(sim->d_msgw);
+    delete sim;
+}
+
+ldpc_sim *ldpc_sim_create(const ldpc_code *code, int k, int n_tx, int p, const uint8_t *G, int max_batch) {
+    if (!code || k <= 0 || n_tx < k || n_tx > code->N || max_batch <= 0 || (G && (p <= 0 || k + p < n_tx))) {
+        set_error(LDPC_EINVAL, "ldpc_sim_create: bad arguments (k=%d n_tx=%d p=%d N=%d)", k, n_tx, p, code ? code->N : -1);
+        return nullptr;
+    }
+    if (!G && n_tx > k) { /* all-zero codewords: parity positions are simply 0 */ }
+    int device;
+    { std::lock_guard<std::mutex> lk(g_mu); device = g_device; }
+    if (device < 0) { set_error(LDPC_ENODEVICE, "ldpc_init() has not succeeded"); return nullptr; }
+    ldpc_sim *s = new (std::nothrow) ldpc_sim();
+    if (!s) { set_error(LDPC_ENOMEM, "out of host memory"); return nullptr; }
+    s->device = device; s->p = G ? p : 0; s->max_batch = max_batch;
+    s->dev.N = code->N; s->dev.k = k; s->dev.n_tx = n_tx; s->dev.kwords = (k + 31) / 32; s->dev.gt = nullptr;
+    hipError_t e = hipSetDevice(device);
+    if (e == hipSuccess && G) {
+        s->gt_host.assign((size_t)p * s->dev.kwords, 0u);
+        for (int r = 0; r < k; r++)
+            for (int j = 0; j < p; j++)
+                if (G[(size_t)r * p + j]) s->gt_host[(size_t)j * s->dev.kwords + (r >> 5)] |= 1u << (r & 31);
+        e = hipMalloc((void **)&s->d_gt, s->gt_host.size() * 4);
+        if (e == hipSuccess) e = hipMemcpy(s->d_gt, s->gt_host.data(), s->gt_host.size() * 4, hipMemcpyHostToDevice);
+        s->dev.gt = s->d_gt;
+    }
+    if (e == hipSuccess) e = hipMalloc((void **)&s->d_msgw, (size_t)max_batch * s->dev.kwords * 4);
+    if (e != hipSuccess) { set_error(LDPC_EHIP, "ldpc_sim_create: %s", hipGetErrorString(e)); ldpc_sim_destroy(s); return nullptr; }
+    return s;
+}
+
+int ldpc_sim_generate(ldpc_sim *sim, uint64_t seed, uint64_t first_frame, int batch, double ebn0_db, float *d_llr,
+                      uint8_t *d_msg, void *stream) {
+    if (!sim || !d_llr || batch < 0 || batch > sim->max_batch) return set_error(LDPC_EINVAL, "ldpc_sim_generate: bad arguments");
+    if (batch == 0) return LDPC_OK;
+    HIPCHK(hipSetDevice(sim->device));
+    return ldpc::sim_generate(sim->dev, sim->d_msgw, (hipStream_t)stream, seed, first_frame, batch, ebn0_db, d_llr, d_msg);
+}
+
+int ldpc_sim_tally(ldpc_sim *sim, int batch, const uint8_t *d_bits, const int32_t *d_iters, uint64_t *d_tally, void *stream) {
+    if (!sim || !d_bits || !d_tally || batch < 0 || batch > sim->max_batch) return set_error(LDPC_EINVAL, "ldpc_sim_tally: bad arguments");
+    if (batch == 0) return LDPC_OK;
+    HIPCHK(hipSetDevice(sim->device));
+    return ldpc::sim_tally(sim->dev, sim->d_msgw, (hipStream_t)stream, batch, d_bits, d_iters, (unsigned long long *)d_tally);
+}
+
+int ldpc_sim_encode_host(const ldpc_sim *sim, const uint8_t *msg, uint8_t *parity) {
+    if (!sim || !msg || !parity) return set_error(LDPC_EINVAL, "null argument");
+    const int kw = sim->dev.kwords;
+    std::vector<uint32_t> mw((size_t)kw, 0u);
+    for (int r = 0; r < sim->dev.k; r++) if (msg[r]) mw[r >> 5] |= 1u << (r & 31);
+    for (int j = 0; j < sim->p; j++) {
+        uint32_t acc = 0;
+        for (int w = 0; w < kw; w++) acc ^= mw[w] & sim->gt_host[(size_t)j * kw + w];
+        parity[j] = (uint8_t)(__builtin_popcount(acc) & 1);
+    }
+    return LDPC_OK;
 }
 
 }  // extern "C"

@@ -325,7 +325,9 @@ static int run_turns(FloodState &s, hipStream_t st, int max_iters, int batch, do
     const dim3 tr_grid((d.N + 63) / 64, (d.Bp + 63) / 64);
     for (int n = 0; n < max_iters; n++) {
         if (d_trace) hipLaunchKernelGGL((trace_store_kernel<ST>), tr_grid, dim3(256), 0, st, d, lam, d_trace, n, max_iters + 1, batch);
+        if (s.timer) s.timer->begin(st);
         hipLaunchKernelGGL((flood_cn_kernel<ST, VARIANT>), cn_grid, cn_block, 0, st, d, msg, scr, lam, n + 1, 0, 0);
+        if (s.timer) s.timer->end(st);
         hipLaunchKernelGGL((flood_vn_kernel<ST>), vn_grid, vn_block, 0, st, d, msg, orig, lam, n, 0);
     }
     if (d_trace) hipLaunchKernelGGL((trace_store_kernel<ST>), tr_grid, dim3(256), 0, st, d, lam, d_trace, max_iters, max_iters + 1, batch);

@@ -1,0 +1,477 @@
+// host.cc -- C++ mirror of the reference's host side of the decode path:
+//   * matrix ingest  (src/Data/BitMatrix/Loader.hs:53-81, Alist.hs:30-46, Matlab.hs:20-26,
+//                     src/Data/Matrix/QuasiCyclic.hs:19-25,52-56, Fast/Arraylet.hs:68-79)
+//   * the plug-in record `mkLDPC` builds (src/ECC/Code/LDPC/Utils.hs:35-75): name, encode, decode,
+//     message_length, codeword_length, with the same code-name grammar (Utils.hs:82-88,100-108):
+//       ldpc/<decoder>/<matrix>/<max-rounds>[/<x>/<y>]      rate = x % y
+//     decoders registered here: hip-tanh, hip-minsum, with an optional dtype suffix -f32 (default),
+//     -f64, -f16 (new tokens next to the reference's registry, main/Main.hs:34-36).
+// GHC is not available in this image, so this layer is C++ behind the same C ABI; INTEGRATION.md
+// has the Haskell module that calls the ABI from the reference itself.
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <sys/stat.h>
+
+#include <algorithm>
+#include <fstream>
+#include <new>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include "internal.h"
+
+using ldpc::set_error;
+
+// ------------------------------------------------------------------ arbitrary-size bit rows
+// a non-negative integer read from decimal text, as little-endian 32-bit limbs
+static bool parse_decimal(const std::string &tok, std::vector<uint32_t> &limbs) {
+    limbs.assign(1, 0u);
+    if (tok.empty()) return false;
+    for (char ch : tok) {
+        if (ch < '0' || ch > '9') return false;
+        uint64_t carry = (uint64_t)(ch - '0');
+        for (size_t i = 0; i < limbs.size(); i++) {
+            uint64_t v = (uint64_t)limbs[i] * 10u + carry;
+            limbs[i] = (uint32_t)v;
+            carry = v >> 32;
+        }
+        if (carry) limbs.push_back((uint32_t)carry);
+    }
+    return true;
+}
+static inline bool limb_bit(const std::vector<uint32_t> &l, int b) {
+    size_t w = (size_t)b >> 5;
+    return w < l.size() && ((l[w] >> (b & 31)) & 1u);
+}
+static int limb_top(const std::vector<uint32_t> &l) {  // index of highest set bit, -1 if zero
+    for (int w = (int)l.size() - 1; w >= 0; w--)
+        if (l[w]) return w * 32 + 31 - __builtin_clz(l[w]);
+    return -1;
+}
+
+struct ldpc_matrix {
+    int rows = 0, cols = 0;                       // EXPANDED size (getNRows/getNCols, Loader.hs:31-46)
+    int sz = 0, brows = 0, bcols = 0;             // quasi-cyclic description when sz > 0
+    std::vector<std::vector<uint32_t>> blocks;    // [brows*bcols] first-row bit patterns (QC)
+    std::vector<uint8_t> dense;                   // rows*cols bytes when not QC
+    std::string source;
+};
+
+static bool read_file(const std::string &path, std::string &out) {
+    std::ifstream f(path, std::ios::binary);
+    if (!f) return false;
+    std::stringstream ss;
+    ss << f.rdbuf();
+    out = ss.str();
+    return true;
+}
+static bool file_exists(const std::string &p) {
+    struct stat st;
+    return stat(p.c_str(), &st) == 0 && S_ISREG(st.st_mode);
+}
+static std::vector<std::string> split_ws(const std::string &s) {
+    std::vector<std::string> out;
+    std::istringstream is(s);
+    std::string t;
+    while (is >> t) out.push_back(t);
+    return out;
+}
+
+// QuasiCyclic.hs:52-56: cycle size, then a Matlab-style matrix of integers (one row per line)
+static int parse_q(const std::string &text, ldpc_matrix *m) {
+    std::istringstream is(text);
+    std::string line;
+    std::vector<std::vector<std::string>> rows;
+    bool have_sz = false;
+    while (std::getline(is, line)) {
+        auto toks = split_ws(line);
+        if (toks.empty()) continue;
+        if (!have_sz) {
+            char *end = nullptr;
+            long v = strtol(toks[0].c_str(), &end, 10);
+            if (*end || v <= 0 || v > (1 << 20)) return set_error(LDPC_EFORMAT, ".q: bad cycle size '%s'", toks[0].c_str());
+            m->sz = (int)v;
+            have_sz = true;
+            toks.erase(toks.begin());
+            if (toks.empty()) continue;
+        }
+        rows.push_back(toks);
+    }
+    if (!have_sz || rows.empty()) return set_error(LDPC_EFORMAT, ".q: empty matrix");
+    m->brows = (int)rows.size();
+    m->bcols = (int)rows[0].size();
+    m->blocks.resize((size_t)m->brows * m->bcols);
+    for (int r = 0; r < m->brows; r++) {
+        if ((int)rows[r].size() != m->bcols) return set_error(LDPC_EFORMAT, ".q: ragged row %d", r);
+        for (int c = 0; c < m->bcols; c++) {
+            auto &l = m->blocks[(size_t)r * m->bcols + c];
+            if (!parse_decimal(rows[r][c], l)) return set_error(LDPC_EFORMAT, ".q: bad integer '%s'", rows[r][c].c_str());
+            if (limb_top(l) >= m->sz) return set_error(LDPC_EFORMAT, ".q: entry (%d,%d) has bits above the cycle size %d", r, c, m->sz);
+        }
+    }
+    m->rows = m->brows * m->sz;
+    m->cols = m->bcols * m->sz;
+    return LDPC_OK;
+}
+
+// Alist.hs:30-46: zeros are filtered out first; rows, cols, 2 ignored, row counts, col counts, row lists
+static int parse_alist_reference(const std::string &text, ldpc_matrix *m) {
+    std::vector<long> t;
+    for (auto &s : split_ws(text)) {
+        char *end = nullptr;
+        long v = strtol(s.c_str(), &end, 10);
+        if (*end) return set_error(LDPC_EFORMAT, "alist: bad token '%s'", s.c_str());
+        if (v != 0) t.push_back(v);
+    }
+    size_t pos = 0;
+    auto item = [&](long &v) { if (pos >= t.size()) return false; v = t[pos++]; return true; };
+    long n, mm, ign;
+    if (!item(n) || !item(mm) || !item(ign) || !item(ign) || n <= 0 || mm <= 0) return set_error(LDPC_EFORMAT, "alist: truncated header");
+    std::vector<long> num_n((size_t)n), num_m((size_t)mm);
+    for (auto &v : num_n) if (!item(v)) return set_error(LDPC_EFORMAT, "alist: truncated row counts");
+    for (auto &v : num_m) if (!item(v)) return set_error(LDPC_EFORMAT, "alist: truncated column counts");
+    m->rows = (int)n; m->cols = (int)mm;
+    m->dense.assign((size_t)n * mm, 0);
+    for (long r = 0; r < n; r++)
+        for (long c = 0; c < num_n[(size_t)r]; c++) {
+            long v;
+            if (!item(v) || v < 1 || v > mm) return set_error(LDPC_EFORMAT, "alist: bad entry in row %ld", r + 1);
+            m->dense[(size_t)r * mm + (v - 1)] = 1;
+        }
+    return LDPC_OK;
+}
+
+// MacKay's published order: N M / max col wt, max row wt / col weights / row weights / col lists / row lists
+static int parse_alist_mackay(const std::string &text, ldpc_matrix *m) {
+    std::vector<long> t;
+    for (auto &s : split_ws(text)) {
+        char *end = nullptr;
+        long v = strtol(s.c_str(), &end, 10);
+        if (*end) return set_error(LDPC_EFORMAT, "alist: bad token '%s'", s.c_str());
+        t.push_back(v);
+    }
+    if (t.size() < 4) return set_error(LDPC_EFORMAT, "alist: truncated header");
+    long N = t[0], M = t[1], maxc = t[2], maxr = t[3];
+    if (N <= 0 || M <= 0 || maxc <= 0 || maxr <= 0) return set_error(LDPC_EFORMAT, "alist: bad header");
+    size_t need = 4 + (size_t)N + M + (size_t)N * maxc + (size_t)M * maxr;
+    if (t.size() < need) return set_error(LDPC_EFORMAT, "alist: %zu tokens, MacKay layout needs %zu", t.size(), need);
+    size_t pos = 4;
+    std::vector<long> colw(t.begin() + pos, t.begin() + pos + N); pos += N;
+    std::vector<long> roww(t.begin() + pos, t.begin() + pos + M); pos += M;
+    m->rows = (int)M; m->cols = (int)N;
+    m->dense.assign((size_t)M * N, 0);
+    for (long c = 0; c < N; c++, pos += maxc)
+        for (long q = 0; q < colw[(size_t)c]; q++) {
+            long r = t[pos + q];
+            if (r < 1 || r > M) return set_error(LDPC_EFORMAT, "alist: bad row index %ld in column %ld", r, c + 1);
+            m->dense[(size_t)(r - 1) * N + c] = 1;
+        }
+    for (long r = 0; r < M; r++, pos += maxr)
+        for (long q = 0; q < roww[(size_t)r]; q++) {
+            long c = t[pos + q];
+            if (c < 1 || c > N || !m->dense[(size_t)r * N + (c - 1)])
+                return set_error(LDPC_EFORMAT, "alist: row list of row %ld disagrees with the column lists", r + 1);
+        }
+    return LDPC_OK;
+}
+
+// Data/BitMatrix/Matlab.hs:20-26: lines of "0"/"1" words
+static int parse_m(const std::string &text, ldpc_matrix *m) {
+    std::istringstream is(text);
+    std::string line;
+    int cols = -1, rows = 0;
+    while (std::getline(is, line)) {
+        auto toks = split_ws(line);
+        if (toks.empty()) continue;
+        if (cols < 0) cols = (int)toks.size();
+        if ((int)toks.size() != cols) return set_error(LDPC_EFORMAT, ".m: ragged row %d", rows);
+        for (auto &w : toks) {
+            if (w == "0") m->dense.push_back(0);
+            else if (w == "1") m->dense.push_back(1);
+            else return set_error(LDPC_EFORMAT, "readBit: no parse '%s'", w.c_str());
+        }
+        rows++;
+    }
+    if (rows == 0) return set_error(LDPC_EFORMAT, ".m: empty matrix");
+    m->rows = rows; m->cols = cols;
+    return LDPC_OK;
+}
+
+extern "C" {
+
+void ldpc_matrix_destroy(ldpc_matrix *m) { delete m; }
+
+// Loader.hs:58-81 loadMatrix: for each loader (q, alist, m) x each prefix, first file that exists wins
+ldpc_matrix *ldpc_matrix_load(const char *codes_dir, const char *name) {
+    if (!codes_dir || !name) { set_error(LDPC_EINVAL, "null argument"); return nullptr; }
+    ldpc_matrix *m = new (std::nothrow) ldpc_matrix();
+    if (!m) { set_error(LDPC_ENOMEM, "out of host memory"); return nullptr; }
+    try {
+        const char *suffixes[3] = {"q", "alist", "m"};
+        for (int s = 0; s < 3; s++) {
+            std::string path = std::string(codes_dir) + "/" + name + "." + suffixes[s];
+            if (!file_exists(path)) continue;
+            std::string text;
+            if (!read_file(path, text)) { set_error(LDPC_ENOTFOUND, "cannot read %s", path.c_str()); delete m; return nullptr; }
+            int rc = s == 0 ? parse_q(text, m) : (s == 1 ? parse_alist_reference(text, m) : parse_m(text, m));
+            if (rc != LDPC_OK) { delete m; return nullptr; }
+            m->source = path;
+            return m;
+        }
+        set_error(LDPC_ENOTFOUND, "can not find any matrix files in \"%s\" under %s", name, codes_dir);
+    } catch (...) { set_error(LDPC_ENOMEM, "out of host memory"); }
+    delete m;
+    return nullptr;
+}
+
+// a single file in MacKay's alist order (codes/1920.1280.3.303; the reference's reader would
+// transpose it, SURVEY.md section 0 note ii)
+ldpc_matrix *ldpc_matrix_load_mackay(const char *path) {
+    if (!path) { set_error(LDPC_EINVAL, "null argument"); return nullptr; }
+    ldpc_matrix *m = new (std::nothrow) ldpc_matrix();
+    if (!m) { set_error(LDPC_ENOMEM, "out of host memory"); return nullptr; }
+    try {
+        std::string text;
+        if (!read_file(path, text)) { set_error(LDPC_ENOTFOUND, "cannot read %s", path); delete m; return nullptr; }
+        if (parse_alist_mackay(text, m) != LDPC_OK) { delete m; return nullptr; }
+        m->source = path;
+        return m;
+    } catch (...) { set_error(LDPC_ENOMEM, "out of host memory"); }
+    delete m;
+    return nullptr;
+}
+
+int ldpc_matrix_info(const ldpc_matrix *m, int *rows, int *cols, int *qc_sz, int *block_rows, int *block_cols) {
+    if (!m) return set_error(LDPC_EINVAL, "null matrix");
+    if (rows) *rows = m->rows;
+    if (cols) *cols = m->cols;
+    if (qc_sz) *qc_sz = m->sz;
+    if (block_rows) *block_rows = m->brows;
+    if (block_cols) *block_cols = m->bcols;
+    return LDPC_OK;
+}
+
+// QuasiCyclic.hs:19-25 toBitMatrix for QC sources; a copy otherwise.  out: rows*cols bytes
+int ldpc_matrix_dense(const ldpc_matrix *m, uint8_t *out) {
+    if (!m || !out) return set_error(LDPC_EINVAL, "null argument");
+    if (m->sz == 0) { memcpy(out, m->dense.data(), m->dense.size()); return LDPC_OK; }
+    memset(out, 0, (size_t)m->rows * m->cols);
+    for (int br = 0; br < m->brows; br++)
+        for (int bc = 0; bc < m->bcols; bc++) {
+            const auto &l = m->blocks[(size_t)br * m->bcols + bc];
+            for (int k = 0; k < m->sz; k++) {
+                if (!limb_bit(l, k)) continue;
+                for (int i = 0; i < m->sz; i++) out[(size_t)(br * m->sz + i) * m->cols + bc * m->sz + (i + k) % m->sz] = 1;
+            }
+        }
+    return LDPC_OK;
+}
+
+// Fast/Arraylet.hs:68-79 initMatrixlet / GPU/CUDA/Arraylet2.hs:299-331: rotation table, -1 = empty;
+// a block with more than one circulant is an error there and LDPC_EUNSUPPORTED here.
+int ldpc_matrix_qc_offsets(const ldpc_matrix *m, int32_t *offsets) {
+    if (!m || !offsets) return set_error(LDPC_EINVAL, "null argument");
+    if (m->sz == 0) return set_error(LDPC_EUNSUPPORTED, "can not load %s as QuasiCyclic", m->source.c_str());
+    for (size_t i = 0; i < m->blocks.size(); i++) {
+        const auto &l = m->blocks[i];
+        int top = limb_top(l);
+        if (top < 0) { offsets[i] = -1; continue; }
+        int pop = 0;
+        for (uint32_t w : l) pop += __builtin_popcount(w);
+        if (pop != 1) return set_error(LDPC_EUNSUPPORTED, "QuasiCyclic matrix has non-powers of two initial value at block %zu", i);
+        offsets[i] = top;
+    }
+    return LDPC_OK;
+}
+
+// the parity-check graph of a loaded matrix: QC table when every block is a single circulant
+// (what the QuasiCyclic decoders take), generic CSR otherwise (what the Matrix Bool decoders take)
+ldpc_code *ldpc_code_from_matrix(const ldpc_matrix *m) {
+    if (!m) { set_error(LDPC_EINVAL, "null matrix"); return nullptr; }
+    try {
+        if (m->sz > 0) {
+            std::vector<int32_t> off(m->blocks.size());
+            if (ldpc_matrix_qc_offsets(m, off.data()) == LDPC_OK) return ldpc_code_create_qc(m->sz, m->brows, m->bcols, off.data());
+        }
+        std::vector<uint8_t> d((size_t)m->rows * m->cols);
+        if (ldpc_matrix_dense(m, d.data()) != LDPC_OK) return nullptr;
+        std::vector<int32_t> rp((size_t)m->rows + 1, 0), ci;
+        for (int r = 0; r < m->rows; r++) {
+            for (int c = 0; c < m->cols; c++)
+                if (d[(size_t)r * m->cols + c]) ci.push_back(c);
+            rp[(size_t)r + 1] = (int32_t)ci.size();
+        }
+        if (ci.empty()) ci.push_back(0);
+        return ldpc_code_create_csr(m->rows, m->cols, rp.data(), ci.data());
+    } catch (...) { set_error(LDPC_ENOMEM, "out of host memory"); return nullptr; }
+}
+
+}  // extern "C"
+
+// ------------------------------------------------------------------ the ECC record (mkLDPC)
+struct ldpc_ecc {
+    std::string name;            // Utils.hs:60
+    int message_length = 0;      // Utils.hs:73   m_length = rows G
+    int codeword_length = 0;     // Utils.hs:74   c_length = m_length * den / num
+    int unpunctured_length = 0;  // cols H
+    int max_iters = 0, variant = 0, dtype = 0, rate_num = 0, rate_den = 0;
+    ldpc_code *code = nullptr;
+    ldpc_ctx *ctx = nullptr;
+    ldpc_sim *sim = nullptr;
+    int parity_len = 0;
+    std::vector<double> llr_buf;
+    std::vector<uint8_t> bits_buf;
+};
+
+static std::vector<std::string> split_slash(const std::string &s) {
+    std::vector<std::string> out;
+    size_t b = 0;
+    while (true) {
+        size_t e = s.find('/', b);
+        out.push_back(s.substr(b, e == std::string::npos ? e : e - b));
+        if (e == std::string::npos) break;
+        b = e + 1;
+    }
+    return out;
+}
+static bool all_digits(const std::string &s) {
+    return !s.empty() && std::all_of(s.begin(), s.end(), [](char c) { return c >= '0' && c <= '9'; });
+}
+
+extern "C" {
+
+void ldpc_ecc_destroy(ldpc_ecc *e) {
+    if (!e) return;
+    if (e->sim) ldpc_sim_destroy(e->sim);
+    if (e->ctx) ldpc_ctx_destroy(e->ctx);
+    if (e->code) ldpc_code_destroy(e->code);
+    delete e;
+}
+
+// Utils.hs:100-108 (the Code factory) + Utils.hs:35-75 (mkLDPC).  Returns NULL with
+// LDPC_ENOTFOUND when the name is not one of this library's decoders (the factory's `_ -> return []`).
+ldpc_ecc *ldpc_ecc_create(const char *codes_dir, const char *code_name, int max_batch) {
+    if (!codes_dir || !code_name || max_batch <= 0) { set_error(LDPC_EINVAL, "bad argument"); return nullptr; }
+    ldpc_ecc *e = nullptr;
+    ldpc_matrix *g = nullptr, *h = nullptr;
+    try {
+        auto xs = split_slash(code_name);
+        // ["ldpc",nm,m,n] | ["ldpc",nm,m,n,x,y]
+        if (!((xs.size() == 4 || xs.size() == 6) && xs[0] == "ldpc" && all_digits(xs[3]) &&
+              (xs.size() == 4 || (all_digits(xs[4]) && all_digits(xs[5]))))) {
+            set_error(LDPC_ENOTFOUND, "'%s' does not match ldpc/<decoder>/<matrix-name>/<max-rounds>[/x/y]", code_name);
+            return nullptr;
+        }
+        std::string dec = xs[1];
+        int dtype = LDPC_F32;
+        auto ends = [&](const char *suf) { size_t n = strlen(suf); return dec.size() > n && dec.compare(dec.size() - n, n, suf) == 0; };
+        if (ends("-f64")) { dtype = LDPC_F64; dec.resize(dec.size() - 4); }
+        else if (ends("-f16")) { dtype = LDPC_F16; dec.resize(dec.size() - 4); }
+        else if (ends("-f32")) { dec.resize(dec.size() - 4); }
+        int variant;
+        if (dec == "hip-tanh") variant = LDPC_TANH;
+        else if (dec == "hip-minsum") variant = LDPC_MINSUM;
+        else { set_error(LDPC_ENOTFOUND, "decoder '%s' is not provided by libldpc_hip (hip-tanh, hip-minsum)", xs[1].c_str()); return nullptr; }
+
+        g = ldpc_matrix_load(codes_dir, (xs[2] + "/G").c_str());  // Utils.hs:36
+        if (!g) return nullptr;
+        h = ldpc_matrix_load(codes_dir, (xs[2] + "/H").c_str());  // Utils.hs:40
+        if (!h) { ldpc_matrix_destroy(g); return nullptr; }
+        if (g->rows + g->cols != h->cols) {                      // Utils.hs:43
+            set_error(LDPC_EFORMAT, "bad code size match (%d,%d)", g->rows + g->cols, h->cols);
+            ldpc_matrix_destroy(g); ldpc_matrix_destroy(h);
+            return nullptr;
+        }
+        e = new ldpc_ecc();
+        e->message_length = g->rows;
+        e->unpunctured_length = h->cols;
+        e->max_iters = atoi(xs[3].c_str());
+        e->variant = variant; e->dtype = dtype;
+        if (xs.size() == 6) { e->rate_num = atoi(xs[4].c_str()); e->rate_den = atoi(xs[5].c_str()); }
+        else { e->rate_num = e->message_length; e->rate_den = e->unpunctured_length; }  // Utils.hs:46-48
+        if (e->rate_num <= 0 || e->rate_den <= 0) { set_error(LDPC_EINVAL, "bad rate %d/%d", e->rate_num, e->rate_den); goto fail; }
+        {   // Ratio Int normalises: numerator/denominator of the reduced fraction (Utils.hs:50,60)
+            int a = e->rate_num, b = e->rate_den;
+            while (b) { int t = a % b; a = b; b = t; }
+            e->rate_num /= a; e->rate_den /= a;
+        }
+        e->codeword_length = (int)(((long long)e->message_length * e->rate_den) / e->rate_num);  // Utils.hs:50
+        if (e->codeword_length < e->message_length || e->codeword_length > e->unpunctured_length) {
+            set_error(LDPC_EINVAL, "rate %d/%d gives codeword length %d outside [%d,%d]", e->rate_num, e->rate_den,
+                      e->codeword_length, e->message_length, e->unpunctured_length);
+            goto fail;
+        }
+        e->name = "ldpc/" + xs[1] + "/" + xs[2] + "/" + std::to_string(e->max_iters) + "/" + std::to_string(e->rate_num) + "/" +
+                  std::to_string(e->rate_den);  // Utils.hs:60
+        e->code = ldpc_code_from_matrix(h);
+        if (!e->code) goto fail;
+        {   // Utils.hs:53 (one replica).  LDPC_HIP_PATH=flood|fused overrides the automatic kernel choice.
+            int path = LDPC_PATH_AUTO;
+            const char *pe = getenv("LDPC_HIP_PATH");
+            if (pe && !strcmp(pe, "flood")) path = LDPC_PATH_FLOOD;
+            else if (pe && !strcmp(pe, "fused")) path = LDPC_PATH_FUSED;
+            e->ctx = ldpc_ctx_create_ex(e->code, variant, dtype, max_batch, path);
+        }
+        if (!e->ctx) goto fail;
+        {
+            std::vector<uint8_t> gd((size_t)g->rows * g->cols);
+            if (ldpc_matrix_dense(g, gd.data()) != LDPC_OK) goto fail;
+            e->parity_len = g->cols;
+            e->sim = ldpc_sim_create(e->code, e->message_length, e->codeword_length, g->cols, gd.data(), max_batch);
+            if (!e->sim) goto fail;
+        }
+        e->llr_buf.assign((size_t)e->unpunctured_length, 0.0);
+        e->bits_buf.assign((size_t)e->unpunctured_length, 0);
+        ldpc_matrix_destroy(g); ldpc_matrix_destroy(h);
+        return e;
+    } catch (...) { set_error(LDPC_ENOMEM, "out of host memory"); }
+fail:
+    if (g) ldpc_matrix_destroy(g);
+    if (h) ldpc_matrix_destroy(h);
+    ldpc_ecc_destroy(e);
+    return nullptr;
+}
+
+const char *ldpc_ecc_name(const ldpc_ecc *e) { return e ? e->name.c_str() : ""; }
+int ldpc_ecc_message_length(const ldpc_ecc *e) { return e ? e->message_length : set_error(LDPC_EINVAL, "null ecc"); }
+int ldpc_ecc_codeword_length(const ldpc_ecc *e) { return e ? e->codeword_length : set_error(LDPC_EINVAL, "null ecc"); }
+int ldpc_ecc_unpunctured_length(const ldpc_ecc *e) { return e ? e->unpunctured_length : set_error(LDPC_EINVAL, "null ecc"); }
+int ldpc_ecc_max_iters(const ldpc_ecc *e) { return e ? e->max_iters : set_error(LDPC_EINVAL, "null ecc"); }
+ldpc_ctx *ldpc_ecc_ctx(ldpc_ecc *e) { return e ? e->ctx : nullptr; }
+ldpc_sim *ldpc_ecc_sim(ldpc_ecc *e) { return e ? e->sim : nullptr; }
+const ldpc_code *ldpc_ecc_code(const ldpc_ecc *e) { return e ? e->code : nullptr; }
+
+// Utils.hs:61  encode = \inp -> inp ++ take (c_length - m_length) (encoder' inp)
+int ldpc_ecc_encode(const ldpc_ecc *e, const uint8_t *msg, uint8_t *codeword) {
+    if (!e || !msg || !codeword) return set_error(LDPC_EINVAL, "null argument");
+    try {
+        std::vector<uint8_t> par((size_t)e->parity_len);
+        int rc = ldpc_sim_encode_host(e->sim, msg, par.data());
+        if (rc != LDPC_OK) return rc;
+        memcpy(codeword, msg, (size_t)e->message_length);
+        memcpy(codeword + e->message_length, par.data(), (size_t)(e->codeword_length - e->message_length));
+        return LDPC_OK;
+    } catch (...) { return set_error(LDPC_ENOMEM, "out of host memory"); }
+}
+
+// Utils.hs:62-72  decode: unpuncture (take c_length ++ zeros), run the replica, take m_length bits;
+// `Nothing` (a failing replica) -> hard decisions of the input, flag False.
+int ldpc_ecc_decode(ldpc_ecc *e, const double *llr, uint8_t *msg_bits, int *ok) {
+    if (!e || !llr || !msg_bits) return set_error(LDPC_EINVAL, "null argument");
+    std::copy(llr, llr + e->codeword_length, e->llr_buf.begin());
+    std::fill(e->llr_buf.begin() + e->codeword_length, e->llr_buf.end(), 0.0);  // Utils.hs:55
+    int iters = 0, conv = 0;
+    int rc = ldpc_decode_one(e->ctx, e->max_iters, e->llr_buf.data(), e->bits_buf.data(), &iters, &conv);
+    if (rc != LDPC_OK) {  // Utils.hs:71
+        for (int i = 0; i < e->message_length; i++) msg_bits[i] = llr[i] > 0.0 ? 1 : 0;
+        if (ok) *ok = 0;
+        return LDPC_OK;
+    }
+    memcpy(msg_bits, e->bits_buf.data(), (size_t)e->message_length);  // Utils.hs:72
+    if (ok) *ok = 1;
+    return LDPC_OK;
+}
+
+}  // extern "C"

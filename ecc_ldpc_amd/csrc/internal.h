@@ -24,9 +24,45 @@ struct FloodDev {
     uint8_t *done;           // [Bp]
 };
 
+// HIP-event bracket around every launch of a context's dominant kernel (bench.py roofline leg)
+struct KernelTimer {
+    bool enabled = false;
+    std::vector<hipEvent_t> ev;  // pairs: start, stop
+    size_t used = 0;
+    void begin(hipStream_t st) {
+        if (!enabled) return;
+        if (used + 2 > ev.size()) {
+            hipEvent_t a, b;
+            if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { enabled = false; return; }
+            ev.push_back(a); ev.push_back(b);
+        }
+        (void)hipEventRecord(ev[used], st);
+    }
+    void end(hipStream_t st) {
+        if (!enabled) return;
+        (void)hipEventRecord(ev[used + 1], st);
+        used += 2;
+    }
+    int drain(int *launches, double *total_ms) {
+        double t = 0;
+        for (size_t i = 0; i < used; i += 2) {
+            if (hipEventSynchronize(ev[i + 1]) != hipSuccess) return -1;
+            float ms = 0;
+            if (hipEventElapsedTime(&ms, ev[i], ev[i + 1]) != hipSuccess) return -1;
+            t += ms;
+        }
+        if (launches) *launches = (int)(used / 2);
+        if (total_ms) *total_ms = t;
+        used = 0;
+        return 0;
+    }
+    void destroy() { for (auto e : ev) (void)hipEventDestroy(e); ev.clear(); used = 0; }
+};
+
 struct FloodState {
     FloodDev dev;
     int variant, dtype;
+    KernelTimer *timer = nullptr;
     void *msg = nullptr, *scratch = nullptr, *lam = nullptr, *orig = nullptr;
 };
 

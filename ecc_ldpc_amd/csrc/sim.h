@@ -1,0 +1,13 @@
+// sim.h -- frame source / tally (sim.hip) interface
+#pragma once
+#include "internal.h"
+namespace ldpc {
+struct SimDev {
+    int N, k, n_tx, kwords;
+    const uint32_t *gt;  // [p][kwords] column j of G packed over message bits; null = all-zero codewords
+};
+int sim_generate(const SimDev &s, uint32_t *msgw, hipStream_t st, uint64_t seed, uint64_t first_frame, int batch,
+                 double ebn0_db, float *d_llr, uint8_t *d_msg);
+int sim_tally(const SimDev &s, const uint32_t *msgw, hipStream_t st, int batch, const uint8_t *d_bits, const int32_t *d_iters,
+              unsigned long long *d_tally);
+}  // namespace ldpc

@@ -134,6 +134,86 @@ int ldpc_debug_step(ldpc_ctx *ctx, int batch, const double *orig, const double *
 int ldpc_decode_trace(ldpc_ctx *ctx, int max_iters, int batch, const double *llr, uint8_t *bits,
                       int32_t *iters, uint8_t *converged, double *trace_lam);
 
+/* ---- dominant-kernel timing (bench.py's `roofline` object) ---------------------------------------
+ * When enabled, the context brackets every launch of its dominant kernel (fused: the one decode
+ * kernel; flood: the check-node kernel) with HIP events on the stream the kernel is launched on.
+ * ldpc_ctx_kernel_time drains them: number of launches and their summed duration (ms) since the
+ * last call.  Blocks until the recorded launches have finished. */
+int ldpc_ctx_set_timing(ldpc_ctx *ctx, int enabled);
+int ldpc_ctx_kernel_time(ldpc_ctx *ctx, int *launches, double *total_ms);
+/* name of that kernel as it appears in a rocprofv3 kernel trace (substring) */
+const char *ldpc_ctx_kernel_name(const ldpc_ctx *ctx);
+
+/* ---- frame source and error tally for a BER / throughput harness -----------------------------------
+ * The reference leaves message generation, BPSK + AWGN and BER statistics to the external tester
+ * (ecc-manifold `eccMain`, main/Main.hs:41-48); a harness built on this library can keep frames
+ * on the device instead.  Encoding is the reference's systematic rule
+ *   codeword = msg ++ take (c_length - k) (msg * G)   (Utils.hs:61, Reference/Orig.hs:25-26,
+ * Fast/Encoder.hs:26-63).  G is given dense, row-major bytes [k][p] (0/1), or NULL for all-zero
+ * codewords (codes shipped without a generator).  n_tx = transmitted length (c_length, Utils.hs:50);
+ * positions n_tx..N-1 are punctured: LLR 0 (Utils.hs:55). */
+typedef struct ldpc_sim ldpc_sim;
+ldpc_sim *ldpc_sim_create(const ldpc_code *code, int k, int n_tx, int p, const uint8_t *G, int max_batch);
+void ldpc_sim_destroy(ldpc_sim *sim);
+/* frames [first_frame, first_frame+batch) of the stream identified by `seed`, at Eb/N0 (dB):
+ * d_llr [batch][N] float32 (device), d_msg [batch][k] bytes (device, may be NULL).  Enqueued on
+ * `stream` (NULL = default stream), not synchronised.  The message words stay inside `sim` for
+ * the next ldpc_sim_tally call. */
+int ldpc_sim_generate(ldpc_sim *sim, uint64_t seed, uint64_t first_frame, int batch, double ebn0_db,
+                      float *d_llr, uint8_t *d_msg, void *stream);
+/* d_tally[4] (device, uint64) += {frames, frame errors, message-bit errors, sum of iterations}
+ * for the frames of the last ldpc_sim_generate call; d_iters may be NULL. */
+int ldpc_sim_tally(ldpc_sim *sim, int batch, const uint8_t *d_bits, const int32_t *d_iters,
+                   uint64_t *d_tally, void *stream);
+/* host-side encode of one message with the same rule (parity only, p bytes) -- used by tests */
+int ldpc_sim_encode_host(const ldpc_sim *sim, const uint8_t *msg, uint8_t *parity);
+
+/* ---- matrix ingest --------------------------------------------------------------------------------
+ * replaces loadMatrix (src/Data/BitMatrix/Loader.hs:58-81): `name` is "<matrix>/H" or "<matrix>/G";
+ * for each loader in the reference's order (.q, .alist, .m; Loader.hs:53-57) the first existing
+ * file <codes_dir>/<name>.<suffix> is parsed: .q = QuasiCyclic.hs:52-56 (integers of any size),
+ * .alist = the reference's reader, Alist.hs:30-46 (zeros dropped, ROWS first, row lists only),
+ * .m = Data/BitMatrix/Matlab.hs:20-26. */
+typedef struct ldpc_matrix ldpc_matrix;
+ldpc_matrix *ldpc_matrix_load(const char *codes_dir, const char *name);
+/* one file in MacKay's published alist order (N M first, zero-padded lists), e.g.
+ * codes/1920.1280.3.303, which the reference's reader cannot load. */
+ldpc_matrix *ldpc_matrix_load_mackay(const char *path);
+void ldpc_matrix_destroy(ldpc_matrix *m);
+/* rows/cols of the EXPANDED matrix (getNRows/getNCols, Loader.hs:31-46); qc_sz = 0 if not .q */
+int ldpc_matrix_info(const ldpc_matrix *m, int *rows, int *cols, int *qc_sz, int *block_rows, int *block_cols);
+int ldpc_matrix_dense(const ldpc_matrix *m, uint8_t *out /* rows*cols bytes 0/1 */);  /* QuasiCyclic.hs:19-25 */
+/* rotation table of a .q matrix, -1 = empty block (Fast/Arraylet.hs:68-79); LDPC_EUNSUPPORTED for
+ * a block holding more than one circulant (the reference errors there too). */
+int ldpc_matrix_qc_offsets(const ldpc_matrix *m, int32_t *offsets /* block_rows*block_cols */);
+/* QC graph when every block is a single circulant, generic CSR otherwise */
+ldpc_code *ldpc_code_from_matrix(const ldpc_matrix *m);
+
+/* ---- the plug-in record ----------------------------------------------------------------------------
+ * C mirror of what mkLDPC returns (src/ECC/Code/LDPC/Utils.hs:35-75): ECC{name, encode, decode,
+ * message_length, codeword_length}, selected by the reference's code-name grammar
+ *   ldpc/<decoder>/<matrix-name>/<max-rounds>[/<x>/<y>]        (Utils.hs:82-88,100-108; rate x%y)
+ * with <decoder> in {hip-tanh, hip-minsum}[-f32|-f64|-f16].  NULL + LDPC_ENOTFOUND for any other
+ * name (the factory's `_ -> return []`). One decoder replica is created (maxThreadCount = 1, like
+ * the CUDA plug-ins, GPU/CUDA/Arraylet2.hs:61). */
+typedef struct ldpc_ecc ldpc_ecc;
+ldpc_ecc *ldpc_ecc_create(const char *codes_dir, const char *code_name, int max_batch);
+void ldpc_ecc_destroy(ldpc_ecc *ecc);
+const char *ldpc_ecc_name(const ldpc_ecc *ecc);            /* Utils.hs:60 */
+int ldpc_ecc_message_length(const ldpc_ecc *ecc);          /* Utils.hs:73 */
+int ldpc_ecc_codeword_length(const ldpc_ecc *ecc);         /* Utils.hs:74 (after puncturing) */
+int ldpc_ecc_unpunctured_length(const ldpc_ecc *ecc);      /* cols H */
+int ldpc_ecc_max_iters(const ldpc_ecc *ecc);
+/* encode: msg [message_length] bytes -> codeword [codeword_length] bytes (Utils.hs:61) */
+int ldpc_ecc_encode(const ldpc_ecc *ecc, const uint8_t *msg, uint8_t *codeword);
+/* decode: llr [codeword_length] doubles -> msg_bits [message_length]; *ok = the record's Bool
+ * (Utils.hs:62-72: un-puncture with zeros, decode, take message_length) */
+int ldpc_ecc_decode(ldpc_ecc *ecc, const double *llr, uint8_t *msg_bits, int *ok);
+/* the pieces, for batched use (owned by the record) */
+ldpc_ctx *ldpc_ecc_ctx(ldpc_ecc *ecc);
+ldpc_sim *ldpc_ecc_sim(ldpc_ecc *ecc);
+const ldpc_code *ldpc_ecc_code(const ldpc_ecc *ecc);
+
 #ifdef __cplusplus
 }
 #endif

@@ -163,6 +163,27 @@ def main():
         dist.destroy_process_group()
 
 
+def host_cores():
+    """CPU threads this process may really use: affinity mask, capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if q > 0:
+                    n = min(n, max(1, q // per))
+            break
+        except Exception:
+            continue
+    env = os.environ.get("LDPC_CPU_THREADS")
+    return int(env) if env else n
+
+
 def cpu_baseline(args, ecc, llr_dev, gpu_value):
     """The CPU restatement of the reference decoder (oracle/, kind "port": the Haskell itself cannot be
     built here) timed on this box's host cores on a bounded sample of the SAME frames."""
@@ -171,7 +192,7 @@ def cpu_baseline(args, ecc, llr_dev, gpu_value):
     code = ecc.code
     rp, ci = code.csr()
     g = oracle.Graph(rp, ci, code.N)
-    cores = os.cpu_count() or 1
+    cores = host_cores()
     variant = "min" if args.variant == "minsum" else "tanh"
     probe = min(llr_dev.shape[0], 2 * cores)
     x = llr_dev[:probe].cpu().numpy().astype(np.float64)

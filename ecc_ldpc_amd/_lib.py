@@ -41,6 +41,28 @@ class LdpcError(RuntimeError):
 _lib = None
 
 
+def _preload_hip_runtime():
+    """One process must hold ONE HIP runtime.  PyTorch wheels bundle their own libamdhip64.so; if
+    libldpc_hip.so pulled in /opt/rocm's copy first, a later `import torch` would bring up a second
+    runtime that sees no GPUs.  So when a torch wheel is installed, load ITS runtime first (by file,
+    without importing torch); libldpc_hip.so then binds to the already-loaded libamdhip64.so.N."""
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except Exception:
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    libdir = os.path.join(list(spec.submodule_search_locations)[0], "lib")
+    for name in ("libhsa-runtime64.so", "libamdhip64.so"):
+        path = os.path.join(libdir, name)
+        if os.path.exists(path):
+            try:
+                C.CDLL(path, mode=C.RTLD_GLOBAL)
+            except OSError:
+                pass
+
+
 def lib():
     global _lib
     if _lib is not None:
@@ -48,6 +70,7 @@ def lib():
     if not os.path.exists(SO_PATH):
         raise ImportError(f"{SO_PATH} is missing: build it with `python ecc_ldpc_amd/build.py` "
                           "(the HIP library is the only decode path; there is no fallback)")
+    _preload_hip_runtime()
     L = C.CDLL(SO_PATH)
     vp, i32p, u8p, f64p, f32p, ip = C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_uint8), C.POINTER(C.c_double), C.POINTER(C.c_float), C.POINTER(C.c_int)
     L.ldpc_last_error.restype = C.c_char_p

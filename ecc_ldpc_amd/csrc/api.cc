@@ -305,6 +305,7 @@ ldpc_ctx *ldpc_ctx_create_ex(const ldpc_code *code_c, int variant, int dtype, in
     } else {
         ctx->fused = ldpc::fused_create(*code, variant, dtype, max_batch);
         if (!ctx->fused) { ldpc_ctx_destroy(ctx); return nullptr; }
+        ldpc::fused_set_timer(ctx->fused, &ctx->timer);
     }
     return ctx;
 }

@@ -9,6 +9,7 @@ bool fused_supported(const ldpc_code &code, int variant, int dtype);
 const char *fused_why_not(const ldpc_code &code, int variant, int dtype);
 FusedState *fused_create(const ldpc_code &code, int variant, int dtype, int max_batch);
 void fused_destroy(FusedState *s);
+void fused_set_timer(FusedState *s, KernelTimer *t);
 // d_llr [batch][N] float32/float64; outputs may be null except d_bits
 int fused_decode(FusedState &s, hipStream_t st, int max_iters, int batch, const void *d_llr, int llr_is_f64,
                  uint8_t *d_bits, int32_t *d_iters, uint8_t *d_conv, double *d_final, double *d_trace);

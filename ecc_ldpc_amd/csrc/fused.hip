@@ -1,12 +1,571 @@
-// fused.hip -- placeholder until the on-chip kernel lands: reports "unsupported" so that
-// LDPC_PATH_AUTO resolves to the flood path and LDPC_PATH_FUSED fails loudly.
+// fused.hip -- whole-decode-in-one-launch min-sum flooding BP for quasi-cyclic codes (gfx950).
+//
+// One launch decodes a batch; a frame's entire BP state stays on-chip for all iterations:
+//   * lam (a-posteriori LLRs, N values)  -> LDS, 44*V*4 bytes per wave (V = max(sz,64))
+//   * check->variable messages           -> VGPRs, compressed per check row to the record
+//       {m1s, m2s, idx, signs}  (= the reference's MinSum2 / `omit` two-min semigroup,
+//       src/ECC/Code/LDPC/Utils.hs:133-144; leave-one-out min is m2 at the argmin, m1 elsewhere)
+//   * channel LLRs (orig)                -> VGPRs
+// Mapping: ONE WAVE owns one frame (sz >= 64; lane l owns rows l, l+64, .. of every circulant) or
+// 64/sz frames (sz < 64; lane l -> frame l % cpw, row l / cpw).  Waves never communicate: there
+// is no barrier, no atomic and no cross-lane traffic in the iteration loop; DS operations of one
+// wave execute in program order, which is what makes the two phases below race-free.
+//
+// Loop turn n (src/ECC/Code/LDPC/Reference/Min.hs:63-67 == Orig.hs:67-71):
+//   phase A  for every row the lane owns: gather lam[col] from LDS (consecutive lanes hit
+//            consecutive dwords: conflict-free), row parity of hard(lam) = the syndrome
+//            (Min.hs:69-72), rebuild ne from the record, t = lam - ne, reduce to the new record
+//            (Min.hs:75-86).  Syndrome zero -> frame done, output hard(lam) (Min.hs:64).
+//   phase B  lam <- orig, then lam[col] += ne'[m,col] block-row by block-row in DESCENDING row
+//            order = the reference's foldr (+) orig (col of ne') (Min.hs:100-103).  Inside a
+//            block-row every lane hits a distinct column; successive block-rows are ordered by
+//            the wave's in-order DS queue.
+// After max_iters turns one more syndrome pass decides between hard(lam) and hard(orig) (Min.hs:64-65).
+//
+// Graph description: `tab` holds, block-row-major, one dword per non-empty circulant:
+//   lo 16 bits = rotation * cpw * sizeof(CT)   (byte rotation inside a block column)
+//   hi 16 bits = bc * V * sizeof(CT)           (byte base of the block column in LDS)
+// The degree sequence of the block rows is a compile-time Plan (registers must be named statically).
+#include <string.h>
+
+#include <type_traits>
+#include <utility>
+#include <vector>
+
 #include "fused.h"
+#include "ldpc_math.h"
+
 namespace ldpc {
-struct FusedState {};
-bool fused_supported(const ldpc_code &, int, int) { return false; }
-const char *fused_why_not(const ldpc_code &, int, int) { return "fused kernel not built"; }
-FusedState *fused_create(const ldpc_code &, int, int, int) { set_error(LDPC_EUNSUPPORTED, "fused kernel not built"); return nullptr; }
-void fused_destroy(FusedState *s) { delete s; }
-int fused_decode(FusedState &, hipStream_t, int, int, const void *, int, uint8_t *, int32_t *, uint8_t *, double *, double *) { return set_error(LDPC_EUNSUPPORTED, "fused kernel not built"); }
-int fused_step(FusedState &, hipStream_t, int, const double *, const double *, const double *, double *, double *, uint8_t *) { return set_error(LDPC_EUNSUPPORTED, "fused kernel not built"); }
+
+// ------------------------------------------------------------------ plans
+// AR4JA rate-4/5 protograph as shipped in codes/jpl.1024.4.5 and codes/jpl.4096.4.5:
+// 12 x 44 blocks, block rows 0-3 of weight 3, 4-11 of weight 18.
+struct PlanAR4JA45 {
+    static constexpr int NBR = 12, NBC = 44, NEDGE = 4 * 3 + 8 * 18;
+    static constexpr int deg(int br) { return br < 4 ? 3 : 18; }
+    static constexpr int ebeg(int br) { return br < 4 ? 3 * br : 12 + 18 * (br - 4); }
+};
+
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F &&f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+template <int I, int N, class F>
+__device__ __forceinline__ void static_rfor(F &&f) {  // N-1 down to I
+    if constexpr (I < N) {
+        f(std::integral_constant<int, N - 1>{});
+        static_rfor<I, N - 1>(f);
+    }
+}
+
+// the graph table is read through the CONSTANT address space: the kernel never writes it, and only
+// then may the compiler use scalar loads (s_load) although the kernel also stores to global memory.
+typedef const __attribute__((address_space(4))) uint32_t *ctab_t;
+struct FusedArgs {
+    const uint32_t *tab;
+    const void *llr;  // [batch][N] float or double
+    uint8_t *bits;    // [batch][N]
+    int32_t *iters;   // may be null
+    uint8_t *conv;    // may be null
+    double *final_lam;  // may be null [batch][N]
+    double *trace;      // may be null [batch][max_iters+1][N]
+    int batch, max_iters, llr_is_f64;
+    // teacher-forced single step (verification): state in, state out
+    int step_mode;
+    const double *st_lam;  // [batch][N]
+    const void *st_m1, *st_m2;  // [batch][M] CT
+    const uint32_t *st_sg;      // [batch][M]
+    double *st_ne_out;          // [batch][E] CSR edge order
+    uint8_t *st_syn;            // [batch]
+};
+
+// A wave-uniform zero the optimiser cannot see through.  Adding it to the (loop-invariant) graph
+// table pointer keeps the table loads and the address arithmetic INSIDE the iteration loop: hoisted,
+// 156 x RPL addresses would live in VGPRs for the whole decode and spill.  readfirstlane makes the
+// value provably uniform again (inline-asm results count as divergent), so the loads stay s_load.
+__device__ __forceinline__ uint32_t opaque_uniform_zero() {
+    uint32_t z;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(z));
+    return __builtin_amdgcn_readfirstlane(z);
+}
+__device__ __forceinline__ uint32_t bfi(uint32_t mask, uint32_t a, uint32_t b) {  // (a & mask) | (b & ~mask)
+    uint32_t r;
+    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(r) : "s"(mask), "v"(a), "v"(b));
+    return r;
+}
+
+template <typename CT> struct Bits;
+template <> struct Bits<float> { using U = uint32_t; };
+template <> struct Bits<double> { using U = uint64_t; };
+
+template <typename CT>
+__device__ __forceinline__ CT lds_ld(const char *lds, uint32_t a) { return *reinterpret_cast<const CT *>(lds + a); }
+template <typename CT>
+__device__ __forceinline__ void lds_st(char *lds, uint32_t a, CT v) { *reinterpret_cast<CT *>(lds + a) = v; }
+// rebuild message k of a row from its record.  F bit (D-1-k) = sign of ne_k.
+template <int D, int K>
+__device__ __forceinline__ float rec_msg(float m1s, float m2s, uint32_t sgi, uint32_t idx) {
+    float mag = (idx == (uint32_t)K) ? m2s : m1s;
+    uint32_t sgn = sgi << (31 - (D - 1 - K));
+    return __uint_as_float(bfi(0x7fffffffu, __float_as_uint(mag), sgn));
+}
+template <int D, int K>
+__device__ __forceinline__ double rec_msg(double m1s, double m2s, uint32_t sgi, uint32_t idx) {
+    double mag = (idx == (uint32_t)K) ? m2s : m1s;
+    return ((sgi >> (D - 1 - K)) & 1u) ? -mag : mag;
+}
+
+// phase A for the RPL rows (r0 + 64h) a lane owns in one block row of degree D: returns whether any
+// of them has odd parity of hard(lam) (a non-zero syndrome bit); updates the records.
+template <typename CT, int D, int RPL, bool SYNDROME_ONLY>
+__device__ __forceinline__ bool rows_phase_a(const char *lds, ctab_t tabrow, uint32_t p4, uint32_t vmask,
+                                             CT *m1s, CT *m2s, uint32_t *sgi) {
+    constexpr uint32_t ES = sizeof(CT);
+    asm volatile("" : "+v"(p4));
+    CT l[RPL][D];
+#pragma unroll
+    for (int k = 0; k < D; k++) {
+        uint32_t ent = tabrow[k];  // wave-uniform kernel-argument load -> SGPR
+        uint32_t a = ((p4 + (ent & 0xffffu)) & vmask) | (ent >> 16);
+#pragma unroll
+        for (int h = 0; h < RPL; h++) {
+            // row r0+64h sits 64 elements further round the circulant: for RPL == 2 that is a0 ^ 256 B
+            uint32_t ah = (RPL == 2) ? (a ^ (h * 64 * ES)) : (h == 0 ? a : ((((p4 + 64 * ES * h) + (ent & 0xffffu)) & vmask) | (ent >> 16)));
+            l[h][k] = lds_ld<CT>(lds, ah);
+        }
+    }
+    bool any = false;
+#pragma unroll
+    for (int h = 0; h < RPL; h++) {
+        bool par = false;
+#pragma unroll
+        for (int k = 0; k < D; k++) par ^= (l[h][k] > CT(0));
+        any |= par;
+    }
+    if constexpr (SYNDROME_ONLY) return any;
+#pragma unroll
+    for (int h = 0; h < RPL; h++) {
+        const uint32_t idx = sgi[h] >> 24;
+        CT m1 = CT(INFINITY), m2 = CT(INFINITY);
+        uint32_t nidx = 0, sg = 0;
+        if constexpr (sizeof(CT) == 4) {
+            uint32_t X = 0;
+            static_for<0, D>([&](auto kc) {
+                constexpr int k = decltype(kc)::value;
+                float ne = rec_msg<D, k>(m1s[h], m2s[h], sgi[h], idx);
+                float t = l[h][k] - ne;
+                uint32_t tb = __float_as_uint(t);
+                X ^= tb;
+                sg = __builtin_amdgcn_alignbit(sg, tb, 31);  // sg = (sg << 1) | sign(t)
+                float a = fabsf(t);
+                nidx = (a < m1) ? (uint32_t)k : nidx;
+                m2 = __builtin_amdgcn_fmed3f(m1, m2, a);
+                m1 = fminf(m1, a);
+            });
+            // sign of ne'_k = sign-parity of all t, xor sign(t_k), xor (D odd)   ("min-sum signs")
+            uint32_t Xc = X ^ ((D & 1) ? 0x80000000u : 0u);
+            uint32_t F = sg ^ (uint32_t)((int32_t)Xc >> 31);
+            asm("" : "+v"(nidx));  // keep k small: (k << 24) constants would otherwise occupy 18 VGPRs
+            sgi[h] = (nidx << 24) | (F & ((1u << D) - 1u));
+        } else {
+            unsigned sx = 0;
+            static_for<0, D>([&](auto kc) {
+                constexpr int k = decltype(kc)::value;
+                double ne = rec_msg<D, k>(m1s[h], m2s[h], sgi[h], idx);
+                double t = l[h][k] - ne;
+                unsigned s = (unsigned)(__double_as_longlong(t) >> 63) & 1u;
+                sx ^= s;
+                sg = (sg << 1) | s;
+                double a = fabs(t);
+                if (a < m1) { m2 = m1; m1 = a; nidx = k; }
+                else if (a < m2) { m2 = a; }
+            });
+            uint32_t flip = (sx ^ (D & 1)) ? ((1u << D) - 1u) : 0u;
+            sgi[h] = (nidx << 24) | ((sg ^ flip) & ((1u << D) - 1u));
+        }
+        m1s[h] = CT(0.75) * m1;  // |(-3/4) * acc|: the one rounding of Min.hs:78
+        m2s[h] = CT(0.75) * m2;
+    }
+    return any;
+}
+
+// phase B for the same rows: lam[col_k] += ne'_k.  All D x RPL targets of one block row are distinct
+// columns, so the row is done as: read every target, add, write every target back (three batches; one
+// ds_read and one ds_write per edge).  NOT ds_add_f32: LDS float atomics serialise to ~1 lane/clk on
+// gfx950 (tools/microbench_lds.hip: 75 clk per wave-instruction vs 11 for read+add+write).
+template <typename CT, int D, int RPL>
+__device__ __forceinline__ void rows_phase_b(char *lds, ctab_t tabrow, uint32_t p4, uint32_t vmask,
+                                             const CT *m1s, const CT *m2s, const uint32_t *sgi) {
+    constexpr uint32_t ES = sizeof(CT);
+    asm volatile("" : "+v"(p4));
+    uint32_t idx[RPL];
+#pragma unroll
+    for (int h = 0; h < RPL; h++) idx[h] = sgi[h] >> 24;
+    CT cur[RPL][D];
+    uint32_t adr[D];
+#pragma unroll
+    for (int k = 0; k < D; k++) {
+        uint32_t ent = tabrow[k];
+        adr[k] = ((p4 + (ent & 0xffffu)) & vmask) | (ent >> 16);
+#pragma unroll
+        for (int h = 0; h < RPL; h++) {
+            uint32_t ah = (RPL == 2) ? (adr[k] ^ (h * 64 * ES)) : (h == 0 ? adr[k] : ((((p4 + 64 * ES * h) + (ent & 0xffffu)) & vmask) | (ent >> 16)));
+            cur[h][k] = lds_ld<CT>(lds, ah);
+        }
+    }
+    static_for<0, D>([&](auto kc) {
+        constexpr int k = decltype(kc)::value;
+#pragma unroll
+        for (int h = 0; h < RPL; h++) cur[h][k] = rec_msg<D, k>(m1s[h], m2s[h], sgi[h], idx[h]) + cur[h][k];
+    });
+#pragma unroll
+    for (int k = 0; k < D; k++) {
+        uint32_t ent = tabrow[k];
+#pragma unroll
+        for (int h = 0; h < RPL; h++) {
+            uint32_t ah = (RPL == 2) ? (adr[k] ^ (h * 64 * ES)) : (h == 0 ? adr[k] : ((((p4 + 64 * ES * h) + (ent & 0xffffu)) & vmask) | (ent >> 16)));
+            lds_st<CT>(lds, ah, cur[h][k]);
+        }
+    }
+}
+
+// SZ = circulant size; RPL rows per lane per block row (sz/64, >= 1); CPW frames per wave (64/sz, >= 1)
+template <typename CT, class Plan, int SZ>
+struct FusedCfg {
+    static constexpr int RPL = SZ >= 64 ? SZ / 64 : 1;
+    static constexpr int CPW = SZ >= 64 ? 1 : 64 / SZ;
+    static constexpr int V = SZ * CPW;  // "virtual circulant" width in elements (>= 64)
+    static constexpr int N = Plan::NBC * SZ;
+    static constexpr int M = Plan::NBR * SZ;
+    static constexpr int LDS_BYTES = Plan::NBC * V * (int)sizeof(CT);
+    static constexpr int NREC = Plan::NBR * RPL;
+    static constexpr int NORIG = Plan::NBC * RPL;
+    // waves per SIMD we ask the register allocator for
+    static constexpr int WAVES_PER_EU = (sizeof(CT) == 8) ? 1 : (RPL >= 2 ? 2 : 4);
+};
+
+template <typename CT, class Plan, int SZ>
+__global__ __launch_bounds__(64, (FusedCfg<CT, Plan, SZ>::WAVES_PER_EU)) void fused_decode_kernel(FusedArgs A) {
+    using Cfg = FusedCfg<CT, Plan, SZ>;
+    constexpr int RPL = Cfg::RPL, CPW = Cfg::CPW, V = Cfg::V, N = Cfg::N;
+    constexpr uint32_t ES = sizeof(CT);
+    constexpr uint32_t vmask = V * ES - 1;
+    __shared__ __attribute__((aligned(16))) char lds[Cfg::LDS_BYTES];
+
+    const uint32_t lane = threadIdx.x;
+    const uint32_t sub = lane % CPW;  // frame inside the wave
+    const uint32_t r0 = lane / CPW;   // row / column the lane owns inside a block (h = 0)
+    const long long frame = (long long)blockIdx.x * CPW + sub;
+    const bool valid = frame < A.batch;
+    const uint32_t p4 = lane * ES;    // byte position of the lane inside a block column (h = 0)
+    const size_t fN = (size_t)(valid ? frame : 0) * N;
+
+    // ---- channel LLRs -> registers (orig) ; records <- 0 (Min.hs:59-60 orig_ne = 0)
+    CT orig[Cfg::NORIG];  // lanes of padding frames read frame 0 (never written back)
+    if (A.llr_is_f64) {
+        const double *src = reinterpret_cast<const double *>(A.llr) + fN + r0;
+#pragma unroll
+        for (int i = 0; i < Cfg::NORIG; i++) orig[i] = (CT)src[(i / RPL) * SZ + 64 * (i % RPL)];
+    } else {
+        const float *src = reinterpret_cast<const float *>(A.llr) + fN + r0;
+#pragma unroll
+        for (int i = 0; i < Cfg::NORIG; i++) orig[i] = (CT)src[(i / RPL) * SZ + 64 * (i % RPL)];
+    }
+    CT m1s[Cfg::NREC], m2s[Cfg::NREC];
+    uint32_t sgi[Cfg::NREC];
+#pragma unroll
+    for (int i = 0; i < Cfg::NREC; i++) { m1s[i] = CT(0); m2s[i] = CT(0); sgi[i] = 0; }
+
+    if (A.step_mode && valid) {  // teacher-forced state: records given
+        static_for<0, Plan::NBR>([&](auto brc) {
+            constexpr int br = decltype(brc)::value;
+#pragma unroll
+            for (int h = 0; h < RPL; h++) {
+                size_t ri = (size_t)frame * Cfg::M + br * SZ + r0 + 64 * h;
+                m1s[br * RPL + h] = reinterpret_cast<const CT *>(A.st_m1)[ri];
+                m2s[br * RPL + h] = reinterpret_cast<const CT *>(A.st_m2)[ri];
+                sgi[br * RPL + h] = A.st_sg[ri];
+            }
+        });
+    }
+    // ---- lam <- orig (or the given lam in step mode) in LDS
+    static_for<0, Plan::NBC>([&](auto bcc) {
+        constexpr int bc = decltype(bcc)::value;
+#pragma unroll
+        for (int h = 0; h < RPL; h++) {
+            CT v = orig[bc * RPL + h];
+            if (A.step_mode && valid) v = (CT)A.st_lam[fN + bc * SZ + r0 + 64 * h];
+            lds_st<CT>(lds, (p4 + 64 * ES * h) | (bc * V * ES), v);
+        }
+    });
+
+    // lanes that belong to the same frame as this lane
+    unsigned long long fmask = ~0ull;
+    if constexpr (CPW > 1) {
+        unsigned long long m = 0;
+#pragma unroll
+        for (int i = 0; i < 64; i += CPW) m |= 1ull << i;
+        fmask = m << sub;
+    }
+
+    bool active = valid;  // frame still iterating
+    bool converged = false;
+    int n_done = 0;
+    const int turns = A.step_mode ? 1 : A.max_iters;
+
+    for (int n = 0;; n++) {
+        if (!__any(active)) break;
+        if (A.trace && active) {  // lam at the top of loop turn n
+            static_for<0, Plan::NBC>([&](auto bcc) {
+                constexpr int bc = decltype(bcc)::value;
+#pragma unroll
+                for (int h = 0; h < RPL; h++)
+                    A.trace[((size_t)frame * (A.max_iters + 1) + n) * N + bc * SZ + r0 + 64 * h] =
+                        (double)lds_ld<CT>(lds, (p4 + 64 * ES * h) | (bc * V * ES));
+            });
+        }
+        const bool last = (n >= turns);
+        ctab_t tabA = (ctab_t)A.tab + opaque_uniform_zero();
+        // ---- phase A: syndrome + new records (records untouched on the last, syndrome-only turn)
+        bool unsat = false;
+        if (active) {
+            if (!last) {
+                static_for<0, Plan::NBR>([&](auto brc) {
+                    constexpr int br = decltype(brc)::value;
+                    constexpr int D = Plan::deg(br);
+                    unsat |= rows_phase_a<CT, D, RPL, false>(lds, tabA + Plan::ebeg(br), p4, vmask, &m1s[br * RPL], &m2s[br * RPL], &sgi[br * RPL]);
+                });
+            } else {
+                static_for<0, Plan::NBR>([&](auto brc) {
+                    constexpr int br = decltype(brc)::value;
+                    constexpr int D = Plan::deg(br);
+                    unsat |= rows_phase_a<CT, D, RPL, true>(lds, tabA + Plan::ebeg(br), p4, vmask, (CT *)nullptr, (CT *)nullptr, (uint32_t *)nullptr);
+                });
+            }
+        }
+        const unsigned long long ub = __ballot(unsat);  // inactive lanes vote 0
+        const bool frame_unsat = (ub & fmask) != 0ull;
+        if (A.step_mode) {
+            if (valid && r0 == 0) A.st_syn[frame] = frame_unsat ? 0 : 1;
+        } else if (active && !frame_unsat) {  // Min.hs:64: syndrome zero -> return lam
+            converged = true; active = false; n_done = n;
+        }
+        if (last) {                            // Min.hs:65: n >= maxIterations -> return orig_lam
+            if (active) { active = false; n_done = n; }
+            break;
+        }
+        // ---- phase B: lam <- orig ; lam[col] += ne' in descending row order (Min.hs:100-103)
+        if (active) {
+            ctab_t tabB = (ctab_t)A.tab + opaque_uniform_zero();
+            static_for<0, Plan::NBC>([&](auto bcc) {
+                constexpr int bc = decltype(bcc)::value;
+#pragma unroll
+                for (int h = 0; h < RPL; h++) lds_st<CT>(lds, (p4 + 64 * ES * h) | (bc * V * ES), orig[bc * RPL + h]);
+            });
+            static_rfor<0, Plan::NBR>([&](auto brc) {
+                constexpr int br = decltype(brc)::value;
+                constexpr int D = Plan::deg(br);
+                rows_phase_b<CT, D, RPL>(lds, tabB + Plan::ebeg(br), p4, vmask, &m1s[br * RPL], &m2s[br * RPL], &sgi[br * RPL]);
+            });
+        }
+        if (A.step_mode) break;
+    }
+
+    if (!valid) return;
+    if (A.step_mode) {  // state out: lam' and the expanded messages ne' (CSR edge order)
+        static_for<0, Plan::NBC>([&](auto bcc) {
+            constexpr int bc = decltype(bcc)::value;
+#pragma unroll
+            for (int h = 0; h < RPL; h++)
+                A.final_lam[fN + bc * SZ + r0 + 64 * h] = (double)lds_ld<CT>(lds, (p4 + 64 * ES * h) | (bc * V * ES));
+        });
+        static_for<0, Plan::NBR>([&](auto brc) {
+            constexpr int br = decltype(brc)::value;
+            constexpr int D = Plan::deg(br);
+#pragma unroll
+            for (int h = 0; h < RPL; h++) {
+                const uint32_t idx = sgi[br * RPL + h] >> 24;
+                const size_t e0 = (size_t)frame * Plan::NEDGE * SZ + (size_t)SZ * Plan::ebeg(br) + (size_t)D * (r0 + 64 * h);
+                static_for<0, D>([&](auto kc) {
+                    constexpr int k = decltype(kc)::value;
+                    A.st_ne_out[e0 + k] = (double)rec_msg<D, k>(m1s[br * RPL + h], m2s[br * RPL + h], sgi[br * RPL + h], idx);
+                });
+            }
+        });
+        return;
+    }
+    // ---- result: hard(lam) for a converged frame, hard(orig) otherwise (Min.hs:55,64-65)
+    static_for<0, Plan::NBC>([&](auto bcc) {
+        constexpr int bc = decltype(bcc)::value;
+#pragma unroll
+        for (int h = 0; h < RPL; h++) {
+            CT v = converged ? lds_ld<CT>(lds, (p4 + 64 * ES * h) | (bc * V * ES)) : orig[bc * RPL + h];
+            size_t gi = fN + bc * SZ + r0 + 64 * h;
+            A.bits[gi] = v > CT(0) ? 1 : 0;
+            if (A.final_lam) A.final_lam[gi] = (double)v;
+        }
+    });
+    if (r0 == 0) {
+        if (A.iters) A.iters[frame] = n_done;
+        if (A.conv) A.conv[frame] = converged ? 1 : 0;
+    }
+}
+
+// ------------------------------------------------------------------ host side
+struct FusedState {
+    int variant = 0, dtype = 0, max_batch = 0, sz = 0, M = 0, N = 0, E = 0;
+    KernelTimer *timer = nullptr;
+    uint32_t *d_tab = nullptr;
+    std::vector<int32_t> row_ptr;  // host copy for the step-mode record conversion
+};
+
+static bool plan_matches_ar4ja45(const ldpc_code &c) {
+    if (c.sz <= 0 || c.block_rows != PlanAR4JA45::NBR || c.block_cols != PlanAR4JA45::NBC) return false;
+    for (int br = 0; br < c.block_rows; br++) {
+        int d = 0;
+        for (int bc = 0; bc < c.block_cols; bc++) d += c.offsets[(size_t)br * c.block_cols + bc] >= 0;
+        if (d != PlanAR4JA45::deg(br)) return false;
+    }
+    return true;
+}
+
+const char *fused_why_not(const ldpc_code &c, int variant, int dtype) {
+    if (variant != LDPC_MINSUM) return "only the min-sum rule has a fused kernel";
+    if (dtype != LDPC_F32 && dtype != LDPC_F64) return "fused kernel exists for f32 and f64";
+    if (c.sz == 0) return "code was not created from a quasi-cyclic description";
+    if (!(c.sz == 32 || c.sz == 64 || c.sz == 128)) return "circulant size must be 32, 64 or 128";
+    if (!plan_matches_ar4ja45(c)) return "block structure is not the AR4JA rate-4/5 plan (12x44 blocks, row weights 3,3,3,3,18x8)";
+    return nullptr;
+}
+bool fused_supported(const ldpc_code &c, int variant, int dtype) { return fused_why_not(c, variant, dtype) == nullptr; }
+
+template <typename CT, int SZ>
+static int launch(FusedState &s, hipStream_t st, FusedArgs &a) {
+    using Cfg = FusedCfg<CT, PlanAR4JA45, SZ>;
+    const int grid = (a.batch + Cfg::CPW - 1) / Cfg::CPW;
+    auto kern = fused_decode_kernel<CT, PlanAR4JA45, SZ>;
+    if (s.timer && !a.step_mode) s.timer->begin(st);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64), 0, st, a);
+    if (s.timer && !a.step_mode) s.timer->end(st);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return set_error(LDPC_EHIP, "fused launch: %s", hipGetErrorString(e));
+    return LDPC_OK;
+}
+
+static int dispatch(FusedState &s, hipStream_t st, FusedArgs &a) {
+    if (s.dtype == LDPC_F32) {
+        switch (s.sz) {
+            case 32: return launch<float, 32>(s, st, a);
+            case 64: return launch<float, 64>(s, st, a);
+            case 128: return launch<float, 128>(s, st, a);
+        }
+    } else if (s.dtype == LDPC_F64) {
+        switch (s.sz) {
+            case 32: return launch<double, 32>(s, st, a);
+            case 64: return launch<double, 64>(s, st, a);
+            case 128: return launch<double, 128>(s, st, a);
+        }
+    }
+    return set_error(LDPC_EUNSUPPORTED, "no fused kernel for sz=%d dtype=%d", s.sz, s.dtype);
+}
+
+FusedState *fused_create(const ldpc_code &c, int variant, int dtype, int max_batch) {
+    const char *why = fused_why_not(c, variant, dtype);
+    if (why) { set_error(LDPC_EUNSUPPORTED, "%s", why); return nullptr; }
+    FusedState *s = new (std::nothrow) FusedState();
+    if (!s) { set_error(LDPC_ENOMEM, "out of host memory"); return nullptr; }
+    s->variant = variant; s->dtype = dtype; s->max_batch = max_batch; s->sz = c.sz; s->M = c.M; s->N = c.N; s->E = c.E;
+    s->row_ptr = c.row_ptr;
+    const int es = dtype == LDPC_F64 ? 8 : 4;
+    const int cpw = c.sz >= 64 ? 1 : 64 / c.sz, V = c.sz * cpw;
+    std::vector<uint32_t> tab;
+    for (int br = 0; br < c.block_rows; br++)
+        for (int bc = 0; bc < c.block_cols; bc++) {
+            int off = c.offsets[(size_t)br * c.block_cols + bc];
+            if (off < 0) continue;
+            uint32_t lo = (uint32_t)(off * cpw * es), hi = (uint32_t)(bc * V * es);
+            if (lo > 0xffffu || hi > 0xffffu) { delete s; set_error(LDPC_EUNSUPPORTED, "graph table field overflow"); return nullptr; }
+            tab.push_back(lo | (hi << 16));
+        }
+    hipError_t e = hipMalloc((void **)&s->d_tab, tab.size() * 4);
+    if (e == hipSuccess) e = hipMemcpy(s->d_tab, tab.data(), tab.size() * 4, hipMemcpyHostToDevice);
+    if (e != hipSuccess) { set_error(LDPC_EHIP, "fused_create: %s", hipGetErrorString(e)); fused_destroy(s); return nullptr; }
+    return s;
+}
+
+void fused_destroy(FusedState *s) {
+    if (!s) return;
+    (void)hipFree(s->d_tab);
+    delete s;
+}
+
+void fused_set_timer(FusedState *s, KernelTimer *t) { if (s) s->timer = t; }
+
+int fused_decode(FusedState &s, hipStream_t st, int max_iters, int batch, const void *d_llr, int llr_is_f64, uint8_t *d_bits,
+                 int32_t *d_iters, uint8_t *d_conv, double *d_final, double *d_trace) {
+    FusedArgs a{};
+    a.tab = s.d_tab; a.llr = d_llr; a.llr_is_f64 = llr_is_f64; a.bits = d_bits; a.iters = d_iters; a.conv = d_conv;
+    a.final_lam = d_final; a.trace = d_trace; a.batch = batch; a.max_iters = max_iters; a.step_mode = 0;
+    return dispatch(s, st, a);
+}
+
+// teacher-forced step: the oracle's messages of a row take at most two magnitudes (that is what
+// min-sum produces), so they convert losslessly to the kernel's row record on the host.
+template <typename CT>
+static int step_typed(FusedState &s, hipStream_t st, int batch, const double *d_orig, const double *d_lam, const double *d_ne,
+                      double *d_ne_out, double *d_lam_out, uint8_t *d_syn) {
+    const size_t B = (size_t)batch, M = (size_t)s.M, E = (size_t)s.E;
+    std::vector<double> ne(B * E);
+    hipError_t e = hipMemcpyAsync(ne.data(), d_ne, B * E * 8, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) return set_error(LDPC_EHIP, "fused_step: %s", hipGetErrorString(e));
+    std::vector<CT> m1(B * M), m2(B * M);
+    std::vector<uint32_t> sg(B * M);
+    for (size_t f = 0; f < B; f++)
+        for (size_t m = 0; m < M; m++) {
+            const int b = s.row_ptr[m], D = s.row_ptr[m + 1] - b;
+            const double *x = &ne[f * E + b];
+            double lo = INFINITY, hi = 0;
+            for (int k = 0; k < D; k++) { lo = std::min(lo, fabs(x[k])); hi = std::max(hi, fabs(x[k])); }
+            int idx = 0, nhi = 0;
+            uint32_t F = 0;
+            for (int k = 0; k < D; k++) {
+                if (fabs(x[k]) == hi && hi != lo) { idx = k; nhi++; }
+                else if (fabs(x[k]) != lo) return set_error(LDPC_EINVAL, "fused_step: row %zu holds more than two message magnitudes", m);
+                if (std::signbit(x[k])) F |= 1u << (D - 1 - k);
+            }
+            if (nhi > 1) return set_error(LDPC_EINVAL, "fused_step: row %zu is not a min-sum state", m);
+            m1[f * M + m] = (CT)lo; m2[f * M + m] = (CT)(nhi ? hi : lo);
+            sg[f * M + m] = ((uint32_t)idx << 24) | F;
+        }
+    void *dm1 = nullptr, *dm2 = nullptr;
+    uint32_t *dsg = nullptr;
+    e = hipMalloc(&dm1, B * M * sizeof(CT));
+    if (e == hipSuccess) e = hipMalloc(&dm2, B * M * sizeof(CT));
+    if (e == hipSuccess) e = hipMalloc((void **)&dsg, B * M * 4);
+    if (e == hipSuccess) e = hipMemcpyAsync(dm1, m1.data(), B * M * sizeof(CT), hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(dm2, m2.data(), B * M * sizeof(CT), hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(dsg, sg.data(), B * M * 4, hipMemcpyHostToDevice, st);
+    int rc = LDPC_OK;
+    if (e != hipSuccess) rc = set_error(LDPC_EHIP, "fused_step: %s", hipGetErrorString(e));
+    if (rc == LDPC_OK) {
+        FusedArgs a{};
+        a.tab = s.d_tab; a.llr = d_orig; a.llr_is_f64 = 1; a.batch = batch; a.max_iters = 1; a.step_mode = 1;
+        a.st_lam = d_lam; a.st_m1 = dm1; a.st_m2 = dm2; a.st_sg = dsg; a.st_ne_out = d_ne_out; a.final_lam = d_lam_out; a.st_syn = d_syn;
+        rc = dispatch(s, st, a);
+    }
+    (void)hipStreamSynchronize(st);
+    (void)hipFree(dm1); (void)hipFree(dm2); (void)hipFree(dsg);
+    return rc;
+}
+
+int fused_step(FusedState &s, hipStream_t st, int batch, const double *d_orig, const double *d_lam, const double *d_ne,
+               double *d_ne_out, double *d_lam_out, uint8_t *d_syn) {
+    if (s.dtype == LDPC_F64) return step_typed<double>(s, st, batch, d_orig, d_lam, d_ne, d_ne_out, d_lam_out, d_syn);
+    return step_typed<float>(s, st, batch, d_orig, d_lam, d_ne, d_ne_out, d_lam_out, d_syn);
+}
+
 }  // namespace ldpc

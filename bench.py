@@ -56,6 +56,7 @@ def main():
         raise SystemExit("for --gpus > 1 launch through torch.distributed.run (one process per GPU)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -115,11 +116,10 @@ def main():
     tally[1] = (wrong > 0).sum()
     tally[2] = wrong.sum()
     tally[3] = iters_t.sum()
-    el = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(el, op=dist.ReduceOp.MAX)
-        dist.all_reduce(tally, op=dist.ReduceOp.SUM)  # the path's only collective: 32 bytes over RCCL/xGMI
-    elapsed = float(el.item())
+    from ecc_ldpc_amd import harness
+    dist_mod = dist if world > 1 else None
+    elapsed = harness.max_over_ranks(t1 - t0, dev, dist_mod)
+    harness.all_reduce_tallies(tally, dist_mod)  # the path's only collective: 32 bytes over RCCL/xGMI
     frames_total = world * args.steps * B
     value = frames_total * k / elapsed / 1e6
 

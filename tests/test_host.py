@@ -1,0 +1,125 @@
+"""The C++ host mirror: matrix ingest against the oracle-side parsers (CPU), the mkLDPC record and the
+device frame source (GPU)."""
+import os
+
+import numpy as np
+import pytest
+
+import ecc_ldpc_amd as E
+from oracle import formats, oracle
+from tests.helpers import CODES, load
+
+
+def test_loaders_match_the_restated_parsers():
+    for name in ("jpl.1024.4.5", "jpl.4096.4.5"):
+        for which in ("H", "G"):
+            m = E.Matrix.load(CODES, f"{name}/{which}")
+            sz, rows = formats.read_qc(open(os.path.join(CODES, name, f"{which}.q")).read())
+            assert (m.sz, m.block_rows, m.block_cols) == (sz, len(rows), len(rows[0]))
+            assert np.array_equal(m.dense(), formats.qc_expand(sz, rows))
+            if which == "H":
+                assert np.array_equal(m.qc_offsets(), formats.qc_offsets(sz, rows))
+            else:
+                with pytest.raises(E.LdpcError) as e:  # G blocks are dense circulants: Arraylet.hs:72-73 errors
+                    m.qc_offsets()
+                assert e.value.code == -5
+    mo = E.Matrix.load(CODES, "moon.7.13/H")
+    assert mo.sz == 0 and np.array_equal(mo.dense(), load("moon.7.13").H)
+    mk = E.Matrix.load_mackay(os.path.join(CODES, "1920.1280.3.303"))
+    assert np.array_equal(mk.dense(), load("1920.1280.3.303").H)
+
+
+def test_loader_search_order_and_errors(tmp_path):
+    d = tmp_path / "c" / "x"
+    d.mkdir(parents=True)
+    (d / "H.m").write_text("1 0 1\n0 1 1\n")
+    m = E.Matrix.load(str(tmp_path / "c"), "x/H")
+    assert np.array_equal(m.dense(), [[1, 0, 1], [0, 1, 1]])
+    (d / "H.alist").write_text("2 3\n2 2\n2 2\n1 1 2\n1 3\n2 3\n1\n2\n1 2\n")
+    m = E.Matrix.load(str(tmp_path / "c"), "x/H")  # .alist is tried before .m (Loader.hs:53-57)
+    assert np.array_equal(m.dense(), [[1, 0, 1], [0, 1, 1]])
+    (d / "H.q").write_text("4\n1 0\n2 8\n")       # .q before both
+    m = E.Matrix.load(str(tmp_path / "c"), "x/H")
+    assert (m.rows, m.cols, m.sz) == (8, 8, 4)
+    assert np.array_equal(m.dense(), formats.qc_expand(4, [[1, 0], [2, 8]]))
+    with pytest.raises(E.LdpcError) as e:
+        E.Matrix.load(str(tmp_path / "c"), "nope/H")
+    assert e.value.code == -8
+    (d / "H.q").write_text("4\n1 x\n")
+    with pytest.raises(E.LdpcError) as e:
+        E.Matrix.load(str(tmp_path / "c"), "x/H")
+    assert e.value.code == -7
+    (d / "H.q").write_text("4\n16 0\n")  # bit above the cycle size
+    with pytest.raises(E.LdpcError):
+        E.Matrix.load(str(tmp_path / "c"), "x/H")
+
+
+def test_code_name_grammar_rejections():
+    for bad in ("ldpc/reference/jpl.1024.4.5/50", "bpsk", "ldpc/hip-minsum/jpl.1024.4.5/x", "ldpc/hip-minsum/jpl.1024.4.5/50/4"):
+        with pytest.raises(E.LdpcError) as e:
+            E.ECC(CODES, bad)
+        assert e.value.code == -8, bad  # not ours: the factory's `_ -> return []`
+
+
+@pytest.mark.gpu
+def test_ecc_record_mirrors_mkLDPC(hip):
+    ecc = hip.ECC(CODES, "ldpc/hip-minsum/jpl.1024.4.5/50/4/5", max_batch=4)
+    assert ecc.name == "ldpc/hip-minsum/jpl.1024.4.5/50/4/5"
+    assert (ecc.message_length, ecc.codeword_length, ecc.unpunctured_length) == (1024, 1280, 1408)
+    e2 = hip.ECC(CODES, "ldpc/hip-tanh-f64/jpl.1024.4.5/20", max_batch=4)  # no rate: k / cols(H) = 8/11
+    assert e2.name == "ldpc/hip-tanh-f64/jpl.1024.4.5/20/8/11" and e2.codeword_length == 1408
+    c = load("jpl.1024.4.5")
+    rng = np.random.default_rng(3)
+    msg = rng.integers(0, 2, 1024).astype(np.uint8)
+    cw = ecc.encode(msg)
+    assert np.array_equal(cw, c.encode(msg)[:1280])  # systematic, punctured tail dropped (Utils.hs:61)
+    from oracle import channel
+    llr = channel.frames(c.encode(msg)[None, :], 3.5, 1024, 1280, 1408, seed=5)[0]
+    out, ok = ecc.decode(llr[:1280])
+    o = oracle.decode(c.graph, "min", 50, llr)
+    assert ok and np.array_equal(out, o["bits"][:1024])
+    mo = hip.ECC(CODES, "ldpc/hip-tanh/moon.7.13/20", max_batch=2)
+    assert (mo.message_length, mo.codeword_length) == (7, 20)
+    m = load("moon.7.13")
+    msg = np.array([1, 0, 1, 1, 0, 0, 1], np.uint8)
+    assert np.array_equal(mo.encode(msg), m.encode(msg))
+
+
+@pytest.mark.gpu
+def test_device_frame_source(hip):
+    import torch
+    ecc = hip.ECC(CODES, "ldpc/hip-minsum/jpl.1024.4.5/50/4/5", max_batch=512)
+    dev = torch.device("cuda", 0)
+    B, N, k, n_tx = 512, 1408, 1024, 1280
+    llr = torch.empty((B, N), dtype=torch.float32, device=dev)
+    msg = torch.empty((B, k), dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
+    ecc.sim.generate(42, 1000, B, 3.0, llr.data_ptr(), msg.data_ptr(), None)
+    torch.cuda.synchronize()
+    l1, m1 = llr.cpu().numpy().copy(), msg.cpu().numpy().copy()
+    # counter-based: the same (seed, frame id) gives the same frame wherever it is generated
+    ecc.sim.generate(42, 1000 + 100, B - 100, 3.0, llr.data_ptr(), msg.data_ptr(), None)
+    torch.cuda.synchronize()
+    assert np.array_equal(llr.cpu().numpy()[: B - 100], l1[100:]) and np.array_equal(msg.cpu().numpy()[: B - 100], m1[100:])
+    assert (l1[:, n_tx:] == 0).all()                      # punctured tail (Utils.hs:55)
+    assert 0.45 < m1.mean() < 0.55
+    c = load("jpl.1024.4.5")
+    cws = np.stack([c.encode(m) for m in m1[:16]])
+    s2 = 1.0 / (2 * 0.8 * 10 ** 0.3)
+    y = l1[:16, :n_tx] * s2 / 2.0                          # LLR = 2y/sigma^2
+    noise = y - (2.0 * cws[:, :n_tx] - 1.0)
+    assert abs(noise.mean()) < 0.02 and abs(noise.var() / s2 - 1.0) < 0.05
+    allnoise = (l1[:, :n_tx] * s2 / 2.0) - np.sign(l1[:, :n_tx] * 0 + 1) * 0  # (sanity only)
+    assert np.isfinite(allnoise).all()
+    # tally kernel agrees with a host count
+    bits = torch.zeros((B, N), dtype=torch.uint8, device=dev)
+    ecc.sim.generate(42, 1000, B, 3.0, llr.data_ptr(), msg.data_ptr(), None)
+    bits[:, :k] = msg
+    bits[3, 5] ^= 1
+    bits[7, 0:4] ^= 1
+    iters = torch.full((B,), 7, dtype=torch.int32, device=dev)
+    tally = torch.zeros(4, dtype=torch.int64, device=dev)
+    torch.cuda.synchronize()
+    ecc.sim.tally(B, bits.data_ptr(), iters.data_ptr(), tally.data_ptr(), None)
+    torch.cuda.synchronize()
+    assert tally.tolist() == [B, 2, 5, 7 * B]

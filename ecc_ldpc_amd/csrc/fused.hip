@@ -6,10 +6,12 @@
 //       {m1s, m2s, idx, signs}  (= the reference's MinSum2 / `omit` two-min semigroup,
 //       src/ECC/Code/LDPC/Utils.hs:133-144; leave-one-out min is m2 at the argmin, m1 elsewhere)
 //   * channel LLRs (orig)                -> VGPRs
-// Mapping: ONE WAVE owns one frame (sz >= 64; lane l owns rows l, l+64, .. of every circulant) or
-// 64/sz frames (sz < 64; lane l -> frame l % cpw, row l / cpw).  Waves never communicate: there
-// is no barrier, no atomic and no cross-lane traffic in the iteration loop; DS operations of one
-// wave execute in program order, which is what makes the two phases below race-free.
+// Mapping: a frame is owned by a workgroup of WPF waves, one circulant row per lane and block row:
+//   sz = 128 : WPF = 2 (128 threads, thread t owns row t of every circulant), 7 frames = 14 waves per CU
+//   sz = 64  : WPF = 1, one frame per wave;   sz = 32 : one wave holds 2 frames (lane -> frame l&1, row l>>1)
+// With WPF = 1 waves never communicate (no barrier, no atomic, no shuffle): the only ordering used is
+// a wave's in-order DS queue.  With WPF = 2 the two waves meet at s_barrier between the ordered steps
+// of phase B (block rows must be added in descending order and share columns) and to OR their syndromes.
 //
 // Loop turn n (src/ECC/Code/LDPC/Reference/Min.hs:63-67 == Orig.hs:67-71):
 //   phase A  for every row the lane owns: gather lam[col] from LDS (consecutive lanes hit
@@ -120,7 +122,7 @@ __device__ __forceinline__ double rec_msg(double m1s, double m2s, uint32_t sgi, 
 
 // phase A for the RPL rows (r0 + 64h) a lane owns in one block row of degree D: returns whether any
 // of them has odd parity of hard(lam) (a non-zero syndrome bit); updates the records.
-template <typename CT, int D, int RPL, bool SYNDROME_ONLY>
+template <typename CT, int D, int RPL, int HSTEP, bool SYNDROME_ONLY>
 __device__ __forceinline__ bool rows_phase_a(const char *lds, ctab_t tabrow, uint32_t p4, uint32_t vmask,
                                              CT *m1s, CT *m2s, uint32_t *sgi) {
     constexpr uint32_t ES = sizeof(CT);
@@ -132,8 +134,8 @@ __device__ __forceinline__ bool rows_phase_a(const char *lds, ctab_t tabrow, uin
         uint32_t a = ((p4 + (ent & 0xffffu)) & vmask) | (ent >> 16);
 #pragma unroll
         for (int h = 0; h < RPL; h++) {
-            // row r0+64h sits 64 elements further round the circulant: for RPL == 2 that is a0 ^ 256 B
-            uint32_t ah = (RPL == 2) ? (a ^ (h * 64 * ES)) : (h == 0 ? a : ((((p4 + 64 * ES * h) + (ent & 0xffffu)) & vmask) | (ent >> 16)));
+            // row r0 + h*HSTEP/ES sits half a circulant further round: for RPL == 2 that is a0 ^ HSTEP bytes
+            uint32_t ah = (RPL == 2) ? (a ^ (uint32_t)(h * HSTEP)) : (h == 0 ? a : ((((p4 + HSTEP * h) + (ent & 0xffffu)) & vmask) | (ent >> 16)));
             l[h][k] = lds_ld<CT>(lds, ah);
         }
     }
@@ -196,7 +198,7 @@ __device__ __forceinline__ bool rows_phase_a(const char *lds, ctab_t tabrow, uin
 // columns, so the row is done as: read every target, add, write every target back (three batches; one
 // ds_read and one ds_write per edge).  NOT ds_add_f32: LDS float atomics serialise to ~1 lane/clk on
 // gfx950 (tools/microbench_lds.hip: 75 clk per wave-instruction vs 11 for read+add+write).
-template <typename CT, int D, int RPL>
+template <typename CT, int D, int RPL, int HSTEP>
 __device__ __forceinline__ void rows_phase_b(char *lds, ctab_t tabrow, uint32_t p4, uint32_t vmask,
                                              const CT *m1s, const CT *m2s, const uint32_t *sgi) {
     constexpr uint32_t ES = sizeof(CT);
@@ -212,7 +214,7 @@ __device__ __forceinline__ void rows_phase_b(char *lds, ctab_t tabrow, uint32_t 
         adr[k] = ((p4 + (ent & 0xffffu)) & vmask) | (ent >> 16);
 #pragma unroll
         for (int h = 0; h < RPL; h++) {
-            uint32_t ah = (RPL == 2) ? (adr[k] ^ (h * 64 * ES)) : (h == 0 ? adr[k] : ((((p4 + 64 * ES * h) + (ent & 0xffffu)) & vmask) | (ent >> 16)));
+            uint32_t ah = (RPL == 2) ? (adr[k] ^ (uint32_t)(h * HSTEP)) : (h == 0 ? adr[k] : ((((p4 + HSTEP * h) + (ent & 0xffffu)) & vmask) | (ent >> 16)));
             cur[h][k] = lds_ld<CT>(lds, ah);
         }
     }
@@ -226,36 +228,41 @@ __device__ __forceinline__ void rows_phase_b(char *lds, ctab_t tabrow, uint32_t 
         uint32_t ent = tabrow[k];
 #pragma unroll
         for (int h = 0; h < RPL; h++) {
-            uint32_t ah = (RPL == 2) ? (adr[k] ^ (h * 64 * ES)) : (h == 0 ? adr[k] : ((((p4 + 64 * ES * h) + (ent & 0xffffu)) & vmask) | (ent >> 16)));
+            uint32_t ah = (RPL == 2) ? (adr[k] ^ (uint32_t)(h * HSTEP)) : (h == 0 ? adr[k] : ((((p4 + HSTEP * h) + (ent & 0xffffu)) & vmask) | (ent >> 16)));
             lds_st<CT>(lds, ah, cur[h][k]);
         }
     }
 }
 
-// SZ = circulant size; RPL rows per lane per block row (sz/64, >= 1); CPW frames per wave (64/sz, >= 1)
+// SZ = circulant size.  WPF waves per frame, RPL rows per lane and block row, CPW frames per wave.
 template <typename CT, class Plan, int SZ>
 struct FusedCfg {
-    static constexpr int RPL = SZ >= 64 ? SZ / 64 : 1;
+    static constexpr int WPF = SZ >= 128 ? 2 : 1;
+    static constexpr int THREADS = 64 * WPF;
+    static constexpr int RPL = SZ >= THREADS ? SZ / THREADS : 1;
     static constexpr int CPW = SZ >= 64 ? 1 : 64 / SZ;
     static constexpr int V = SZ * CPW;  // "virtual circulant" width in elements (>= 64)
     static constexpr int N = Plan::NBC * SZ;
     static constexpr int M = Plan::NBR * SZ;
-    static constexpr int LDS_BYTES = Plan::NBC * V * (int)sizeof(CT);
+    static constexpr int LAM_BYTES = Plan::NBC * V * (int)sizeof(CT);
+    static constexpr int LDS_BYTES = LAM_BYTES + (WPF > 1 ? 16 : 0);
     static constexpr int NREC = Plan::NBR * RPL;
     static constexpr int NORIG = Plan::NBC * RPL;
+    static constexpr int HSTEP = THREADS * (int)sizeof(CT);  // byte distance between a lane's rows
     // waves per SIMD we ask the register allocator for
-    static constexpr int WAVES_PER_EU = (sizeof(CT) == 8) ? 1 : (RPL >= 2 ? 2 : 4);
+    static constexpr int WAVES_PER_EU = (sizeof(CT) == 8) ? (RPL >= 2 ? 1 : 2) : (RPL >= 2 ? 2 : 4);
 };
 
 template <typename CT, class Plan, int SZ>
-__global__ __launch_bounds__(64, (FusedCfg<CT, Plan, SZ>::WAVES_PER_EU)) void fused_decode_kernel(FusedArgs A) {
+__global__ __launch_bounds__((FusedCfg<CT, Plan, SZ>::THREADS), (FusedCfg<CT, Plan, SZ>::WAVES_PER_EU)) void fused_decode_kernel(FusedArgs A) {
     using Cfg = FusedCfg<CT, Plan, SZ>;
-    constexpr int RPL = Cfg::RPL, CPW = Cfg::CPW, V = Cfg::V, N = Cfg::N;
+    constexpr int RPL = Cfg::RPL, CPW = Cfg::CPW, V = Cfg::V, N = Cfg::N, WPF = Cfg::WPF, HSTEP = Cfg::HSTEP;
+    constexpr int RSTEP = Cfg::THREADS;  // row distance between a lane's rows
     constexpr uint32_t ES = sizeof(CT);
     constexpr uint32_t vmask = V * ES - 1;
     __shared__ __attribute__((aligned(16))) char lds[Cfg::LDS_BYTES];
 
-    const uint32_t lane = threadIdx.x;
+    const uint32_t lane = threadIdx.x;  // position inside the frame's workgroup (0 .. 64*WPF-1)
     const uint32_t sub = lane % CPW;  // frame inside the wave
     const uint32_t r0 = lane / CPW;   // row / column the lane owns inside a block (h = 0)
     const long long frame = (long long)blockIdx.x * CPW + sub;
@@ -268,11 +275,11 @@ __global__ __launch_bounds__(64, (FusedCfg<CT, Plan, SZ>::WAVES_PER_EU)) void fu
     if (A.llr_is_f64) {
         const double *src = reinterpret_cast<const double *>(A.llr) + fN + r0;
 #pragma unroll
-        for (int i = 0; i < Cfg::NORIG; i++) orig[i] = (CT)src[(i / RPL) * SZ + 64 * (i % RPL)];
+        for (int i = 0; i < Cfg::NORIG; i++) orig[i] = (CT)src[(i / RPL) * SZ + RSTEP * (i % RPL)];
     } else {
         const float *src = reinterpret_cast<const float *>(A.llr) + fN + r0;
 #pragma unroll
-        for (int i = 0; i < Cfg::NORIG; i++) orig[i] = (CT)src[(i / RPL) * SZ + 64 * (i % RPL)];
+        for (int i = 0; i < Cfg::NORIG; i++) orig[i] = (CT)src[(i / RPL) * SZ + RSTEP * (i % RPL)];
     }
     CT m1s[Cfg::NREC], m2s[Cfg::NREC];
     uint32_t sgi[Cfg::NREC];
@@ -284,7 +291,7 @@ __global__ __launch_bounds__(64, (FusedCfg<CT, Plan, SZ>::WAVES_PER_EU)) void fu
             constexpr int br = decltype(brc)::value;
 #pragma unroll
             for (int h = 0; h < RPL; h++) {
-                size_t ri = (size_t)frame * Cfg::M + br * SZ + r0 + 64 * h;
+                size_t ri = (size_t)frame * Cfg::M + br * SZ + r0 + RSTEP * h;
                 m1s[br * RPL + h] = reinterpret_cast<const CT *>(A.st_m1)[ri];
                 m2s[br * RPL + h] = reinterpret_cast<const CT *>(A.st_m2)[ri];
                 sgi[br * RPL + h] = A.st_sg[ri];
@@ -297,10 +304,12 @@ __global__ __launch_bounds__(64, (FusedCfg<CT, Plan, SZ>::WAVES_PER_EU)) void fu
 #pragma unroll
         for (int h = 0; h < RPL; h++) {
             CT v = orig[bc * RPL + h];
-            if (A.step_mode && valid) v = (CT)A.st_lam[fN + bc * SZ + r0 + 64 * h];
-            lds_st<CT>(lds, (p4 + 64 * ES * h) | (bc * V * ES), v);
+            if (A.step_mode && valid) v = (CT)A.st_lam[fN + bc * SZ + r0 + RSTEP * h];
+            lds_st<CT>(lds, (p4 + HSTEP * h) | (bc * V * ES), v);
         }
     });
+
+    if constexpr (WPF > 1) __syncthreads();  // the other wave's half of lam must be in LDS before turn 0 gathers it
 
     // lanes that belong to the same frame as this lane
     unsigned long long fmask = ~0ull;
@@ -323,8 +332,8 @@ __global__ __launch_bounds__(64, (FusedCfg<CT, Plan, SZ>::WAVES_PER_EU)) void fu
                 constexpr int bc = decltype(bcc)::value;
 #pragma unroll
                 for (int h = 0; h < RPL; h++)
-                    A.trace[((size_t)frame * (A.max_iters + 1) + n) * N + bc * SZ + r0 + 64 * h] =
-                        (double)lds_ld<CT>(lds, (p4 + 64 * ES * h) | (bc * V * ES));
+                    A.trace[((size_t)frame * (A.max_iters + 1) + n) * N + bc * SZ + r0 + RSTEP * h] =
+                        (double)lds_ld<CT>(lds, (p4 + HSTEP * h) | (bc * V * ES));
             });
         }
         const bool last = (n >= turns);
@@ -336,18 +345,24 @@ __global__ __launch_bounds__(64, (FusedCfg<CT, Plan, SZ>::WAVES_PER_EU)) void fu
                 static_for<0, Plan::NBR>([&](auto brc) {
                     constexpr int br = decltype(brc)::value;
                     constexpr int D = Plan::deg(br);
-                    unsat |= rows_phase_a<CT, D, RPL, false>(lds, tabA + Plan::ebeg(br), p4, vmask, &m1s[br * RPL], &m2s[br * RPL], &sgi[br * RPL]);
+                    unsat |= rows_phase_a<CT, D, RPL, HSTEP, false>(lds, tabA + Plan::ebeg(br), p4, vmask, &m1s[br * RPL], &m2s[br * RPL], &sgi[br * RPL]);
                 });
             } else {
                 static_for<0, Plan::NBR>([&](auto brc) {
                     constexpr int br = decltype(brc)::value;
                     constexpr int D = Plan::deg(br);
-                    unsat |= rows_phase_a<CT, D, RPL, true>(lds, tabA + Plan::ebeg(br), p4, vmask, (CT *)nullptr, (CT *)nullptr, (uint32_t *)nullptr);
+                    unsat |= rows_phase_a<CT, D, RPL, HSTEP, true>(lds, tabA + Plan::ebeg(br), p4, vmask, (CT *)nullptr, (CT *)nullptr, (uint32_t *)nullptr);
                 });
             }
         }
         const unsigned long long ub = __ballot(unsat);  // inactive lanes vote 0
-        const bool frame_unsat = (ub & fmask) != 0ull;
+        bool frame_unsat = (ub & fmask) != 0ull;
+        if constexpr (WPF > 1) {  // OR over the frame's waves; the barrier also fences phase A reads from phase B writes
+            volatile uint32_t *flags = reinterpret_cast<volatile uint32_t *>(lds + Cfg::LAM_BYTES);
+            if ((lane & 63) == 0) flags[lane >> 6] = frame_unsat ? 1u : 0u;
+            __syncthreads();
+            frame_unsat = (flags[0] | flags[1]) != 0u;
+        }
         if (A.step_mode) {
             if (valid && r0 == 0) A.st_syn[frame] = frame_unsat ? 0 : 1;
         } else if (active && !frame_unsat) {  // Min.hs:64: syndrome zero -> return lam
@@ -363,12 +378,14 @@ __global__ __launch_bounds__(64, (FusedCfg<CT, Plan, SZ>::WAVES_PER_EU)) void fu
             static_for<0, Plan::NBC>([&](auto bcc) {
                 constexpr int bc = decltype(bcc)::value;
 #pragma unroll
-                for (int h = 0; h < RPL; h++) lds_st<CT>(lds, (p4 + 64 * ES * h) | (bc * V * ES), orig[bc * RPL + h]);
+                for (int h = 0; h < RPL; h++) lds_st<CT>(lds, (p4 + HSTEP * h) | (bc * V * ES), orig[bc * RPL + h]);
             });
+            if constexpr (WPF > 1) __syncthreads();
             static_rfor<0, Plan::NBR>([&](auto brc) {
                 constexpr int br = decltype(brc)::value;
                 constexpr int D = Plan::deg(br);
-                rows_phase_b<CT, D, RPL>(lds, tabB + Plan::ebeg(br), p4, vmask, &m1s[br * RPL], &m2s[br * RPL], &sgi[br * RPL]);
+                rows_phase_b<CT, D, RPL, HSTEP>(lds, tabB + Plan::ebeg(br), p4, vmask, &m1s[br * RPL], &m2s[br * RPL], &sgi[br * RPL]);
+                if constexpr (WPF > 1) __syncthreads();  // block rows share columns: next one only after this one landed
             });
         }
         if (A.step_mode) break;
@@ -380,7 +397,7 @@ __global__ __launch_bounds__(64, (FusedCfg<CT, Plan, SZ>::WAVES_PER_EU)) void fu
             constexpr int bc = decltype(bcc)::value;
 #pragma unroll
             for (int h = 0; h < RPL; h++)
-                A.final_lam[fN + bc * SZ + r0 + 64 * h] = (double)lds_ld<CT>(lds, (p4 + 64 * ES * h) | (bc * V * ES));
+                A.final_lam[fN + bc * SZ + r0 + RSTEP * h] = (double)lds_ld<CT>(lds, (p4 + HSTEP * h) | (bc * V * ES));
         });
         static_for<0, Plan::NBR>([&](auto brc) {
             constexpr int br = decltype(brc)::value;
@@ -388,7 +405,7 @@ __global__ __launch_bounds__(64, (FusedCfg<CT, Plan, SZ>::WAVES_PER_EU)) void fu
 #pragma unroll
             for (int h = 0; h < RPL; h++) {
                 const uint32_t idx = sgi[br * RPL + h] >> 24;
-                const size_t e0 = (size_t)frame * Plan::NEDGE * SZ + (size_t)SZ * Plan::ebeg(br) + (size_t)D * (r0 + 64 * h);
+                const size_t e0 = (size_t)frame * Plan::NEDGE * SZ + (size_t)SZ * Plan::ebeg(br) + (size_t)D * (r0 + RSTEP * h);
                 static_for<0, D>([&](auto kc) {
                     constexpr int k = decltype(kc)::value;
                     A.st_ne_out[e0 + k] = (double)rec_msg<D, k>(m1s[br * RPL + h], m2s[br * RPL + h], sgi[br * RPL + h], idx);
@@ -402,8 +419,8 @@ __global__ __launch_bounds__(64, (FusedCfg<CT, Plan, SZ>::WAVES_PER_EU)) void fu
         constexpr int bc = decltype(bcc)::value;
 #pragma unroll
         for (int h = 0; h < RPL; h++) {
-            CT v = converged ? lds_ld<CT>(lds, (p4 + 64 * ES * h) | (bc * V * ES)) : orig[bc * RPL + h];
-            size_t gi = fN + bc * SZ + r0 + 64 * h;
+            CT v = converged ? lds_ld<CT>(lds, (p4 + HSTEP * h) | (bc * V * ES)) : orig[bc * RPL + h];
+            size_t gi = fN + bc * SZ + r0 + RSTEP * h;
             A.bits[gi] = v > CT(0) ? 1 : 0;
             if (A.final_lam) A.final_lam[gi] = (double)v;
         }
@@ -448,7 +465,7 @@ static int launch(FusedState &s, hipStream_t st, FusedArgs &a) {
     const int grid = (a.batch + Cfg::CPW - 1) / Cfg::CPW;
     auto kern = fused_decode_kernel<CT, PlanAR4JA45, SZ>;
     if (s.timer && !a.step_mode) s.timer->begin(st);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(64), 0, st, a);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(Cfg::THREADS), 0, st, a);
     if (s.timer && !a.step_mode) s.timer->end(st);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return set_error(LDPC_EHIP, "fused launch: %s", hipGetErrorString(e));

@@ -464,7 +464,7 @@ int ldpc_ctx_kernel_time(ldpc_ctx *ctx, int *launches, double *total_ms) {
 
 const char *ldpc_ctx_kernel_name(const ldpc_ctx *ctx) {
     if (!ctx) return "";
-    return ctx->path == LDPC_PATH_FUSED ? "fused_decode_kernel" : "flood_cn_kernel";
+    return ctx->path == LDPC_PATH_FUSED ? "fused_" : "flood_cn_kernel";  // fused_msg_kernel / fused_decode_kernel
 }
 
 // ------------------------------------------------------------------------------- frame source

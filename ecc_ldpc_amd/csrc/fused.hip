@@ -28,6 +28,7 @@
 //   lo 16 bits = rotation * cpw * sizeof(CT)   (byte rotation inside a block column)
 //   hi 16 bits = bc * V * sizeof(CT)           (byte base of the block column in LDS)
 // The degree sequence of the block rows is a compile-time Plan (registers must be named statically).
+#include <stdlib.h>
 #include <string.h>
 
 #include <type_traits>
@@ -36,77 +37,10 @@
 
 #include "fused.h"
 #include "ldpc_math.h"
+#include "fused_common.h"
 
 namespace ldpc {
 
-// ------------------------------------------------------------------ plans
-// AR4JA rate-4/5 protograph as shipped in codes/jpl.1024.4.5 and codes/jpl.4096.4.5:
-// 12 x 44 blocks, block rows 0-3 of weight 3, 4-11 of weight 18.
-struct PlanAR4JA45 {
-    static constexpr int NBR = 12, NBC = 44, NEDGE = 4 * 3 + 8 * 18;
-    static constexpr int deg(int br) { return br < 4 ? 3 : 18; }
-    static constexpr int ebeg(int br) { return br < 4 ? 3 * br : 12 + 18 * (br - 4); }
-};
-
-template <int I, int N, class F>
-__device__ __forceinline__ void static_for(F &&f) {
-    if constexpr (I < N) {
-        f(std::integral_constant<int, I>{});
-        static_for<I + 1, N>(f);
-    }
-}
-template <int I, int N, class F>
-__device__ __forceinline__ void static_rfor(F &&f) {  // N-1 down to I
-    if constexpr (I < N) {
-        f(std::integral_constant<int, N - 1>{});
-        static_rfor<I, N - 1>(f);
-    }
-}
-
-// the graph table is read through the CONSTANT address space: the kernel never writes it, and only
-// then may the compiler use scalar loads (s_load) although the kernel also stores to global memory.
-typedef const __attribute__((address_space(4))) uint32_t *ctab_t;
-struct FusedArgs {
-    const uint32_t *tab;
-    const void *llr;  // [batch][N] float or double
-    uint8_t *bits;    // [batch][N]
-    int32_t *iters;   // may be null
-    uint8_t *conv;    // may be null
-    double *final_lam;  // may be null [batch][N]
-    double *trace;      // may be null [batch][max_iters+1][N]
-    int batch, max_iters, llr_is_f64;
-    // teacher-forced single step (verification): state in, state out
-    int step_mode;
-    const double *st_lam;  // [batch][N]
-    const void *st_m1, *st_m2;  // [batch][M] CT
-    const uint32_t *st_sg;      // [batch][M]
-    double *st_ne_out;          // [batch][E] CSR edge order
-    uint8_t *st_syn;            // [batch]
-};
-
-// A wave-uniform zero the optimiser cannot see through.  Adding it to the (loop-invariant) graph
-// table pointer keeps the table loads and the address arithmetic INSIDE the iteration loop: hoisted,
-// 156 x RPL addresses would live in VGPRs for the whole decode and spill.  readfirstlane makes the
-// value provably uniform again (inline-asm results count as divergent), so the loads stay s_load.
-__device__ __forceinline__ uint32_t opaque_uniform_zero() {
-    uint32_t z;
-    asm volatile("v_mov_b32 %0, 0" : "=v"(z));
-    return __builtin_amdgcn_readfirstlane(z);
-}
-__device__ __forceinline__ uint32_t bfi(uint32_t mask, uint32_t a, uint32_t b) {  // (a & mask) | (b & ~mask)
-    uint32_t r;
-    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(r) : "s"(mask), "v"(a), "v"(b));
-    return r;
-}
-
-template <typename CT> struct Bits;
-template <> struct Bits<float> { using U = uint32_t; };
-template <> struct Bits<double> { using U = uint64_t; };
-
-template <typename CT>
-__device__ __forceinline__ CT lds_ld(const char *lds, uint32_t a) { return *reinterpret_cast<const CT *>(lds + a); }
-template <typename CT>
-__device__ __forceinline__ void lds_st(char *lds, uint32_t a, CT v) { *reinterpret_cast<CT *>(lds + a) = v; }
 // rebuild message k of a row from its record.  F bit (D-1-k) = sign of ne_k.
 template <int D, int K>
 __device__ __forceinline__ float rec_msg(float m1s, float m2s, uint32_t sgi, uint32_t idx) {
@@ -233,25 +167,6 @@ __device__ __forceinline__ void rows_phase_b(char *lds, ctab_t tabrow, uint32_t 
         }
     }
 }
-
-// SZ = circulant size.  WPF waves per frame, RPL rows per lane and block row, CPW frames per wave.
-template <typename CT, class Plan, int SZ>
-struct FusedCfg {
-    static constexpr int WPF = SZ >= 128 ? 2 : 1;
-    static constexpr int THREADS = 64 * WPF;
-    static constexpr int RPL = SZ >= THREADS ? SZ / THREADS : 1;
-    static constexpr int CPW = SZ >= 64 ? 1 : 64 / SZ;
-    static constexpr int V = SZ * CPW;  // "virtual circulant" width in elements (>= 64)
-    static constexpr int N = Plan::NBC * SZ;
-    static constexpr int M = Plan::NBR * SZ;
-    static constexpr int LAM_BYTES = Plan::NBC * V * (int)sizeof(CT);
-    static constexpr int LDS_BYTES = LAM_BYTES + (WPF > 1 ? 16 : 0);
-    static constexpr int NREC = Plan::NBR * RPL;
-    static constexpr int NORIG = Plan::NBC * RPL;
-    static constexpr int HSTEP = THREADS * (int)sizeof(CT);  // byte distance between a lane's rows
-    // waves per SIMD we ask the register allocator for
-    static constexpr int WAVES_PER_EU = (sizeof(CT) == 8) ? (RPL >= 2 ? 1 : 2) : (RPL >= 2 ? 2 : 4);
-};
 
 template <typename CT, class Plan, int SZ>
 __global__ __launch_bounds__((FusedCfg<CT, Plan, SZ>::THREADS), (FusedCfg<CT, Plan, SZ>::WAVES_PER_EU)) void fused_decode_kernel(FusedArgs A) {
@@ -434,6 +349,7 @@ __global__ __launch_bounds__((FusedCfg<CT, Plan, SZ>::THREADS), (FusedCfg<CT, Pl
 // ------------------------------------------------------------------ host side
 struct FusedState {
     int variant = 0, dtype = 0, max_batch = 0, sz = 0, M = 0, N = 0, E = 0;
+    bool use_msg = true;  // per-edge-message kernel (fused_msg.hip) vs compressed-record kernel (this file)
     KernelTimer *timer = nullptr;
     uint32_t *d_tab = nullptr;
     std::vector<int32_t> row_ptr;  // host copy for the step-mode record conversion
@@ -450,8 +366,8 @@ static bool plan_matches_ar4ja45(const ldpc_code &c) {
 }
 
 const char *fused_why_not(const ldpc_code &c, int variant, int dtype) {
-    if (variant != LDPC_MINSUM) return "only the min-sum rule has a fused kernel";
-    if (dtype != LDPC_F32 && dtype != LDPC_F64) return "fused kernel exists for f32 and f64";
+    if (variant == LDPC_TANH && dtype != LDPC_F32) return "the fused tanh kernel exists for f32 only (f64 tanh: flood path)";
+    if (dtype != LDPC_F32 && dtype != LDPC_F64) return "fused kernels exist for f32 and f64";
     if (c.sz == 0) return "code was not created from a quasi-cyclic description";
     if (!(c.sz == 32 || c.sz == 64 || c.sz == 128)) return "circulant size must be 32, 64 or 128";
     if (!plan_matches_ar4ja45(c)) return "block structure is not the AR4JA rate-4/5 plan (12x44 blocks, row weights 3,3,3,3,18x8)";
@@ -496,6 +412,11 @@ FusedState *fused_create(const ldpc_code &c, int variant, int dtype, int max_bat
     if (!s) { set_error(LDPC_ENOMEM, "out of host memory"); return nullptr; }
     s->variant = variant; s->dtype = dtype; s->max_batch = max_batch; s->sz = c.sz; s->M = c.M; s->N = c.N; s->E = c.E;
     s->row_ptr = c.row_ptr;
+    {   // LDPC_FUSED_KERNEL=rec selects the compressed-record kernel (min-sum only) for A/B measurements
+        const char *k = getenv("LDPC_FUSED_KERNEL");
+        s->use_msg = fused_msg_has(variant, dtype, c.sz) && !(k && !strcmp(k, "rec") && variant == LDPC_MINSUM);
+        if (!s->use_msg && variant != LDPC_MINSUM) { delete s; set_error(LDPC_EUNSUPPORTED, "no fused kernel"); return nullptr; }
+    }
     const int es = dtype == LDPC_F64 ? 8 : 4;
     const int cpw = c.sz >= 64 ? 1 : 64 / c.sz, V = c.sz * cpw;
     std::vector<uint32_t> tab;
@@ -526,6 +447,7 @@ int fused_decode(FusedState &s, hipStream_t st, int max_iters, int batch, const 
     FusedArgs a{};
     a.tab = s.d_tab; a.llr = d_llr; a.llr_is_f64 = llr_is_f64; a.bits = d_bits; a.iters = d_iters; a.conv = d_conv;
     a.final_lam = d_final; a.trace = d_trace; a.batch = batch; a.max_iters = max_iters; a.step_mode = 0;
+    if (s.use_msg) return fused_msg_launch(s.variant, s.dtype, s.sz, st, a, s.timer);
     return dispatch(s, st, a);
 }
 
@@ -581,6 +503,12 @@ static int step_typed(FusedState &s, hipStream_t st, int batch, const double *d_
 
 int fused_step(FusedState &s, hipStream_t st, int batch, const double *d_orig, const double *d_lam, const double *d_ne,
                double *d_ne_out, double *d_lam_out, uint8_t *d_syn) {
+    if (s.use_msg) {  // per-edge messages: the state goes in and out as it is
+        FusedArgs a{};
+        a.tab = s.d_tab; a.llr = d_orig; a.llr_is_f64 = 1; a.batch = batch; a.max_iters = 1; a.step_mode = 1;
+        a.st_lam = d_lam; a.st_ne_in = d_ne; a.st_ne_out = d_ne_out; a.final_lam = d_lam_out; a.st_syn = d_syn;
+        return fused_msg_launch(s.variant, s.dtype, s.sz, st, a, nullptr);
+    }
     if (s.dtype == LDPC_F64) return step_typed<double>(s, st, batch, d_orig, d_lam, d_ne, d_ne_out, d_lam_out, d_syn);
     return step_typed<float>(s, st, batch, d_orig, d_lam, d_ne, d_ne_out, d_lam_out, d_syn);
 }

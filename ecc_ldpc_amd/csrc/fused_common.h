@@ -1,0 +1,107 @@
+// fused_common.h -- pieces shared by the fused on-chip kernels (fused.hip: compressed-record min-sum;
+// fused_msg.hip: per-edge messages in VGPRs, min-sum and tanh).
+#pragma once
+#include <string.h>
+
+#include <type_traits>
+#include <utility>
+
+#include "fused.h"
+#include "ldpc_math.h"
+
+namespace ldpc {
+
+// ------------------------------------------------------------------ plans
+// AR4JA rate-4/5 protograph as shipped in codes/jpl.1024.4.5 and codes/jpl.4096.4.5:
+// 12 x 44 blocks, block rows 0-3 of weight 3, 4-11 of weight 18.
+struct PlanAR4JA45 {
+    static constexpr int NBR = 12, NBC = 44, NEDGE = 4 * 3 + 8 * 18;
+    static constexpr int deg(int br) { return br < 4 ? 3 : 18; }
+    static constexpr int ebeg(int br) { return br < 4 ? 3 * br : 12 + 18 * (br - 4); }
+};
+
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F &&f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+template <int I, int N, class F>
+__device__ __forceinline__ void static_rfor(F &&f) {  // N-1 down to I
+    if constexpr (I < N) {
+        f(std::integral_constant<int, N - 1>{});
+        static_rfor<I, N - 1>(f);
+    }
+}
+
+// the graph table is read through the CONSTANT address space: the kernel never writes it, and only
+// then may the compiler use scalar loads (s_load) although the kernel also stores to global memory.
+typedef const __attribute__((address_space(4))) uint32_t *ctab_t;
+struct FusedArgs {
+    const uint32_t *tab;
+    const void *llr;  // [batch][N] float or double
+    uint8_t *bits;    // [batch][N]
+    int32_t *iters;   // may be null
+    uint8_t *conv;    // may be null
+    double *final_lam;  // may be null [batch][N]
+    double *trace;      // may be null [batch][max_iters+1][N]
+    int batch, max_iters, llr_is_f64;
+    // teacher-forced single step (verification): state in, state out
+    int step_mode;
+    const double *st_lam;  // [batch][N]
+    const void *st_m1, *st_m2;  // [batch][M] CT
+    const uint32_t *st_sg;      // [batch][M]
+    double *st_ne_out;          // [batch][E] CSR edge order
+    const double *st_ne_in;     // [batch][E] (per-edge-message kernels)
+    uint8_t *st_syn;            // [batch]
+};
+
+// A wave-uniform zero the optimiser cannot see through.  Adding it to the (loop-invariant) graph
+// table pointer keeps the table loads and the address arithmetic INSIDE the iteration loop: hoisted,
+// 156 x RPL addresses would live in VGPRs for the whole decode and spill.  readfirstlane makes the
+// value provably uniform again (inline-asm results count as divergent), so the loads stay s_load.
+__device__ __forceinline__ uint32_t opaque_uniform_zero() {
+    uint32_t z;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(z));
+    return __builtin_amdgcn_readfirstlane(z);
+}
+__device__ __forceinline__ uint32_t bfi(uint32_t mask, uint32_t a, uint32_t b) {  // (a & mask) | (b & ~mask)
+    uint32_t r;
+    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(r) : "s"(mask), "v"(a), "v"(b));
+    return r;
+}
+
+template <typename CT> struct Bits;
+template <> struct Bits<float> { using U = uint32_t; };
+template <> struct Bits<double> { using U = uint64_t; };
+
+template <typename CT>
+__device__ __forceinline__ CT lds_ld(const char *lds, uint32_t a) { return *reinterpret_cast<const CT *>(lds + a); }
+template <typename CT>
+__device__ __forceinline__ void lds_st(char *lds, uint32_t a, CT v) { *reinterpret_cast<CT *>(lds + a) = v; }
+// SZ = circulant size.  WPF waves per frame, RPL rows per lane and block row, CPW frames per wave.
+template <typename CT, class Plan, int SZ>
+struct FusedCfg {
+    static constexpr int WPF = SZ >= 128 ? 2 : 1;
+    static constexpr int THREADS = 64 * WPF;
+    static constexpr int RPL = SZ >= THREADS ? SZ / THREADS : 1;
+    static constexpr int CPW = SZ >= 64 ? 1 : 64 / SZ;
+    static constexpr int V = SZ * CPW;  // "virtual circulant" width in elements (>= 64)
+    static constexpr int N = Plan::NBC * SZ;
+    static constexpr int M = Plan::NBR * SZ;
+    static constexpr int LAM_BYTES = Plan::NBC * V * (int)sizeof(CT);
+    static constexpr int LDS_BYTES = LAM_BYTES + (WPF > 1 ? 16 : 0);
+    static constexpr int NREC = Plan::NBR * RPL;
+    static constexpr int NORIG = Plan::NBC * RPL;
+    static constexpr int HSTEP = THREADS * (int)sizeof(CT);  // byte distance between a lane's rows
+    // waves per SIMD we ask the register allocator for
+    static constexpr int WAVES_PER_EU = (sizeof(CT) == 8) ? (RPL >= 2 ? 1 : 2) : (RPL >= 2 ? 2 : 4);
+};
+
+
+// launcher of the per-edge-message kernels (fused_msg.hip)
+bool fused_msg_has(int variant, int dtype, int sz);
+int fused_msg_launch(int variant, int dtype, int sz, hipStream_t st, FusedArgs &a, KernelTimer *timer);
+
+}  // namespace ldpc

@@ -1,0 +1,307 @@
+// fused_msg.hip -- fused on-chip flooding BP with PER-EDGE messages in VGPRs (min-sum and tanh).
+//
+// Same mapping, LDS layout and loop structure as fused.hip (see its header): a frame is owned by a
+// workgroup of WPF waves, lam lives in LDS, one launch decodes the batch.  The difference is the
+// message store: every check->variable message ne[m,n] the thread owns stays in its own VGPR
+// (156 per thread for the AR4JA plan) instead of the 3-register row record.  On gfx950 only
+// f32 add/sub/mul/fma, and/or/xor and add/sub_u32 issue in 2 clk; compares, selects, shifts, bfi,
+// min/max/med3 take 4 (tools/microbench_valu.hip).  Rebuilding messages from records twice per turn
+// costs ~32 of the record kernel's ~76 VALU-clk per edge; here an edge costs ~44:
+//   phase A  t = lam[col] - ne (in place), two-min + sign parity over the row, then
+//            ne' = bfi(|.| = (|t| == m1 ? 0.75 m2 : 0.75 m1), sign = signs(all t) ^ sign(t) ^ (D odd))
+//            (Reference/Min.hs:75-86); tanh rule: ldpc_math.h cn_update (Reference/Orig.hs:81-92)
+//   phase B  lam[col] <- ne' + lam[col], block rows in descending order (Orig.hs:95-98)
+// Price: 200+ VGPRs -> 2 waves per SIMD.
+#include "fused_common.h"
+
+namespace ldpc {
+
+template <int RPL, int HSTEP>
+__device__ __forceinline__ uint32_t row_addr(uint32_t a0, uint32_t p4, uint32_t ent, uint32_t vmask, int h) {
+    if (h == 0) return a0;
+    if (RPL == 2) return a0 ^ (uint32_t)HSTEP;
+    return (((p4 + HSTEP * h) + (ent & 0xffffu)) & vmask) | (ent >> 16);
+}
+
+// phase A for the RPL rows a lane owns in one block row of degree D.  msg: [RPL][D] registers.
+template <typename CT, int VARIANT, int D, int RPL, int HSTEP, bool SYNDROME_ONLY>
+__device__ __forceinline__ bool rows_a(const char *lds, ctab_t tabrow, uint32_t p4, uint32_t vmask, CT *msg) {
+    asm volatile("" : "+v"(p4));
+    CT l[RPL][D];
+#pragma unroll
+    for (int k = 0; k < D; k++) {
+        uint32_t ent = tabrow[k];
+        uint32_t a0 = ((p4 + (ent & 0xffffu)) & vmask) | (ent >> 16);
+#pragma unroll
+        for (int h = 0; h < RPL; h++) l[h][k] = lds_ld<CT>(lds, row_addr<RPL, HSTEP>(a0, p4, ent, vmask, h));
+    }
+    bool any = false;
+#pragma unroll
+    for (int h = 0; h < RPL; h++) {
+        bool par = false;
+#pragma unroll
+        for (int k = 0; k < D; k++) par ^= (l[h][k] > CT(0));
+        any |= par;
+    }
+    if constexpr (SYNDROME_ONLY) return any;
+#pragma unroll
+    for (int h = 0; h < RPL; h++) {
+        CT *m = msg + h * D;
+        if constexpr (VARIANT == LDPC_V_MINSUM && sizeof(CT) == 4) {
+            static_assert(D >= 2, "min-sum needs degree >= 2");
+            uint32_t X = 0;
+            float m1 = INFINITY, m2 = INFINITY;
+            static_for<0, D>([&](auto kc) {
+                constexpr int k = decltype(kc)::value;
+                float t = l[h][k] - m[k];
+                m[k] = t;
+                X ^= __float_as_uint(t);
+                float a = fabsf(t);
+                m2 = __builtin_amdgcn_fmed3f(m1, m2, a);
+                m1 = fminf(m1, a);
+            });
+            const float m1s = 0.75f * m1, m2s = 0.75f * m2;  // the one rounding of Min.hs:78
+            const uint32_t Xc = X ^ ((D & 1) ? 0x80000000u : 0u);
+            static_for<0, D>([&](auto kc) {
+                constexpr int k = decltype(kc)::value;
+                float t = m[k];
+                float mag = (fabsf(t) == m1) ? m2s : m1s;   // leave-one-out min: m2 at the arg-min (ties: m2 == m1)
+                m[k] = __uint_as_float(bfi(0x7fffffffu, __float_as_uint(mag), Xc ^ __float_as_uint(t)));
+            });
+        } else {
+            CT t[D];
+#pragma unroll
+            for (int k = 0; k < D; k++) t[k] = l[h][k] - m[k];
+            cn_update<CT, VARIANT, D>(t);
+#pragma unroll
+            for (int k = 0; k < D; k++) m[k] = t[k];
+        }
+    }
+    return any;
+}
+
+// phase B: lam[col_k] <- ne'_k + lam[col_k]; the D x RPL targets of a block row are distinct columns
+template <typename CT, int D, int RPL, int HSTEP>
+__device__ __forceinline__ void rows_b(char *lds, ctab_t tabrow, uint32_t p4, uint32_t vmask, const CT *msg) {
+    asm volatile("" : "+v"(p4));
+    CT cur[RPL][D];
+    uint32_t adr[D];
+#pragma unroll
+    for (int k = 0; k < D; k++) {
+        uint32_t ent = tabrow[k];
+        adr[k] = ((p4 + (ent & 0xffffu)) & vmask) | (ent >> 16);
+#pragma unroll
+        for (int h = 0; h < RPL; h++) cur[h][k] = lds_ld<CT>(lds, row_addr<RPL, HSTEP>(adr[k], p4, ent, vmask, h));
+    }
+#pragma unroll
+    for (int k = 0; k < D; k++) {
+        uint32_t ent = tabrow[k];
+#pragma unroll
+        for (int h = 0; h < RPL; h++) lds_st<CT>(lds, row_addr<RPL, HSTEP>(adr[k], p4, ent, vmask, h), msg[h * D + k] + cur[h][k]);
+    }
+}
+
+template <typename CT, int VARIANT, class Plan, int SZ>
+struct MsgCfg : FusedCfg<CT, Plan, SZ> {
+    using B = FusedCfg<CT, Plan, SZ>;
+    static constexpr int NMSG = Plan::NEDGE * B::RPL;
+    // messages + orig + row temporaries: > 168 VGPRs whatever we do -> plan for 2 waves per SIMD
+    static constexpr int WAVES_PER_EU = (sizeof(CT) == 8 || B::RPL >= 2) ? 1 : 2;
+};
+
+template <typename CT, int VARIANT, class Plan, int SZ>
+__global__ __launch_bounds__((MsgCfg<CT, VARIANT, Plan, SZ>::THREADS), (MsgCfg<CT, VARIANT, Plan, SZ>::WAVES_PER_EU)) void fused_msg_kernel(FusedArgs A) {
+    using Cfg = MsgCfg<CT, VARIANT, Plan, SZ>;
+    constexpr int RPL = Cfg::RPL, CPW = Cfg::CPW, V = Cfg::V, N = Cfg::N, WPF = Cfg::WPF, HSTEP = Cfg::HSTEP;
+    constexpr int RSTEP = Cfg::THREADS;
+    constexpr uint32_t ES = sizeof(CT);
+    constexpr uint32_t vmask = V * ES - 1;
+    __shared__ __attribute__((aligned(16))) char lds[Cfg::LDS_BYTES];
+
+    const uint32_t lane = threadIdx.x;
+    const uint32_t sub = lane % CPW;
+    const uint32_t r0 = lane / CPW;
+    const long long frame = (long long)blockIdx.x * CPW + sub;
+    const bool valid = frame < A.batch;
+    const uint32_t p4 = lane * ES;
+    const size_t fN = (size_t)(valid ? frame : 0) * N;
+    const size_t fE = (size_t)(valid ? frame : 0) * Plan::NEDGE * SZ;
+
+    CT orig[Cfg::NORIG];
+    if (A.llr_is_f64) {
+        const double *src = reinterpret_cast<const double *>(A.llr) + fN + r0;
+#pragma unroll
+        for (int i = 0; i < Cfg::NORIG; i++) orig[i] = (CT)src[(i / RPL) * SZ + RSTEP * (i % RPL)];
+    } else {
+        const float *src = reinterpret_cast<const float *>(A.llr) + fN + r0;
+#pragma unroll
+        for (int i = 0; i < Cfg::NORIG; i++) orig[i] = (CT)src[(i / RPL) * SZ + RSTEP * (i % RPL)];
+    }
+    // messages: index ebeg(br)*RPL + h*D + k ; Orig.hs:64-65 orig_ne = 0
+    CT msg[Cfg::NMSG];
+#pragma unroll
+    for (int i = 0; i < Cfg::NMSG; i++) msg[i] = CT(0);
+    if (A.step_mode) {  // teacher-forced state: messages given in CSR edge order (row-major, ascending column)
+        static_for<0, Plan::NBR>([&](auto brc) {
+            constexpr int br = decltype(brc)::value;
+            constexpr int D = Plan::deg(br);
+#pragma unroll
+            for (int h = 0; h < RPL; h++)
+#pragma unroll
+                for (int k = 0; k < D; k++)
+                    msg[Plan::ebeg(br) * RPL + h * D + k] = (CT)A.st_ne_in[fE + (size_t)SZ * Plan::ebeg(br) + (size_t)D * (r0 + RSTEP * h) + k];
+        });
+    }
+    static_for<0, Plan::NBC>([&](auto bcc) {
+        constexpr int bc = decltype(bcc)::value;
+#pragma unroll
+        for (int h = 0; h < RPL; h++) {
+            CT v = orig[bc * RPL + h];
+            if (A.step_mode) v = (CT)A.st_lam[fN + bc * SZ + r0 + RSTEP * h];
+            lds_st<CT>(lds, (p4 + HSTEP * h) | (bc * V * ES), v);
+        }
+    });
+    if constexpr (WPF > 1) __syncthreads();
+
+    unsigned long long fmask = ~0ull;
+    if constexpr (CPW > 1) {
+        unsigned long long m = 0;
+#pragma unroll
+        for (int i = 0; i < 64; i += CPW) m |= 1ull << i;
+        fmask = m << sub;
+    }
+
+    bool active = valid;
+    bool converged = false;
+    int n_done = 0;
+    const int turns = A.step_mode ? 1 : A.max_iters;
+
+    for (int n = 0;; n++) {
+        if (!__any(active)) break;
+        if (A.trace && active) {
+            static_for<0, Plan::NBC>([&](auto bcc) {
+                constexpr int bc = decltype(bcc)::value;
+#pragma unroll
+                for (int h = 0; h < RPL; h++)
+                    A.trace[((size_t)frame * (A.max_iters + 1) + n) * N + bc * SZ + r0 + RSTEP * h] =
+                        (double)lds_ld<CT>(lds, (p4 + HSTEP * h) | (bc * V * ES));
+            });
+        }
+        const bool last = (n >= turns);
+        ctab_t tabA = (ctab_t)A.tab + opaque_uniform_zero();
+        bool unsat = false;
+        if (active) {
+            if (!last) {
+                static_for<0, Plan::NBR>([&](auto brc) {
+                    constexpr int br = decltype(brc)::value;
+                    unsat |= rows_a<CT, VARIANT, Plan::deg(br), RPL, HSTEP, false>(lds, tabA + Plan::ebeg(br), p4, vmask, &msg[Plan::ebeg(br) * RPL]);
+                });
+            } else {
+                static_for<0, Plan::NBR>([&](auto brc) {
+                    constexpr int br = decltype(brc)::value;
+                    unsat |= rows_a<CT, VARIANT, Plan::deg(br), RPL, HSTEP, true>(lds, tabA + Plan::ebeg(br), p4, vmask, (CT *)nullptr);
+                });
+            }
+        }
+        const unsigned long long ub = __ballot(unsat);
+        bool frame_unsat = (ub & fmask) != 0ull;
+        if constexpr (WPF > 1) {
+            volatile uint32_t *flags = reinterpret_cast<volatile uint32_t *>(lds + Cfg::LAM_BYTES);
+            if ((lane & 63) == 0) flags[lane >> 6] = frame_unsat ? 1u : 0u;
+            __syncthreads();
+            frame_unsat = (flags[0] | flags[1]) != 0u;
+        }
+        if (A.step_mode) {
+            if (valid && r0 == 0) A.st_syn[frame] = frame_unsat ? 0 : 1;
+        } else if (active && !frame_unsat) {
+            converged = true; active = false; n_done = n;
+        }
+        if (last) {
+            if (active) { active = false; n_done = n; }
+            break;
+        }
+        if (active) {
+            ctab_t tabB = (ctab_t)A.tab + opaque_uniform_zero();
+            static_for<0, Plan::NBC>([&](auto bcc) {
+                constexpr int bc = decltype(bcc)::value;
+#pragma unroll
+                for (int h = 0; h < RPL; h++) lds_st<CT>(lds, (p4 + HSTEP * h) | (bc * V * ES), orig[bc * RPL + h]);
+            });
+            if constexpr (WPF > 1) __syncthreads();
+            static_rfor<0, Plan::NBR>([&](auto brc) {
+                constexpr int br = decltype(brc)::value;
+                rows_b<CT, Plan::deg(br), RPL, HSTEP>(lds, tabB + Plan::ebeg(br), p4, vmask, &msg[Plan::ebeg(br) * RPL]);
+                if constexpr (WPF > 1) __syncthreads();
+            });
+        }
+        if (A.step_mode) break;
+    }
+
+    if (!valid) return;
+    if (A.step_mode) {
+        static_for<0, Plan::NBC>([&](auto bcc) {
+            constexpr int bc = decltype(bcc)::value;
+#pragma unroll
+            for (int h = 0; h < RPL; h++)
+                A.final_lam[fN + bc * SZ + r0 + RSTEP * h] = (double)lds_ld<CT>(lds, (p4 + HSTEP * h) | (bc * V * ES));
+        });
+        static_for<0, Plan::NBR>([&](auto brc) {
+            constexpr int br = decltype(brc)::value;
+            constexpr int D = Plan::deg(br);
+#pragma unroll
+            for (int h = 0; h < RPL; h++)
+#pragma unroll
+                for (int k = 0; k < D; k++)
+                    A.st_ne_out[fE + (size_t)SZ * Plan::ebeg(br) + (size_t)D * (r0 + RSTEP * h) + k] = (double)msg[Plan::ebeg(br) * RPL + h * D + k];
+        });
+        return;
+    }
+    static_for<0, Plan::NBC>([&](auto bcc) {
+        constexpr int bc = decltype(bcc)::value;
+#pragma unroll
+        for (int h = 0; h < RPL; h++) {
+            CT v = converged ? lds_ld<CT>(lds, (p4 + HSTEP * h) | (bc * V * ES)) : orig[bc * RPL + h];
+            size_t gi = fN + bc * SZ + r0 + RSTEP * h;
+            A.bits[gi] = v > CT(0) ? 1 : 0;
+            if (A.final_lam) A.final_lam[gi] = (double)v;
+        }
+    });
+    if (r0 == 0) {
+        if (A.iters) A.iters[frame] = n_done;
+        if (A.conv) A.conv[frame] = converged ? 1 : 0;
+    }
+}
+
+template <typename CT, int VARIANT, int SZ>
+static int launch_msg(hipStream_t st, FusedArgs &a, KernelTimer *timer) {
+    using Cfg = MsgCfg<CT, VARIANT, PlanAR4JA45, SZ>;
+    const int grid = (a.batch + Cfg::CPW - 1) / Cfg::CPW;
+    if (timer && !a.step_mode) timer->begin(st);
+    hipLaunchKernelGGL((fused_msg_kernel<CT, VARIANT, PlanAR4JA45, SZ>), dim3(grid), dim3(Cfg::THREADS), 0, st, a);
+    if (timer && !a.step_mode) timer->end(st);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return set_error(LDPC_EHIP, "fused_msg launch: %s", hipGetErrorString(e));
+    return LDPC_OK;
+}
+
+bool fused_msg_has(int variant, int dtype, int sz) {
+    if (!(sz == 32 || sz == 64 || sz == 128)) return false;
+    if (variant == LDPC_MINSUM) return dtype == LDPC_F32 || dtype == LDPC_F64;
+    return dtype == LDPC_F32;  // tanh: f32 (phi domain); f64 tanh stays on the flood path
+}
+
+int fused_msg_launch(int variant, int dtype, int sz, hipStream_t st, FusedArgs &a, KernelTimer *timer) {
+#define CASE_SZ(CT, V)                                                   \
+    switch (sz) {                                                        \
+        case 32: return launch_msg<CT, V, 32>(st, a, timer);             \
+        case 64: return launch_msg<CT, V, 64>(st, a, timer);             \
+        case 128: return launch_msg<CT, V, 128>(st, a, timer);           \
+    }
+    if (variant == LDPC_MINSUM && dtype == LDPC_F32) { CASE_SZ(float, LDPC_V_MINSUM) }
+    else if (variant == LDPC_MINSUM && dtype == LDPC_F64) { CASE_SZ(double, LDPC_V_MINSUM) }
+    else if (variant == LDPC_TANH && dtype == LDPC_F32) { CASE_SZ(float, LDPC_V_TANH) }
+#undef CASE_SZ
+    return set_error(LDPC_EUNSUPPORTED, "no per-edge-message fused kernel for variant=%d dtype=%d sz=%d", variant, dtype, sz);
+}
+
+}  // namespace ldpc

@@ -20,10 +20,11 @@ def _frames(c, per_db, dbs, seed):
 def test_auto_path_is_fused_for_ar4ja_minsum(hip, name, dbs):
     c = load(name)
     assert hip.Decoder(c.hip_code(hip), "min", "f32", 8).path == "fused"
-    assert hip.Decoder(c.hip_code(hip), "tanh", "f32", 8).path == "flood"
+    assert hip.Decoder(c.hip_code(hip), "tanh", "f32", 8).path == "fused"
+    assert hip.Decoder(c.hip_code(hip), "tanh", "f64", 8).path == "flood"
     assert hip.Decoder(c.hip_code(hip, prefer_qc=False), "min", "f32", 8).path == "flood"  # CSR graph: no QC table
     with pytest.raises(hip.LdpcError) as e:
-        hip.Decoder(c.hip_code(hip), "tanh", "f32", 8, path="fused")
+        hip.Decoder(c.hip_code(hip), "tanh", "f64", 8, path="fused")
     assert e.value.code == -5
 
 
@@ -157,3 +158,52 @@ def test_full_size_round_trip_property(hip):
     assert bool((bits == bits2).all()) and bool((it == it2).all()) and bool((cv == cv2).all())
     frac = float(cv.float().mean())
     assert 0.02 < frac < 0.999, frac  # really a mixed batch
+
+
+@pytest.mark.parametrize("name,dbs", CODES)
+def test_tanh_f32_fused(hip, name, dbs):
+    """Fused tanh rule (phi-domain fp32): teacher-forced LLRs within the 1e-5 bar (+ the oracle's own
+    conditioning allowance next to the clamp), free-running bits identical to the oracle, and the
+    fused and flood paths identical to each other (same arithmetic, same summation order)."""
+    from tests.helpers import lam_tolerance
+    c = load(name)
+    per = 24 if name == "jpl.1024.4.5" else 8
+    llr = _frames(c, per, dbs, 800)
+    code = c.hip_code(hip)
+    fused = hip.Decoder(code, "tanh", "f32", max(len(llr), 64), path="fused")
+    flood = hip.Decoder(code, "tanh", "f32", len(llr), path="flood")
+    b1, i1, c1 = fused.decode_batch(llr.astype(np.float32), 50)
+    b2, i2, c2 = flood.decode_batch(llr.astype(np.float32), 50)
+    assert np.array_equal(b1, b2) and np.array_equal(i1, i2) and np.array_equal(c1, c2)
+    ob, oi, oc = oracle.decode_batch(c.graph, "tanh", 50, llr, nthreads=8)
+    assert np.array_equal(b1, ob) and np.array_equal(c1, oc) and (i1 == oi).mean() >= 0.95
+    states = []
+    for f in range(0, len(llr), max(1, len(llr) // 6)):
+        o = oracle.decode(c.graph, "tanh", 50, llr[f], trace=True)
+        ne = np.zeros(c.E)
+        for n in range(o["iters"]):
+            states.append((llr[f], o["trace_lam"][n], ne, o["trace_ne"][n], o["trace_lam"][n + 1]))
+            ne = o["trace_ne"][n]
+    states = states[::2][:128]
+    worst = 0.0
+    for s0 in range(0, len(states), 64):
+        ch = states[s0:s0 + 64]
+        ne2, lam2, syn0 = fused.debug_step(np.stack([s[0] for s in ch]), np.stack([s[1] for s in ch]), np.stack([s[2] for s in ch]))
+        assert not syn0.any()
+        for i, s in enumerate(ch):
+            tol_lam, tol_ne = lam_tolerance(c.graph, s[3], s[4])
+            assert (np.abs(ne2[i] - s[3]) <= tol_ne).all() and (np.abs(lam2[i] - s[4]) <= tol_lam).all()
+            worst = max(worst, (np.abs(lam2[i] - s[4]) / np.maximum(1, np.abs(s[4]))).max())
+    print(f"{name} fused tanh f32: worst teacher-forced relative LLR error {worst:.3e} over {len(states)} turns; {c1.mean() * 100:.0f}% converged")
+
+
+def test_record_kernel_still_matches(hip, monkeypatch):
+    """The compressed-record kernel (LDPC_FUSED_KERNEL=rec) is kept for A/B measurements: it must give
+    the same bits as the default per-edge-message kernel."""
+    c = load("jpl.4096.4.5")
+    llr = _frames(c, 8, (2.0, 3.2), 900).astype(np.float32)
+    code = c.hip_code(hip)
+    a = hip.Decoder(code, "min", "f32", len(llr), path="fused").decode_batch(llr, 50)
+    monkeypatch.setenv("LDPC_FUSED_KERNEL", "rec")
+    b = hip.Decoder(code, "min", "f32", len(llr), path="fused").decode_batch(llr, 50)
+    assert all(np.array_equal(x, y) for x, y in zip(a, b))

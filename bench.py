@@ -29,7 +29,7 @@ HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--code", default="jpl.4096.4.5")
     ap.add_argument("--rate", default="4/5")
@@ -37,7 +37,7 @@ def main():
     ap.add_argument("--dtype", default="f32", choices=["f32", "f64", "f16"])
     ap.add_argument("--iters", type=int, default=50)
     ap.add_argument("--ebn0", type=float, default=2.0)
-    ap.add_argument("--batch", type=int, default=16384, help="frames per GPU per step")
+    ap.add_argument("--batch", type=int, default=65536, help="frames per GPU per step")
     ap.add_argument("--path", default="auto", choices=["auto", "flood", "fused"])
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the cpu_baseline sample (0 = skip)")
     ap.add_argument("--seed", type=lambda s: int(s, 0), default=0x5EEDC0DE)

@@ -102,6 +102,7 @@ struct FusedCfg {
 
 // launcher of the per-edge-message kernels (fused_msg.hip)
 bool fused_msg_has(int variant, int dtype, int sz);
-int fused_msg_launch(int variant, int dtype, int sz, hipStream_t st, FusedArgs &a, KernelTimer *timer);
+int fused_msg_static_id(int sz, const uint16_t *rot, const uint8_t *bc, int nedge);
+int fused_msg_launch(int variant, int dtype, int sz, int static_id, hipStream_t st, FusedArgs &a, KernelTimer *timer);
 
 }  // namespace ldpc

@@ -13,28 +13,55 @@
 //   phase B  lam[col] <- ne' + lam[col], block rows in descending order (Orig.hs:95-98)
 // Price: 200+ VGPRs -> 2 waves per SIMD.
 #include "fused_common.h"
+#include "generated_tables.h"
 
 namespace ldpc {
 
+// graph-table access.  Dyn: encoded dwords in memory (any code with the plan's block structure), read
+// with s_load.  Stat<T>: the table is a constexpr array -> rotation becomes a literal operand and the
+// block-column base an immediate DS offset; nothing is loaded.
+template <typename CT, int SZ>
+struct DynRow {
+    ctab_t p;
+    __device__ __forceinline__ uint32_t lo(int k) const { return p[k] & 0xffffu; }
+    __device__ __forceinline__ uint32_t hi(int k) const { return p[k] >> 16; }
+};
+template <typename CT, int SZ, class T, int EBEG>
+struct StatRow {
+    static constexpr uint32_t CPW = SZ >= 64 ? 1 : 64 / SZ, V = SZ * CPW, ES = sizeof(CT);
+    __device__ __forceinline__ constexpr uint32_t lo(int k) const { return T::rot[EBEG + k] * CPW * ES; }
+    __device__ __forceinline__ constexpr uint32_t hi(int k) const { return T::bc[EBEG + k] * V * ES; }
+};
+struct DynTab {
+    ctab_t p;
+    template <typename CT, int SZ, int EBEG> __device__ __forceinline__ DynRow<CT, SZ> row() const { return DynRow<CT, SZ>{p + EBEG}; }
+    __device__ __forceinline__ DynTab rebase(uint32_t z) const { return DynTab{p + z}; }
+};
+template <class T>
+struct StatTab {
+    template <typename CT, int SZ, int EBEG> __device__ __forceinline__ StatRow<CT, SZ, T, EBEG> row() const { return {}; }
+    __device__ __forceinline__ StatTab rebase(uint32_t) const { return {}; }
+};
+
 template <int RPL, int HSTEP>
-__device__ __forceinline__ uint32_t row_addr(uint32_t a0, uint32_t p4, uint32_t ent, uint32_t vmask, int h) {
+__device__ __forceinline__ uint32_t row_addr(uint32_t a0, uint32_t p4, uint32_t lo, uint32_t vmask, int h) {
     if (h == 0) return a0;
     if (RPL == 2) return a0 ^ (uint32_t)HSTEP;
-    return (((p4 + HSTEP * h) + (ent & 0xffffu)) & vmask) | (ent >> 16);
+    return ((p4 + HSTEP * h) + lo) & vmask;
 }
 
 // phase A for the RPL rows a lane owns in one block row of degree D.  msg: [RPL][D] registers.
-template <typename CT, int VARIANT, int D, int RPL, int HSTEP, bool SYNDROME_ONLY>
-__device__ __forceinline__ bool rows_a(const char *lds, ctab_t tabrow, uint32_t p4, uint32_t vmask, CT *msg) {
+template <typename CT, int VARIANT, int D, int RPL, int HSTEP, bool SYNDROME_ONLY, class Row>
+__device__ __forceinline__ bool rows_a(const char *lds, Row tabrow, uint32_t p4, uint32_t vmask, CT *msg) {
     asm volatile("" : "+v"(p4));
     CT l[RPL][D];
+    static_for<0, D>([&](auto kc) {
+        constexpr int k = decltype(kc)::value;
+        const uint32_t lo = tabrow.lo(k), hi = tabrow.hi(k);
+        uint32_t a0 = (p4 + lo) & vmask;   // position inside the block column; `hi` (its base) is added below
 #pragma unroll
-    for (int k = 0; k < D; k++) {
-        uint32_t ent = tabrow[k];
-        uint32_t a0 = ((p4 + (ent & 0xffffu)) & vmask) | (ent >> 16);
-#pragma unroll
-        for (int h = 0; h < RPL; h++) l[h][k] = lds_ld<CT>(lds, row_addr<RPL, HSTEP>(a0, p4, ent, vmask, h));
-    }
+        for (int h = 0; h < RPL; h++) l[h][k] = lds_ld<CT>(lds + hi, row_addr<RPL, HSTEP>(a0, p4, lo, vmask, h));
+    });
     bool any = false;
 #pragma unroll
     for (int h = 0; h < RPL; h++) {
@@ -81,24 +108,24 @@ __device__ __forceinline__ bool rows_a(const char *lds, ctab_t tabrow, uint32_t 
 }
 
 // phase B: lam[col_k] <- ne'_k + lam[col_k]; the D x RPL targets of a block row are distinct columns
-template <typename CT, int D, int RPL, int HSTEP>
-__device__ __forceinline__ void rows_b(char *lds, ctab_t tabrow, uint32_t p4, uint32_t vmask, const CT *msg) {
+template <typename CT, int D, int RPL, int HSTEP, class Row>
+__device__ __forceinline__ void rows_b(char *lds, Row tabrow, uint32_t p4, uint32_t vmask, const CT *msg) {
     asm volatile("" : "+v"(p4));
     CT cur[RPL][D];
     uint32_t adr[D];
+    static_for<0, D>([&](auto kc) {
+        constexpr int k = decltype(kc)::value;
+        const uint32_t lo = tabrow.lo(k), hi = tabrow.hi(k);
+        adr[k] = (p4 + lo) & vmask;
 #pragma unroll
-    for (int k = 0; k < D; k++) {
-        uint32_t ent = tabrow[k];
-        adr[k] = ((p4 + (ent & 0xffffu)) & vmask) | (ent >> 16);
+        for (int h = 0; h < RPL; h++) cur[h][k] = lds_ld<CT>(lds + hi, row_addr<RPL, HSTEP>(adr[k], p4, lo, vmask, h));
+    });
+    static_for<0, D>([&](auto kc) {
+        constexpr int k = decltype(kc)::value;
+        const uint32_t lo = tabrow.lo(k), hi = tabrow.hi(k);
 #pragma unroll
-        for (int h = 0; h < RPL; h++) cur[h][k] = lds_ld<CT>(lds, row_addr<RPL, HSTEP>(adr[k], p4, ent, vmask, h));
-    }
-#pragma unroll
-    for (int k = 0; k < D; k++) {
-        uint32_t ent = tabrow[k];
-#pragma unroll
-        for (int h = 0; h < RPL; h++) lds_st<CT>(lds, row_addr<RPL, HSTEP>(adr[k], p4, ent, vmask, h), msg[h * D + k] + cur[h][k]);
-    }
+        for (int h = 0; h < RPL; h++) lds_st<CT>(lds + hi, row_addr<RPL, HSTEP>(adr[k], p4, lo, vmask, h), msg[h * D + k] + cur[h][k]);
+    });
 }
 
 template <typename CT, int VARIANT, class Plan, int SZ>
@@ -109,7 +136,7 @@ struct MsgCfg : FusedCfg<CT, Plan, SZ> {
     static constexpr int WAVES_PER_EU = (sizeof(CT) == 8 || B::RPL >= 2) ? 1 : 2;
 };
 
-template <typename CT, int VARIANT, class Plan, int SZ>
+template <typename CT, int VARIANT, class Plan, int SZ, class Tab>
 __global__ __launch_bounds__((MsgCfg<CT, VARIANT, Plan, SZ>::THREADS), (MsgCfg<CT, VARIANT, Plan, SZ>::WAVES_PER_EU)) void fused_msg_kernel(FusedArgs A) {
     using Cfg = MsgCfg<CT, VARIANT, Plan, SZ>;
     constexpr int RPL = Cfg::RPL, CPW = Cfg::CPW, V = Cfg::V, N = Cfg::N, WPF = Cfg::WPF, HSTEP = Cfg::HSTEP;
@@ -188,18 +215,19 @@ __global__ __launch_bounds__((MsgCfg<CT, VARIANT, Plan, SZ>::THREADS), (MsgCfg<C
             });
         }
         const bool last = (n >= turns);
-        ctab_t tabA = (ctab_t)A.tab + opaque_uniform_zero();
+        Tab tabA;
+        if constexpr (std::is_same<Tab, DynTab>::value) tabA = DynTab{(ctab_t)A.tab + opaque_uniform_zero()};
         bool unsat = false;
         if (active) {
             if (!last) {
                 static_for<0, Plan::NBR>([&](auto brc) {
                     constexpr int br = decltype(brc)::value;
-                    unsat |= rows_a<CT, VARIANT, Plan::deg(br), RPL, HSTEP, false>(lds, tabA + Plan::ebeg(br), p4, vmask, &msg[Plan::ebeg(br) * RPL]);
+                    unsat |= rows_a<CT, VARIANT, Plan::deg(br), RPL, HSTEP, false>(lds, tabA.template row<CT, SZ, Plan::ebeg(br)>(), p4, vmask, &msg[Plan::ebeg(br) * RPL]);
                 });
             } else {
                 static_for<0, Plan::NBR>([&](auto brc) {
                     constexpr int br = decltype(brc)::value;
-                    unsat |= rows_a<CT, VARIANT, Plan::deg(br), RPL, HSTEP, true>(lds, tabA + Plan::ebeg(br), p4, vmask, (CT *)nullptr);
+                    unsat |= rows_a<CT, VARIANT, Plan::deg(br), RPL, HSTEP, true>(lds, tabA.template row<CT, SZ, Plan::ebeg(br)>(), p4, vmask, (CT *)nullptr);
                 });
             }
         }
@@ -221,7 +249,8 @@ __global__ __launch_bounds__((MsgCfg<CT, VARIANT, Plan, SZ>::THREADS), (MsgCfg<C
             break;
         }
         if (active) {
-            ctab_t tabB = (ctab_t)A.tab + opaque_uniform_zero();
+            Tab tabB;
+            if constexpr (std::is_same<Tab, DynTab>::value) tabB = DynTab{(ctab_t)A.tab + opaque_uniform_zero()};
             static_for<0, Plan::NBC>([&](auto bcc) {
                 constexpr int bc = decltype(bcc)::value;
 #pragma unroll
@@ -230,7 +259,7 @@ __global__ __launch_bounds__((MsgCfg<CT, VARIANT, Plan, SZ>::THREADS), (MsgCfg<C
             if constexpr (WPF > 1) __syncthreads();
             static_rfor<0, Plan::NBR>([&](auto brc) {
                 constexpr int br = decltype(brc)::value;
-                rows_b<CT, Plan::deg(br), RPL, HSTEP>(lds, tabB + Plan::ebeg(br), p4, vmask, &msg[Plan::ebeg(br) * RPL]);
+                rows_b<CT, Plan::deg(br), RPL, HSTEP>(lds, tabB.template row<CT, SZ, Plan::ebeg(br)>(), p4, vmask, &msg[Plan::ebeg(br) * RPL]);
                 if constexpr (WPF > 1) __syncthreads();
             });
         }
@@ -272,12 +301,12 @@ __global__ __launch_bounds__((MsgCfg<CT, VARIANT, Plan, SZ>::THREADS), (MsgCfg<C
     }
 }
 
-template <typename CT, int VARIANT, int SZ>
+template <typename CT, int VARIANT, int SZ, class Tab>
 static int launch_msg(hipStream_t st, FusedArgs &a, KernelTimer *timer) {
     using Cfg = MsgCfg<CT, VARIANT, PlanAR4JA45, SZ>;
     const int grid = (a.batch + Cfg::CPW - 1) / Cfg::CPW;
     if (timer && !a.step_mode) timer->begin(st);
-    hipLaunchKernelGGL((fused_msg_kernel<CT, VARIANT, PlanAR4JA45, SZ>), dim3(grid), dim3(Cfg::THREADS), 0, st, a);
+    hipLaunchKernelGGL((fused_msg_kernel<CT, VARIANT, PlanAR4JA45, SZ, Tab>), dim3(grid), dim3(Cfg::THREADS), 0, st, a);
     if (timer && !a.step_mode) timer->end(st);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return set_error(LDPC_EHIP, "fused_msg launch: %s", hipGetErrorString(e));
@@ -290,12 +319,33 @@ bool fused_msg_has(int variant, int dtype, int sz) {
     return dtype == LDPC_F32;  // tanh: f32 (phi domain); f64 tanh stays on the flood path
 }
 
-int fused_msg_launch(int variant, int dtype, int sz, hipStream_t st, FusedArgs &a, KernelTimer *timer) {
+// which compiled-in table (if any) equals this code's rotation table: 0 = none, 1 = jpl.1024, 2 = jpl.4096
+template <class T>
+static bool table_equals(int sz, const uint16_t *rot, const uint8_t *bc, int nedge) {
+    if (sz != T::SZ || nedge != T::NEDGE) return false;
+    for (int e = 0; e < nedge; e++)
+        if (rot[e] != T::rot[e] || bc[e] != T::bc[e]) return false;
+    return true;
+}
+int fused_msg_static_id(int sz, const uint16_t *rot, const uint8_t *bc, int nedge) {
+    if (table_equals<TabJpl1024>(sz, rot, bc, nedge)) return 1;
+    if (table_equals<TabJpl4096>(sz, rot, bc, nedge)) return 2;
+    return 0;
+}
+
+int fused_msg_launch(int variant, int dtype, int sz, int static_id, hipStream_t st, FusedArgs &a, KernelTimer *timer) {
+    // compile-time tables: f32 kernels of the shipped codes
+    if (dtype == LDPC_F32 && static_id == 1 && sz == 32)
+        return variant == LDPC_MINSUM ? launch_msg<float, LDPC_V_MINSUM, 32, StatTab<TabJpl1024>>(st, a, timer)
+                                      : launch_msg<float, LDPC_V_TANH, 32, StatTab<TabJpl1024>>(st, a, timer);
+    if (dtype == LDPC_F32 && static_id == 2 && sz == 128)
+        return variant == LDPC_MINSUM ? launch_msg<float, LDPC_V_MINSUM, 128, StatTab<TabJpl4096>>(st, a, timer)
+                                      : launch_msg<float, LDPC_V_TANH, 128, StatTab<TabJpl4096>>(st, a, timer);
 #define CASE_SZ(CT, V)                                                   \
     switch (sz) {                                                        \
-        case 32: return launch_msg<CT, V, 32>(st, a, timer);             \
-        case 64: return launch_msg<CT, V, 64>(st, a, timer);             \
-        case 128: return launch_msg<CT, V, 128>(st, a, timer);           \
+        case 32: return launch_msg<CT, V, 32, DynTab>(st, a, timer);     \
+        case 64: return launch_msg<CT, V, 64, DynTab>(st, a, timer);     \
+        case 128: return launch_msg<CT, V, 128, DynTab>(st, a, timer);   \
     }
     if (variant == LDPC_MINSUM && dtype == LDPC_F32) { CASE_SZ(float, LDPC_V_MINSUM) }
     else if (variant == LDPC_MINSUM && dtype == LDPC_F64) { CASE_SZ(double, LDPC_V_MINSUM) }

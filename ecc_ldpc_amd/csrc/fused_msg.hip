@@ -39,9 +39,70 @@ struct DynTab {
 };
 template <class T>
 struct StatTab {
+    using Table = T;
     template <typename CT, int SZ, int EBEG> __device__ __forceinline__ StatRow<CT, SZ, T, EBEG> row() const { return {}; }
     __device__ __forceinline__ StatTab rebase(uint32_t) const { return {}; }
 };
+template <class Tab> struct IsStatic : std::false_type {};
+template <class T> struct IsStatic<StatTab<T>> : std::true_type {};
+
+// Phase-B "rounds" for a compile-time table.  A column's contributions must be added in descending
+// row order (Orig.hs:96).  round(e) = number of LATER edges (higher block row) in the same block
+// column; edges of one round touch every block column at most once, so all targets of a round are
+// distinct and a round needs no internal ordering.  Rounds 0,1,2,.. reproduce exactly the per-column
+// order of the block-row-by-block-row schedule with max-column-degree barriers instead of NBR.
+template <class T>
+struct Rounds {
+    static constexpr int round_of(int e) {
+        int c = 0;
+        for (int j = e + 1; j < T::NEDGE; j++) c += (T::bc[j] == T::bc[e]) ? 1 : 0;
+        return c;
+    }
+    static constexpr int num_rounds() {
+        int m = 0;
+        for (int e = 0; e < T::NEDGE; e++) m = round_of(e) + 1 > m ? round_of(e) + 1 : m;
+        return m;
+    }
+    static constexpr int count(int q) {
+        int c = 0;
+        for (int e = 0; e < T::NEDGE; e++) c += round_of(e) == q ? 1 : 0;
+        return c;
+    }
+    static constexpr int nth(int q, int i) {  // i-th edge of round q, highest edge index first
+        int c = 0;
+        for (int e = T::NEDGE - 1; e >= 0; e--)
+            if (round_of(e) == q) { if (c == i) return e; c++; }
+        return -1;
+    }
+};
+
+// one chunk [I0, I1) of round Q: read every target, add, write back
+template <typename CT, int SZ, class T, int Q, int I0, int I1>
+__device__ __forceinline__ void round_chunk_b(char *lds, uint32_t p4, uint32_t vmask, const CT *msg) {
+    constexpr uint32_t CPW = SZ >= 64 ? 1 : 64 / SZ, V = SZ * CPW, ES = sizeof(CT);
+    asm volatile("" : "+v"(p4));
+    CT cur[I1 - I0];
+    uint32_t adr[I1 - I0];
+    static_for<I0, I1>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        constexpr int e = Rounds<T>::nth(Q, i);
+        adr[i - I0] = (p4 + T::rot[e] * CPW * ES) & vmask;
+        cur[i - I0] = lds_ld<CT>(lds + T::bc[e] * V * ES, adr[i - I0]);
+    });
+    static_for<I0, I1>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        constexpr int e = Rounds<T>::nth(Q, i);
+        lds_st<CT>(lds + T::bc[e] * V * ES, adr[i - I0], msg[e] + cur[i - I0]);
+    });
+}
+template <typename CT, int SZ, class T, int Q, int I0>
+__device__ __forceinline__ void round_b(char *lds, uint32_t p4, uint32_t vmask, const CT *msg) {
+    constexpr int CNT = Rounds<T>::count(Q), CH = 16;
+    if constexpr (I0 < CNT) {
+        round_chunk_b<CT, SZ, T, Q, I0, (I0 + CH < CNT ? I0 + CH : CNT)>(lds, p4, vmask, msg);
+        round_b<CT, SZ, T, Q, I0 + CH>(lds, p4, vmask, msg);
+    }
+}
 
 template <int RPL, int HSTEP>
 __device__ __forceinline__ uint32_t row_addr(uint32_t a0, uint32_t p4, uint32_t lo, uint32_t vmask, int h) {
@@ -53,7 +114,7 @@ __device__ __forceinline__ uint32_t row_addr(uint32_t a0, uint32_t p4, uint32_t 
 // phase A for the RPL rows a lane owns in one block row of degree D.  msg: [RPL][D] registers.
 template <typename CT, int VARIANT, int D, int RPL, int HSTEP, bool SYNDROME_ONLY, class Row>
 __device__ __forceinline__ bool rows_a(const char *lds, Row tabrow, uint32_t p4, uint32_t vmask, CT *msg) {
-    asm volatile("" : "+v"(p4));
+    asm volatile("" : "+v"(p4));  // keeps the loop-invariant address arithmetic inside the turn loop, row by row
     CT l[RPL][D];
     static_for<0, D>([&](auto kc) {
         constexpr int k = decltype(kc)::value;
@@ -87,13 +148,19 @@ __device__ __forceinline__ bool rows_a(const char *lds, Row tabrow, uint32_t p4,
                 m2 = __builtin_amdgcn_fmed3f(m1, m2, a);
                 m1 = fminf(m1, a);
             });
-            const float m1s = 0.75f * m1, m2s = 0.75f * m2;  // the one rounding of Min.hs:78
-            const uint32_t Xc = X ^ ((D & 1) ? 0x80000000u : 0u);
+            // sign(ne'_k) = signs(all t) ^ sign(t_k) ^ (D odd).  The row part of it is folded into the
+            // two candidate magnitudes once per row; per edge one 3-input bit operation then takes the
+            // magnitude bits from the candidate and sign = candidate.sign ^ t.sign  (v_bitop3_b32).
+            const uint32_t flip = (X ^ ((D & 1) ? 0x80000000u : 0u)) & 0x80000000u;
+            const uint32_t c1 = __float_as_uint(0.75f * m1) ^ flip;  // 0.75f*: the one rounding of Min.hs:78
+            const uint32_t c2 = __float_as_uint(0.75f * m2) ^ flip;
             static_for<0, D>([&](auto kc) {
                 constexpr int k = decltype(kc)::value;
                 float t = m[k];
-                float mag = (fabsf(t) == m1) ? m2s : m1s;   // leave-one-out min: m2 at the arg-min (ties: m2 == m1)
-                m[k] = __uint_as_float(bfi(0x7fffffffu, __float_as_uint(mag), Xc ^ __float_as_uint(t)));
+                uint32_t c = (fabsf(t) == m1) ? c2 : c1;   // leave-one-out min: m2 at the arg-min (ties: m2 == m1)
+                uint32_t tb = __float_as_uint(t);
+                // (c & ~S) | ((c ^ tb) & S), S = sign mask: truth table 0x78 with A=0xF0, B=0xCC, C=0xAA
+                m[k] = __uint_as_float(__builtin_amdgcn_bitop3_b32(c, tb, 0x80000000u, 0x78));
             });
         } else {
             CT t[D];
@@ -217,17 +284,18 @@ __global__ __launch_bounds__((MsgCfg<CT, VARIANT, Plan, SZ>::THREADS), (MsgCfg<C
         const bool last = (n >= turns);
         Tab tabA;
         if constexpr (std::is_same<Tab, DynTab>::value) tabA = DynTab{(ctab_t)A.tab + opaque_uniform_zero()};
+        const uint32_t p4a = p4;
         bool unsat = false;
         if (active) {
             if (!last) {
                 static_for<0, Plan::NBR>([&](auto brc) {
                     constexpr int br = decltype(brc)::value;
-                    unsat |= rows_a<CT, VARIANT, Plan::deg(br), RPL, HSTEP, false>(lds, tabA.template row<CT, SZ, Plan::ebeg(br)>(), p4, vmask, &msg[Plan::ebeg(br) * RPL]);
+                    unsat |= rows_a<CT, VARIANT, Plan::deg(br), RPL, HSTEP, false>(lds, tabA.template row<CT, SZ, Plan::ebeg(br)>(), p4a, vmask, &msg[Plan::ebeg(br) * RPL]);
                 });
             } else {
                 static_for<0, Plan::NBR>([&](auto brc) {
                     constexpr int br = decltype(brc)::value;
-                    unsat |= rows_a<CT, VARIANT, Plan::deg(br), RPL, HSTEP, true>(lds, tabA.template row<CT, SZ, Plan::ebeg(br)>(), p4, vmask, (CT *)nullptr);
+                    unsat |= rows_a<CT, VARIANT, Plan::deg(br), RPL, HSTEP, true>(lds, tabA.template row<CT, SZ, Plan::ebeg(br)>(), p4a, vmask, (CT *)nullptr);
                 });
             }
         }
@@ -251,17 +319,26 @@ __global__ __launch_bounds__((MsgCfg<CT, VARIANT, Plan, SZ>::THREADS), (MsgCfg<C
         if (active) {
             Tab tabB;
             if constexpr (std::is_same<Tab, DynTab>::value) tabB = DynTab{(ctab_t)A.tab + opaque_uniform_zero()};
+            const uint32_t p4b = p4;
             static_for<0, Plan::NBC>([&](auto bcc) {
                 constexpr int bc = decltype(bcc)::value;
 #pragma unroll
                 for (int h = 0; h < RPL; h++) lds_st<CT>(lds, (p4 + HSTEP * h) | (bc * V * ES), orig[bc * RPL + h]);
             });
             if constexpr (WPF > 1) __syncthreads();
-            static_rfor<0, Plan::NBR>([&](auto brc) {
-                constexpr int br = decltype(brc)::value;
-                rows_b<CT, Plan::deg(br), RPL, HSTEP>(lds, tabB.template row<CT, SZ, Plan::ebeg(br)>(), p4, vmask, &msg[Plan::ebeg(br) * RPL]);
-                if constexpr (WPF > 1) __syncthreads();
-            });
+            if constexpr (IsStatic<Tab>::value && WPF > 1 && RPL == 1) {
+                using T = typename Tab::Table;
+                static_for<0, Rounds<T>::num_rounds()>([&](auto qc) {
+                    round_b<CT, SZ, T, decltype(qc)::value, 0>(lds, p4b, vmask, msg);
+                    __syncthreads();  // the next round adds into the same columns
+                });
+            } else {
+                static_rfor<0, Plan::NBR>([&](auto brc) {
+                    constexpr int br = decltype(brc)::value;
+                    rows_b<CT, Plan::deg(br), RPL, HSTEP>(lds, tabB.template row<CT, SZ, Plan::ebeg(br)>(), p4b, vmask, &msg[Plan::ebeg(br) * RPL]);
+                    if constexpr (WPF > 1) __syncthreads();
+                });
+            }
         }
         if (A.step_mode) break;
     }

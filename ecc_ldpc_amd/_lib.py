@@ -8,7 +8,7 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(HERE, "libldpc_hip.so")
+SO_PATH = os.environ.get("LDPC_SO") or os.path.join(HERE, "libldpc_hip.so")  # LDPC_SO: ablation builds (tools/)
 
 OK, EINVAL, ENOMEM, EHIP, ENODEVICE, EUNSUPPORTED, EDEGREE, EFORMAT, ENOTFOUND = 0, -1, -2, -3, -4, -5, -6, -7, -8
 TANH, MINSUM = 0, 1

@@ -15,7 +15,7 @@ namespace ldpc {
 // AR4JA rate-4/5 protograph as shipped in codes/jpl.1024.4.5 and codes/jpl.4096.4.5:
 // 12 x 44 blocks, block rows 0-3 of weight 3, 4-11 of weight 18.
 struct PlanAR4JA45 {
-    static constexpr int NBR = 12, NBC = 44, NEDGE = 4 * 3 + 8 * 18;
+    static constexpr int NBR = 12, NBC = 44, NEDGE = 4 * 3 + 8 * 18, DMAX = 18;
     static constexpr int deg(int br) { return br < 4 ? 3 : 18; }
     static constexpr int ebeg(int br) { return br < 4 ? 3 * br : 12 + 18 * (br - 4); }
 };

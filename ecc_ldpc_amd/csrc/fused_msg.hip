@@ -15,6 +15,12 @@
 #include "fused_common.h"
 #include "generated_tables.h"
 
+// LDPC_DBG: timing-only ablation builds (results are WRONG when non-zero; never shipped):
+//   1 no barriers between phase-B rounds   2 no phase-B adds   4 no pass 2   8 no lam<-orig init   16 no pass 1
+#ifndef LDPC_DBG
+#define LDPC_DBG 0
+#endif
+
 namespace ldpc {
 
 // graph-table access.  Dyn: encoded dwords in memory (any code with the plan's block structure), read
@@ -68,6 +74,11 @@ struct Rounds {
         for (int e = 0; e < T::NEDGE; e++) c += round_of(e) == q ? 1 : 0;
         return c;
     }
+    static constexpr int round0_edge(int bc) {  // the edge that is added first into block column bc
+        for (int e = T::NEDGE - 1; e >= 0; e--)
+            if (T::bc[e] == bc) return e;
+        return -1;
+    }
     static constexpr int nth(int q, int i) {  // i-th edge of round q, highest edge index first
         int c = 0;
         for (int e = T::NEDGE - 1; e >= 0; e--)
@@ -78,9 +89,19 @@ struct Rounds {
 
 // one chunk [I0, I1) of round Q: read every target, add, write back
 template <typename CT, int SZ, class T, int Q, int I0, int I1>
-__device__ __forceinline__ void round_chunk_b(char *lds, uint32_t p4, uint32_t vmask, const CT *msg) {
+__device__ __forceinline__ void round_chunk_b(char *lds, uint32_t p4, uint32_t vmask, const CT *msg, const CT *orig_rot) {
     constexpr uint32_t CPW = SZ >= 64 ? 1 : 64 / SZ, V = SZ * CPW, ES = sizeof(CT);
     asm volatile("" : "+v"(p4));
+    if constexpr (Q == 0) {
+        // first contribution of every column: lam = orig + ne' is a plain store -- the thread holds the
+        // channel LLR of the column it writes here (orig_rot), so there is no lam <- orig pass at all
+        static_for<I0, I1>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            constexpr int e = Rounds<T>::nth(Q, i);
+            lds_st<CT>(lds + T::bc[e] * V * ES, (p4 + T::rot[e] * CPW * ES) & vmask, msg[e] + orig_rot[T::bc[e]]);
+        });
+        return;
+    }
     CT cur[I1 - I0];
     uint32_t adr[I1 - I0];
     static_for<I0, I1>([&](auto ic) {
@@ -96,11 +117,11 @@ __device__ __forceinline__ void round_chunk_b(char *lds, uint32_t p4, uint32_t v
     });
 }
 template <typename CT, int SZ, class T, int Q, int I0>
-__device__ __forceinline__ void round_b(char *lds, uint32_t p4, uint32_t vmask, const CT *msg) {
-    constexpr int CNT = Rounds<T>::count(Q), CH = 16;
+__device__ __forceinline__ void round_b(char *lds, uint32_t p4, uint32_t vmask, const CT *msg, const CT *orig_rot) {
+    constexpr int CNT = Rounds<T>::count(Q), CH = 8;  // 16 pushes the round-0 LLR registers into scratch
     if constexpr (I0 < CNT) {
-        round_chunk_b<CT, SZ, T, Q, I0, (I0 + CH < CNT ? I0 + CH : CNT)>(lds, p4, vmask, msg);
-        round_b<CT, SZ, T, Q, I0 + CH>(lds, p4, vmask, msg);
+        round_chunk_b<CT, SZ, T, Q, I0, (I0 + CH < CNT ? I0 + CH : CNT)>(lds, p4, vmask, msg, orig_rot);
+        round_b<CT, SZ, T, Q, I0 + CH>(lds, p4, vmask, msg, orig_rot);
     }
 }
 
@@ -174,6 +195,81 @@ __device__ __forceinline__ bool rows_a(const char *lds, Row tabrow, uint32_t p4,
     return any;
 }
 
+// ---- phase A as three stages, so the kernel can software-pipeline rows: the gathered lam values are
+// dead after pass 1, so the NEXT row's gather is issued between pass 1 and pass 2 into the same
+// registers and its LDS latency hides behind pass 2.
+template <typename CT, int D, int RPL, int HSTEP, int LD, class Row>
+__device__ __forceinline__ void row_gather(const char *lds, Row tabrow, uint32_t p4, uint32_t vmask, CT (*l)[LD]) {
+    asm volatile("" : "+v"(p4));  // keeps the loop-invariant address arithmetic inside the turn loop
+    static_for<0, D>([&](auto kc) {
+        constexpr int k = decltype(kc)::value;
+        const uint32_t lo = tabrow.lo(k), hi = tabrow.hi(k);
+        uint32_t a0 = (p4 + lo) & vmask;
+#pragma unroll
+        for (int h = 0; h < RPL; h++) l[h][k] = lds_ld<CT>(lds + hi, row_addr<RPL, HSTEP>(a0, p4, lo, vmask, h));
+    });
+}
+template <typename CT> struct RowRed { CT m1, m2; uint32_t X; };
+// pass 1: row parity of hard(lam); t = lam - ne stored in place of ne; two-min + sign parity (min-sum f32)
+template <typename CT, int VARIANT, int D, int RPL, int LD>
+__device__ __forceinline__ bool row_pass1(const CT (*l)[LD], CT *msg, RowRed<CT> *red) {
+    bool any = false;
+#pragma unroll
+    for (int h = 0; h < RPL; h++) {
+        bool par = false;
+#pragma unroll
+        for (int k = 0; k < D; k++) par ^= (l[h][k] > CT(0));
+        any |= par;
+        CT *m = msg + h * D;
+        if constexpr (VARIANT == LDPC_V_MINSUM && sizeof(CT) == 4) {
+            uint32_t X = 0;
+            float m1 = INFINITY, m2 = INFINITY;
+            static_for<0, D>([&](auto kc) {
+                constexpr int k = decltype(kc)::value;
+                float t = l[h][k] - m[k];
+                m[k] = t;
+                X ^= __float_as_uint(t);
+                float a = fabsf(t);
+                m2 = __builtin_amdgcn_fmed3f(m1, m2, a);
+                m1 = fminf(m1, a);
+            });
+            red[h].m1 = m1; red[h].m2 = m2; red[h].X = X;
+        } else {
+#pragma unroll
+            for (int k = 0; k < D; k++) m[k] = l[h][k] - m[k];
+        }
+    }
+    return any;
+}
+// pass 2: ne' from t (in place)
+template <typename CT, int VARIANT, int D, int RPL>
+__device__ __forceinline__ void row_pass2(CT *msg, const RowRed<CT> *red) {
+#pragma unroll
+    for (int h = 0; h < RPL; h++) {
+        CT *m = msg + h * D;
+        if constexpr (VARIANT == LDPC_V_MINSUM && sizeof(CT) == 4) {
+            static_assert(D >= 2, "min-sum needs degree >= 2");
+            const float m1 = red[h].m1;
+            const uint32_t flip = (red[h].X ^ ((D & 1) ? 0x80000000u : 0u)) & 0x80000000u;
+            const uint32_t c1 = __float_as_uint(0.75f * m1) ^ flip;  // 0.75f*: the one rounding of Min.hs:78
+            const uint32_t c2 = __float_as_uint(0.75f * red[h].m2) ^ flip;
+            static_for<0, D>([&](auto kc) {
+                constexpr int k = decltype(kc)::value;
+                float t = m[k];
+                uint32_t c = (fabsf(t) == m1) ? c2 : c1;
+                m[k] = __uint_as_float(__builtin_amdgcn_bitop3_b32(c, __float_as_uint(t), 0x80000000u, 0x78));
+            });
+        } else {
+            CT t[D];
+#pragma unroll
+            for (int k = 0; k < D; k++) t[k] = m[k];
+            cn_update<CT, VARIANT, D>(t);
+#pragma unroll
+            for (int k = 0; k < D; k++) m[k] = t[k];
+        }
+    }
+}
+
 // phase B: lam[col_k] <- ne'_k + lam[col_k]; the D x RPL targets of a block row are distinct columns
 template <typename CT, int D, int RPL, int HSTEP, class Row>
 __device__ __forceinline__ void rows_b(char *lds, Row tabrow, uint32_t p4, uint32_t vmask, const CT *msg) {
@@ -221,8 +317,17 @@ __global__ __launch_bounds__((MsgCfg<CT, VARIANT, Plan, SZ>::THREADS), (MsgCfg<C
     const size_t fN = (size_t)(valid ? frame : 0) * N;
     const size_t fE = (size_t)(valid ? frame : 0) * Plan::NEDGE * SZ;
 
+    // Channel LLRs kept in registers for phase B.  Table-driven kernel: the thread's OWN columns
+    // (lam <- orig pass).  Compile-time table (kRot): the column the thread WRITES in round 0 of each
+    // block column, i.e. own column rotated by that circulant's offset.
+    constexpr bool kRot = IsStatic<Tab>::value && RPL == 1;
+    auto llr_at = [&](size_t gi) -> CT {
+        return A.llr_is_f64 ? (CT) reinterpret_cast<const double *>(A.llr)[gi] : (CT) reinterpret_cast<const float *>(A.llr)[gi];
+    };
     CT orig[Cfg::NORIG];
-    if (A.llr_is_f64) {
+    if constexpr (kRot) {
+        // loaded after the LDS fill below (keeps the prologue's register pressure down)
+    } else if (A.llr_is_f64) {
         const double *src = reinterpret_cast<const double *>(A.llr) + fN + r0;
 #pragma unroll
         for (int i = 0; i < Cfg::NORIG; i++) orig[i] = (CT)src[(i / RPL) * SZ + RSTEP * (i % RPL)];
@@ -250,12 +355,22 @@ __global__ __launch_bounds__((MsgCfg<CT, VARIANT, Plan, SZ>::THREADS), (MsgCfg<C
         constexpr int bc = decltype(bcc)::value;
 #pragma unroll
         for (int h = 0; h < RPL; h++) {
-            CT v = orig[bc * RPL + h];
+            CT v;
+            if constexpr (kRot) v = llr_at(fN + bc * SZ + r0); else v = orig[bc * RPL + h];
             if (A.step_mode) v = (CT)A.st_lam[fN + bc * SZ + r0 + RSTEP * h];
             lds_st<CT>(lds, (p4 + HSTEP * h) | (bc * V * ES), v);
         }
     });
     if constexpr (WPF > 1) __syncthreads();
+    if constexpr (kRot) {
+        asm volatile("" ::: "memory");
+        using T = typename Tab::Table;
+        static_for<0, Plan::NBC>([&](auto bcc) {
+            constexpr int bc = decltype(bcc)::value;
+            constexpr int e0 = Rounds<T>::round0_edge(bc);
+            orig[bc] = llr_at(fN + bc * SZ + ((r0 + T::rot[e0]) & (SZ - 1)));
+        });
+    }
 
     unsigned long long fmask = ~0ull;
     if constexpr (CPW > 1) {
@@ -288,6 +403,8 @@ __global__ __launch_bounds__((MsgCfg<CT, VARIANT, Plan, SZ>::THREADS), (MsgCfg<C
         bool unsat = false;
         if (active) {
             if (!last) {
+                // (a software-pipelined variant -- next row's gather issued between pass 1 and pass 2 --
+                //  measured no faster and costs 18 VGPRs that push the phase-B registers into scratch)
                 static_for<0, Plan::NBR>([&](auto brc) {
                     constexpr int br = decltype(brc)::value;
                     unsat |= rows_a<CT, VARIANT, Plan::deg(br), RPL, HSTEP, false>(lds, tabA.template row<CT, SZ, Plan::ebeg(br)>(), p4a, vmask, &msg[Plan::ebeg(br) * RPL]);
@@ -320,19 +437,19 @@ __global__ __launch_bounds__((MsgCfg<CT, VARIANT, Plan, SZ>::THREADS), (MsgCfg<C
             Tab tabB;
             if constexpr (std::is_same<Tab, DynTab>::value) tabB = DynTab{(ctab_t)A.tab + opaque_uniform_zero()};
             const uint32_t p4b = p4;
-            static_for<0, Plan::NBC>([&](auto bcc) {
-                constexpr int bc = decltype(bcc)::value;
-#pragma unroll
-                for (int h = 0; h < RPL; h++) lds_st<CT>(lds, (p4 + HSTEP * h) | (bc * V * ES), orig[bc * RPL + h]);
-            });
-            if constexpr (WPF > 1) __syncthreads();
-            if constexpr (IsStatic<Tab>::value && WPF > 1 && RPL == 1) {
+            if constexpr (kRot) {
                 using T = typename Tab::Table;
                 static_for<0, Rounds<T>::num_rounds()>([&](auto qc) {
-                    round_b<CT, SZ, T, decltype(qc)::value, 0>(lds, p4b, vmask, msg);
-                    __syncthreads();  // the next round adds into the same columns
+                    if (!(LDPC_DBG & 2)) round_b<CT, SZ, T, decltype(qc)::value, 0>(lds, p4b, vmask, msg, orig);
+                    if constexpr (WPF > 1) if (!(LDPC_DBG & 1)) __syncthreads();  // the next round adds into the same columns
                 });
             } else {
+                static_for<0, Plan::NBC>([&](auto bcc) {
+                    constexpr int bc = decltype(bcc)::value;
+#pragma unroll
+                    for (int h = 0; h < RPL; h++) if (!(LDPC_DBG & 8)) lds_st<CT>(lds, (p4 + HSTEP * h) | (bc * V * ES), orig[bc * RPL + h]);
+                });
+                if constexpr (WPF > 1) __syncthreads();
                 static_rfor<0, Plan::NBR>([&](auto brc) {
                     constexpr int br = decltype(brc)::value;
                     rows_b<CT, Plan::deg(br), RPL, HSTEP>(lds, tabB.template row<CT, SZ, Plan::ebeg(br)>(), p4b, vmask, &msg[Plan::ebeg(br) * RPL]);
@@ -366,8 +483,10 @@ __global__ __launch_bounds__((MsgCfg<CT, VARIANT, Plan, SZ>::THREADS), (MsgCfg<C
         constexpr int bc = decltype(bcc)::value;
 #pragma unroll
         for (int h = 0; h < RPL; h++) {
-            CT v = converged ? lds_ld<CT>(lds, (p4 + HSTEP * h) | (bc * V * ES)) : orig[bc * RPL + h];
             size_t gi = fN + bc * SZ + r0 + RSTEP * h;
+            CT own;
+            if constexpr (kRot) own = llr_at(gi); else own = orig[bc * RPL + h];
+            CT v = converged ? lds_ld<CT>(lds, (p4 + HSTEP * h) | (bc * V * ES)) : own;
             A.bits[gi] = v > CT(0) ? 1 : 0;
             if (A.final_lam) A.final_lam[gi] = (double)v;
         }

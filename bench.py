@@ -63,9 +63,11 @@ def main():
         dist.init_process_group("nccl", device_id=dev)  # nccl == RCCL on ROCm
     E.init(local_rank)
 
-    x, y = args.rate.split("/")
     suffix = "" if args.dtype == "f32" else "-" + args.dtype
-    name = f"ldpc/hip-{args.variant}{suffix}/{args.code}/{args.iters}/{x}/{y}"
+    name = f"ldpc/hip-{args.variant}{suffix}/{args.code}/{args.iters}"
+    if args.rate not in ("", "none"):
+        x, y = args.rate.split("/")
+        name += f"/{x}/{y}"
     if args.path != "auto":
         os.environ["LDPC_HIP_PATH"] = args.path
     ecc = E.ECC(os.path.join(ROOT, "codes"), name, max_batch=args.batch)

@@ -263,7 +263,7 @@ ldpc_ctx *ldpc_ctx_create_ex(const ldpc_code *code_c, int variant, int dtype, in
     if (!ctx) { set_error(LDPC_ENOMEM, "out of host memory"); return nullptr; }
     ctx->code = code; ctx->variant = variant; ctx->dtype = dtype; ctx->max_batch = max_batch; ctx->device = device;
     ctx->Bp = (max_batch + 63) / 64 * 64;
-    ctx->path = (path == LDPC_PATH_AUTO) ? (fused_ok ? LDPC_PATH_FUSED : LDPC_PATH_FLOOD) : path;
+    ctx->path = (path == LDPC_PATH_AUTO) ? (ldpc::fused_preferred(*code, variant, dtype) ? LDPC_PATH_FUSED : LDPC_PATH_FLOOD) : path;
 
 #define CTX_HIP(x)                                                       \
     do {                                                                 \
@@ -489,7 +489,6 @@ ldpc_sim *ldpc_sim_create(const ldpc_code *code, int k, int n_tx, int p, const u
         set_error(LDPC_EINVAL, "ldpc_sim_create: bad arguments (k=%d n_tx=%d p=%d N=%d)", k, n_tx, p, code ? code->N : -1);
         return nullptr;
     }
-    if (!G && n_tx > k) { /* all-zero codewords: parity positions are simply 0 */ }
     int device;
     { std::lock_guard<std::mutex> lk(g_mu); device = g_device; }
     if (device < 0) { set_error(LDPC_ENODEVICE, "ldpc_init() has not succeeded"); return nullptr; }

@@ -7,6 +7,8 @@ namespace ldpc {
 struct FusedState;
 bool fused_supported(const ldpc_code &code, int variant, int dtype);
 const char *fused_why_not(const ldpc_code &code, int variant, int dtype);
+// whether LDPC_PATH_AUTO should pick the fused kernel (it exists AND is the faster path today)
+bool fused_preferred(const ldpc_code &code, int variant, int dtype);
 FusedState *fused_create(const ldpc_code &code, int variant, int dtype, int max_batch);
 void fused_destroy(FusedState *s);
 void fused_set_timer(FusedState *s, KernelTimer *t);

@@ -375,17 +375,27 @@ ldpc_ecc *ldpc_ecc_create(const char *codes_dir, const char *code_name, int max_
         else if (dec == "hip-minsum") variant = LDPC_MINSUM;
         else { set_error(LDPC_ENOTFOUND, "decoder '%s' is not provided by libldpc_hip (hip-tanh, hip-minsum)", xs[1].c_str()); return nullptr; }
 
-        g = ldpc_matrix_load(codes_dir, (xs[2] + "/G").c_str());  // Utils.hs:36
-        if (!g) return nullptr;
-        h = ldpc_matrix_load(codes_dir, (xs[2] + "/H").c_str());  // Utils.hs:40
-        if (!h) { ldpc_matrix_destroy(g); return nullptr; }
-        if (g->rows + g->cols != h->cols) {                      // Utils.hs:43
-            set_error(LDPC_EFORMAT, "bad code size match (%d,%d)", g->rows + g->cols, h->cols);
-            ldpc_matrix_destroy(g); ldpc_matrix_destroy(h);
-            return nullptr;
+        // A matrix name that is a plain FILE under codes_dir is a stand-alone parity-check matrix in
+        // MacKay's alist order with no generator (codes/1920.1280.3.303; the reference cannot load it,
+        // SURVEY.md section 0 note ii): message length = cols - rows (H full rank), frames are the
+        // all-zero codeword.  Otherwise the reference's <matrix>/G + <matrix>/H pair.
+        const bool standalone = file_exists(std::string(codes_dir) + "/" + xs[2]);
+        if (standalone) {
+            h = ldpc_matrix_load_mackay((std::string(codes_dir) + "/" + xs[2]).c_str());
+            if (!h) return nullptr;
+        } else {
+            g = ldpc_matrix_load(codes_dir, (xs[2] + "/G").c_str());  // Utils.hs:36
+            if (!g) return nullptr;
+            h = ldpc_matrix_load(codes_dir, (xs[2] + "/H").c_str());  // Utils.hs:40
+            if (!h) { ldpc_matrix_destroy(g); return nullptr; }
+            if (g->rows + g->cols != h->cols) {                      // Utils.hs:43
+                set_error(LDPC_EFORMAT, "bad code size match (%d,%d)", g->rows + g->cols, h->cols);
+                ldpc_matrix_destroy(g); ldpc_matrix_destroy(h);
+                return nullptr;
+            }
         }
         e = new ldpc_ecc();
-        e->message_length = g->rows;
+        e->message_length = standalone ? h->cols - h->rows : g->rows;
         e->unpunctured_length = h->cols;
         e->max_iters = atoi(xs[3].c_str());
         e->variant = variant; e->dtype = dtype;
@@ -415,16 +425,20 @@ ldpc_ecc *ldpc_ecc_create(const char *codes_dir, const char *code_name, int max_
             e->ctx = ldpc_ctx_create_ex(e->code, variant, dtype, max_batch, path);
         }
         if (!e->ctx) goto fail;
-        {
+        if (g) {
             std::vector<uint8_t> gd((size_t)g->rows * g->cols);
             if (ldpc_matrix_dense(g, gd.data()) != LDPC_OK) goto fail;
             e->parity_len = g->cols;
             e->sim = ldpc_sim_create(e->code, e->message_length, e->codeword_length, g->cols, gd.data(), max_batch);
-            if (!e->sim) goto fail;
+        } else {
+            e->parity_len = 0;
+            e->sim = ldpc_sim_create(e->code, e->message_length, e->codeword_length, 0, nullptr, max_batch);
         }
+        if (!e->sim) goto fail;
         e->llr_buf.assign((size_t)e->unpunctured_length, 0.0);
         e->bits_buf.assign((size_t)e->unpunctured_length, 0);
-        ldpc_matrix_destroy(g); ldpc_matrix_destroy(h);
+        if (g) ldpc_matrix_destroy(g);
+        ldpc_matrix_destroy(h);
         return e;
     } catch (...) { set_error(LDPC_ENOMEM, "out of host memory"); }
 fail:
@@ -447,7 +461,9 @@ const ldpc_code *ldpc_ecc_code(const ldpc_ecc *e) { return e ? e->code : nullptr
 int ldpc_ecc_encode(const ldpc_ecc *e, const uint8_t *msg, uint8_t *codeword) {
     if (!e || !msg || !codeword) return set_error(LDPC_EINVAL, "null argument");
     try {
-        std::vector<uint8_t> par((size_t)e->parity_len);
+        if (e->parity_len == 0 && e->codeword_length > e->message_length)
+            return set_error(LDPC_EUNSUPPORTED, "this code was loaded without a generator matrix: no encoder");
+        std::vector<uint8_t> par((size_t)e->parity_len + 1);
         int rc = ldpc_sim_encode_host(e->sim, msg, par.data());
         if (rc != LDPC_OK) return rc;
         memcpy(codeword, msg, (size_t)e->message_length);

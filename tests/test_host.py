@@ -123,3 +123,21 @@ def test_device_frame_source(hip):
     ecc.sim.tally(B, bits.data_ptr(), iters.data_ptr(), tally.data_ptr(), None)
     torch.cuda.synchronize()
     assert tally.tolist() == [B, 2, 5, 7 * B]
+
+
+@pytest.mark.gpu
+def test_standalone_mackay_matrix_record(hip):
+    """codes/1920.1280.3.303 is a single MacKay-order file without a generator: the record takes
+    k = cols - rows, frames are all-zero codewords, decode works, encode says so."""
+    ecc = hip.ECC(CODES, "ldpc/hip-tanh/1920.1280.3.303/50", max_batch=64)
+    assert (ecc.message_length, ecc.codeword_length, ecc.unpunctured_length) == (640, 1920, 1920)
+    assert ecc.name == "ldpc/hip-tanh/1920.1280.3.303/50/1/3" and ecc.decoder.path == "flood"
+    c = load("1920.1280.3.303")
+    _, llr = c.frames(8, 3.0, seed=31)
+    for f in range(8):
+        out, ok = ecc.decode(llr[f])
+        o = oracle.decode(c.graph, "tanh", 50, llr[f])
+        assert ok and np.array_equal(out, o["bits"][:640])
+    with pytest.raises(hip.LdpcError) as e:
+        ecc.encode(np.zeros(640, np.uint8))
+    assert e.value.code == -5

@@ -1,0 +1,17 @@
+#!/bin/bash
+# Runs bench.py over the BASELINE.json configurations that fit one GPU; one JSON line each -> gpurun_out/bench_matrix.jsonl
+mkdir -p gpurun_out; out=gpurun_out/bench_matrix.jsonl; : > $out
+run() { echo "# $*" >&2; python bench.py --cpu-seconds 0 "$@" 2>/dev/null | tail -1 >> $out; }
+run --steps 6 --warmup 2                                              # headline: jpl.4096 min-sum f32 (fused)
+LDPC_HIP_PATH=flood run --steps 3 --warmup 1 --batch 16384            # same on the generic flood path
+run --steps 3 --warmup 1 --batch 16384 --dtype f16                    # configs[3]: fp16 storage (flood)
+run --steps 3 --warmup 1 --batch 16384 --variant tanh                 # tanh rule, fused
+LDPC_HIP_PATH=flood run --steps 3 --warmup 1 --batch 16384 --variant tanh
+run --steps 6 --warmup 2 --code jpl.1024.4.5                          # configs[1]
+for db in 1 2 3 4; do run --steps 3 --warmup 1 --code 1920.1280.3.303 --rate none --variant tanh --ebn0 $db; done   # configs[2]
+python - <<'PY'
+import json
+for l in open('gpurun_out/bench_matrix.jsonl'):
+    d = json.loads(l)
+    print(f"{d['config']['code_name']:48s} {d['config']['path']:5s} {d['dtype']} B={d['config']['batch_per_gpu']:6d} {d['value']:9.1f} Mbit/s  {d['ms_per_step']:8.2f} ms  rl {d['roofline']['frac']:.3f}  ber {d['ber']:.3e} fer {d['fer']:.3f} it {d['mean_iters']:.1f}")
+PY

@@ -55,31 +55,30 @@ template <> struct Store<__half> {
 template <typename CT> __device__ __forceinline__ bool hard(CT x) { return x > CT(0); }
 
 // ---------------------------------------------------------------- phi (float)
-// phi(x) = -ln(tanh(x/2)) for x >= 0;  phi(0) = +inf, phi(+inf) = 0.  Relative accuracy ~1e-7:
-//   x <  0.5 : tanh(y) = y * P(y^2) (odd Taylor series, y = x/2 <= 0.25), phi = -ln(y P)
-//   e <  1/16: phi = 2 atanh(e) = 2e (1 + e^2/3 + e^4/5 + e^6/7),  e = exp(-x)
-//   else     : phi = ln((1+e)/(1-e))      (1-e in [0.39, 0.94]: no harmful cancellation)
+// phi(x) = -ln(tanh(x/2)),  x >= 0.  Branch-free, 4 hardware transcendentals (v_exp, 2 v_rcp, v_log;
+// ~1 ulp each), two regimes sharing ONE logarithm:
+//   x <  0.5 : phi = -ln(x/2) + x^2/12 - 7x^4/1440 + 31x^6/90720        (1 - e^-x would cancel here)
+//   x >= 0.5 : phi = log1p(w), w = 2e/(1-e), e = e^-x;  log1p(w) = ln(1+w) * w/((1+w)-1), or w itself
+//              once 1+w rounds to 1 (the classic correction of the rounding of 1+w)
+// phi(0) = +inf and phi(+inf) = 0 EXACTLY: a zero factor makes the reference's tanh product, and so
+// its messages, exactly zero (Orig.hs:86-91) and that has to survive.  Emulated in float32 against the
+// double formula: relative error <= 1.1e-6 for x <= 20 (worst 10..20, from the rounding of x*log2 e),
+// absolute error <= 1.7e-6 everywhere.
 __device__ __forceinline__ float phi_f32(float x) {
-    if (x < 0.5f) {
-        float y = 0.5f * x, y2 = y * y;
-        // tanh(y)/y = 1 - y^2/3 + 2y^4/15 - 17y^6/315 + 62y^8/2835 - 1382y^10/155925
-        float p = -1382.0f / 155925.0f;
-        p = fmaf(p, y2, 62.0f / 2835.0f);
-        p = fmaf(p, y2, -17.0f / 315.0f);
-        p = fmaf(p, y2, 2.0f / 15.0f);
-        p = fmaf(p, y2, -1.0f / 3.0f);
-        p = fmaf(p, y2, 1.0f);
-        return -logf(y * p);
-    }
-    float e = expf(-x);
-    if (e < 0.0625f) {
-        float e2 = e * e;
-        float p = fmaf(e2, 1.0f / 7.0f, 1.0f / 5.0f);
-        p = fmaf(p, e2, 1.0f / 3.0f);
-        p = fmaf(p, e2, 1.0f);
-        return 2.0f * e * p;
-    }
-    return logf((1.0f + e) / (1.0f - e));
+    const float e = __builtin_amdgcn_exp2f(x * -1.44269504088896340736f);
+    const float d = fmaxf(1.0f - e, 1.4901161193847656e-08f);
+    const float w = (e + e) * __builtin_amdgcn_rcpf(d);
+    const float u = 1.0f + w;
+    const float um1 = u - 1.0f;
+    const bool small = x < 0.5f;
+    const float lg = __builtin_amdgcn_logf(small ? 0.5f * x : u) * 0.69314718055994530942f;
+    const float x2 = x * x;
+    float p = fmaf(-x2, 31.0f / 90720.0f, 7.0f / 1440.0f);
+    p = fmaf(-x2, p, 1.0f / 12.0f);
+    const float rs = fmaf(x2, p, -lg);
+    float rb = lg * (w * __builtin_amdgcn_rcpf(um1));
+    rb = (um1 == 0.0f) ? w : rb;
+    return small ? rs : rb;
 }
 
 // ---------------------------------------------------------------- check-node update, DEG known
@@ -127,32 +126,38 @@ __device__ __forceinline__ void cn_tanh_f64(double (&t)[DEG]) {
     }
 }
 
-// tanh rule, float, phi domain with prefix/suffix leave-one-out sums (no subtraction).
+// tanh rule, float, phi domain with prefix/suffix leave-one-out sums (no subtraction, so no
+// cancellation when one small |t| dominates the sum).  In place: t[k] becomes phi(|t_k|) after its sign
+// went into a bit word; one extra array holds the suffix sums.
 template <int DEG>
 __device__ __forceinline__ void cn_tanh_f32(float (&t)[DEG]) {
-    float ph[DEG];
-    unsigned par = 0; // parity of negative factors: tanh(-(t/2)) < 0 <=> t > 0
-    bool clampable = true; // the double reference clamps iff every factor rounds to +-1
+    static_assert(DEG <= 32, "sign word holds 32 edges");
+    uint32_t sg = 0, X = 0;  // sg bit (DEG-1-k) = sign bit of t_k ; X bit 31 = parity of the sign bits
 #pragma unroll
     for (int k = 0; k < DEG; k++) {
-        float a = fabsf(t[k]);
-        ph[k] = phi_f32(a);
-        par ^= (t[k] > 0.f) ? 1u : 0u;
-        (void)clampable;
+        uint32_t tb = __float_as_uint(t[k]);
+        X ^= tb;
+        sg = __builtin_amdgcn_alignbit(sg, tb, 31);
+        t[k] = phi_f32(fabsf(t[k]));
     }
     float suf[DEG];
     float run = 0.f;
 #pragma unroll
-    for (int k = DEG - 1; k >= 0; k--) { suf[k] = run; run += ph[k]; }
+    for (int k = DEG - 1; k >= 0; k--) { suf[k] = run; run += t[k]; }
+    // factor_j = tanh(-(t_j/2)) is negative iff t_j > 0; with zero factors the magnitude is 0 and the sign
+    // is irrelevant, so "t_j > 0" may be read off the sign bit: negative factors among j != k are
+    // (DEG-1) - sum_{j != k} signbit_j.  ne'_k = -sign(prod) * mag: positive iff that count is odd.
+    const uint32_t base = X ^ ((DEG & 1) ? 0u : 0x80000000u);  // bit 31: parity((DEG-1) + all sign bits)
     float pre = 0.f;
 #pragma unroll
     for (int k = 0; k < DEG; k++) {
         float S = pre + suf[k];
-        pre += ph[k];
+        pre += t[k];
         float mag = fminf(phi_f32(S), (float)kNeClamp);
-        unsigned neg = par ^ ((t[k] > 0.f) ? 1u : 0u); // sign of the leave-one-out product
-        // ne' = -2 atanh'(sign * P) = -sign * mag
-        t[k] = neg ? mag : -mag;
+        // count parity for edge k = base ^ signbit_k ; ne' > 0 iff odd -> sign bit of ne' = NOT that
+        uint32_t sk = (sg << (31 - (DEG - 1 - k)));
+        uint32_t neg = ~(base ^ sk) & 0x80000000u;
+        t[k] = __uint_as_float(__float_as_uint(mag) | neg);
     }
 }
 

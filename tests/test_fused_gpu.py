@@ -20,8 +20,7 @@ def _frames(c, per_db, dbs, seed):
 def test_auto_path_is_fused_for_ar4ja_minsum(hip, name, dbs):
     c = load(name)
     assert hip.Decoder(c.hip_code(hip), "min", "f32", 8).path == "fused"
-    assert hip.Decoder(c.hip_code(hip), "tanh", "f32", 8).path == "flood"   # fused tanh exists but flood is faster today
-    assert hip.Decoder(c.hip_code(hip), "tanh", "f32", 8, path="fused").path == "fused"
+    assert hip.Decoder(c.hip_code(hip), "tanh", "f32", 8).path == "fused"
     assert hip.Decoder(c.hip_code(hip), "tanh", "f64", 8).path == "flood"
     assert hip.Decoder(c.hip_code(hip, prefer_qc=False), "min", "f32", 8).path == "flood"  # CSR graph: no QC table
     with pytest.raises(hip.LdpcError) as e:

@@ -137,7 +137,7 @@ def main():
     avg_ms = kernel_ms / max(launches, 1)
     achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if launches else 0.0
     roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": measured_traffic(args, dec, B),
                 "kernel": dec.kernel_name, "launches": launches, "avg_launch_ms": round(avg_ms, 4),
                 "algorithmic_bytes_per_launch": bytes_per_launch, "bytes_model": bytes_note}
 
@@ -163,6 +163,20 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def measured_traffic(args, dec, B):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
+    (profiles/*_pmc.json: FETCH_SIZE and WRITE_SIZE collected in separate --pmc runs of this same
+    command), scaled by frames per launch; None when no profile of this configuration is committed."""
+    if not (dec.path == "fused" and args.code == "jpl.4096.4.5" and args.variant == "minsum" and args.dtype == "f32"):
+        return None
+    try:
+        prof = json.load(open(os.path.join(ROOT, "profiles", "r01_fused_v2_f32_minsum_pmc.json")))
+        h = prof["hbm_bytes_per_launch"]
+        return int((h["FETCH_SIZE_raw_bytes"] + h["WRITE_SIZE_bytes"]) * B / 65536)
+    except Exception:
+        return None
 
 
 def host_cores():

@@ -76,7 +76,10 @@ def main():
     B = args.batch
     s_bytes = {"f32": 4, "f64": 8, "f16": 2}[args.dtype]
 
-    stream = torch.cuda.current_stream()
+    # one explicit non-default stream for everything the library enqueues (a NULL handle would mean
+    # "the context's own stream" for decode but the default stream for the frame source)
+    stream = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(stream)
     sp = stream.cuda_stream
     nbuf = max(1, min(args.steps + args.warmup, 4))
     llr = [torch.empty((B, N), dtype=torch.float32, device=dev) for _ in range(nbuf)]

@@ -116,7 +116,9 @@ int ldpc_decode_batch_f64(ldpc_ctx *ctx, int max_iters, int batch, const double 
                           int32_t *iters, uint8_t *converged, double *final_lam);
 /* zero-copy path: every pointer is DEVICE memory on the context's device.  d_llr [batch][N]
  * float32; d_bits [batch][N] bytes; d_iters, d_converged may be NULL.  Work is enqueued on
- * `stream` (a hipStream_t; NULL = the context's own stream) and NOT synchronised. */
+ * `stream` (a hipStream_t) and NOT synchronised.  NULL = the context's OWN stream, which is
+ * non-blocking: it does not order against the default (null) stream, so a caller that produces
+ * d_llr on another stream must pass that stream here (or synchronise first). */
 int ldpc_decode_batch_dev(ldpc_ctx *ctx, int max_iters, int batch, const float *d_llr,
                           uint8_t *d_bits, int32_t *d_iters, uint8_t *d_converged, void *stream);
 /* wait for everything enqueued on the context's stream */
@@ -157,7 +159,8 @@ ldpc_sim *ldpc_sim_create(const ldpc_code *code, int k, int n_tx, int p, const u
 void ldpc_sim_destroy(ldpc_sim *sim);
 /* frames [first_frame, first_frame+batch) of the stream identified by `seed`, at Eb/N0 (dB):
  * d_llr [batch][N] float32 (device), d_msg [batch][k] bytes (device, may be NULL).  Enqueued on
- * `stream` (NULL = default stream), not synchronised.  The message words stay inside `sim` for
+ * `stream` (NULL = the HIP default stream -- NOT a context's stream), not synchronised: pass the same
+ * explicit stream to generate, decode and tally.  The message words stay inside `sim` for
  * the next ldpc_sim_tally call. */
 int ldpc_sim_generate(ldpc_sim *sim, uint64_t seed, uint64_t first_frame, int batch, double ebn0_db,
                       float *d_llr, uint8_t *d_msg, void *stream);

@@ -141,3 +141,15 @@ def test_standalone_mackay_matrix_record(hip):
     with pytest.raises(hip.LdpcError) as e:
         ecc.encode(np.zeros(640, np.uint8))
     assert e.value.code == -5
+
+
+@pytest.mark.gpu
+def test_cli_rows(hip, capsys):
+    """The ecc-ldpc-like CLI (reference usage: main/Main.hs:38-40, NOTES.txt:2-3)."""
+    from ecc_ldpc_amd import cli
+    rc = cli.main(["3", "4.5", "ldpc/hip-minsum/jpl.1024.4.5/50/4/5", "ldpc/reference/jpl.1024.4.5/50", "-m2048", "-b1024"])
+    out = capsys.readouterr()
+    rows = [l.split() for l in out.out.strip().splitlines()]
+    assert rc == 0 and len(rows) == 2 and "no such code" in out.err
+    assert rows[0][1] == "ldpc/hip-minsum/jpl.1024.4.5/50/4/5" and int(rows[0][3]) == 2048
+    assert float(rows[0][5]) > float(rows[1][5]) and float(rows[1][5]) == 0.0  # BER falls with Eb/N0; 4.5 dB is clean

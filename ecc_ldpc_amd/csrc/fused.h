@@ -17,4 +17,15 @@ int fused_decode(FusedState &s, hipStream_t st, int max_iters, int batch, const 
                  uint8_t *d_bits, int32_t *d_iters, uint8_t *d_conv, double *d_final, double *d_trace);
 int fused_step(FusedState &s, hipStream_t st, int batch, const double *d_orig, const double *d_lam,
                const double *d_ne, double *d_ne_out, double *d_lam_out, uint8_t *d_syn);
+
+// generic on-chip kernel for any H that fits in LDS (fused_csr.hip); reached through the functions above
+struct CsrState;
+const char *fused_csr_why_not(const ldpc_code &code, int variant, int dtype);
+CsrState *fused_csr_create(const ldpc_code &code, int variant, int dtype);
+void fused_csr_destroy(CsrState *s);
+void fused_csr_set_timer(CsrState *s, KernelTimer *t);
+int fused_csr_decode(CsrState &s, hipStream_t st, int max_iters, int batch, const void *d_llr, int llr_is_f64, uint8_t *d_bits,
+                     int32_t *d_iters, uint8_t *d_conv, double *d_final, double *d_trace);
+int fused_csr_step(CsrState &s, hipStream_t st, int batch, const double *d_orig, const double *d_lam, const double *d_ne,
+                   double *d_ne_out, double *d_lam_out, uint8_t *d_syn);
 }  // namespace ldpc

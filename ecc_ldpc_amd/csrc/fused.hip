@@ -28,6 +28,7 @@
 //   lo 16 bits = rotation * cpw * sizeof(CT)   (byte rotation inside a block column)
 //   hi 16 bits = bc * V * sizeof(CT)           (byte base of the block column in LDS)
 // The degree sequence of the block rows is a compile-time Plan (registers must be named statically).
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -349,6 +350,7 @@ __global__ __launch_bounds__((FusedCfg<CT, Plan, SZ>::THREADS), (FusedCfg<CT, Pl
 // ------------------------------------------------------------------ host side
 struct FusedState {
     int variant = 0, dtype = 0, max_batch = 0, sz = 0, M = 0, N = 0, E = 0;
+    CsrState *csr = nullptr;  // set when the code has no QC plan: generic on-chip kernel (fused_csr.hip)
     int static_id = 0;    // compiled-in rotation table matching this code (0 = none: table-driven kernel)
     bool use_msg = true;  // per-edge-message kernel (fused_msg.hip) vs compressed-record kernel (this file)
     KernelTimer *timer = nullptr;
@@ -366,13 +368,23 @@ static bool plan_matches_ar4ja45(const ldpc_code &c) {
     return true;
 }
 
-const char *fused_why_not(const ldpc_code &c, int variant, int dtype) {
+static const char *plan_why_not(const ldpc_code &c, int variant, int dtype) {
     if (variant == LDPC_TANH && dtype != LDPC_F32) return "the fused tanh kernel exists for f32 only (f64 tanh: flood path)";
     if (dtype != LDPC_F32 && dtype != LDPC_F64) return "fused kernels exist for f32 and f64";
     if (c.sz == 0) return "code was not created from a quasi-cyclic description";
     if (!(c.sz == 32 || c.sz == 64 || c.sz == 128)) return "circulant size must be 32, 64 or 128";
     if (!plan_matches_ar4ja45(c)) return "block structure is not the AR4JA rate-4/5 plan (12x44 blocks, row weights 3,3,3,3,18x8)";
     return nullptr;
+}
+// a fused (on-chip) kernel exists if the code matches a compiled QC plan, or failing that if a frame fits in LDS
+const char *fused_why_not(const ldpc_code &c, int variant, int dtype) {
+    const char *p = plan_why_not(c, variant, dtype);
+    if (!p) return nullptr;
+    const char *g = fused_csr_why_not(c, variant, dtype);
+    if (!g) return nullptr;
+    static thread_local char buf[400];
+    snprintf(buf, sizeof(buf), "QC-plan kernel: %s; generic on-chip kernel: %s", p, g);
+    return buf;
 }
 bool fused_supported(const ldpc_code &c, int variant, int dtype) { return fused_why_not(c, variant, dtype) == nullptr; }
 // measured r01 (jpl.4096, 16384 frames): min-sum fused 10.0 vs flood 0.85 Gbit/s; tanh fused 2.09 vs flood 0.73
@@ -415,6 +427,11 @@ FusedState *fused_create(const ldpc_code &c, int variant, int dtype, int max_bat
     FusedState *s = new (std::nothrow) FusedState();
     if (!s) { set_error(LDPC_ENOMEM, "out of host memory"); return nullptr; }
     s->variant = variant; s->dtype = dtype; s->max_batch = max_batch; s->sz = c.sz; s->M = c.M; s->N = c.N; s->E = c.E;
+    if (plan_why_not(c, variant, dtype) != nullptr) {  // no QC plan: generic on-chip kernel
+        s->csr = fused_csr_create(c, variant, dtype);
+        if (!s->csr) { delete s; return nullptr; }
+        return s;
+    }
     s->row_ptr = c.row_ptr;
     {   // LDPC_FUSED_KERNEL=rec selects the compressed-record kernel (min-sum only) for A/B measurements
         const char *k = getenv("LDPC_FUSED_KERNEL");
@@ -450,14 +467,16 @@ FusedState *fused_create(const ldpc_code &c, int variant, int dtype, int max_bat
 
 void fused_destroy(FusedState *s) {
     if (!s) return;
+    fused_csr_destroy(s->csr);
     (void)hipFree(s->d_tab);
     delete s;
 }
 
-void fused_set_timer(FusedState *s, KernelTimer *t) { if (s) s->timer = t; }
+void fused_set_timer(FusedState *s, KernelTimer *t) { if (s) { s->timer = t; fused_csr_set_timer(s->csr, t); } }
 
 int fused_decode(FusedState &s, hipStream_t st, int max_iters, int batch, const void *d_llr, int llr_is_f64, uint8_t *d_bits,
                  int32_t *d_iters, uint8_t *d_conv, double *d_final, double *d_trace) {
+    if (s.csr) return fused_csr_decode(*s.csr, st, max_iters, batch, d_llr, llr_is_f64, d_bits, d_iters, d_conv, d_final, d_trace);
     FusedArgs a{};
     a.tab = s.d_tab; a.llr = d_llr; a.llr_is_f64 = llr_is_f64; a.bits = d_bits; a.iters = d_iters; a.conv = d_conv;
     a.final_lam = d_final; a.trace = d_trace; a.batch = batch; a.max_iters = max_iters; a.step_mode = 0;
@@ -517,6 +536,7 @@ static int step_typed(FusedState &s, hipStream_t st, int batch, const double *d_
 
 int fused_step(FusedState &s, hipStream_t st, int batch, const double *d_orig, const double *d_lam, const double *d_ne,
                double *d_ne_out, double *d_lam_out, uint8_t *d_syn) {
+    if (s.csr) return fused_csr_step(*s.csr, st, batch, d_orig, d_lam, d_ne, d_ne_out, d_lam_out, d_syn);
     if (s.use_msg) {  // per-edge messages: the state goes in and out as it is
         FusedArgs a{};
         a.tab = s.d_tab; a.llr = d_orig; a.llr_is_f64 = 1; a.batch = batch; a.max_iters = 1; a.step_mode = 1;

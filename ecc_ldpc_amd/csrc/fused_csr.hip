@@ -1,0 +1,249 @@
+// fused_csr.hip -- on-chip flooding BP for ANY parity-check matrix that fits in LDS (gfx950).
+//
+// The reference's `Matrix Bool` decoders (Reference/Orig.hs:30-31, Reference/Min.hs:33-34) take any H;
+// this is their fused counterpart: one launch decodes the batch, one workgroup (256 threads) owns one
+// frame, and lam, the channel LLRs and every message stay in LDS for all iterations.  Used when the
+// code has no compiled QC plan (fused_msg.hip) and (2N + DMAX*M) elements fit in 160 KB -- e.g.
+// codes/1920.1280.3.303 (BASELINE configs[2]) and codes/moon.7.13; larger codes use flood.hip.
+//
+// Layout: messages in ELL form, slot(m,k) = k*M + m for the k-th edge of row m (ascending column):
+// thread m walks slots m, M+m, 2M+m, .. so a wave touches consecutive dwords (no bank conflicts on the
+// message array; the lam gather follows the code's own column pattern and may conflict).
+// Graph tables in global memory, read every turn through L1/L2 with coalesced vector loads:
+//   ell_col [DMAX][M]  column of slot, -1 = padding
+//   csc_slot[CDMAX][N] slots of column n in DESCENDING row order (the reference's foldr, Orig.hs:96), -1 = none
+// Turn n (Orig.hs:67-71): rows -> parity of hard(lam) (syndrome) and new messages (ldpc_math.h,
+// cn_update_padded: identical arithmetic to the other paths); __syncthreads_or = syndrome verdict;
+// columns -> lam = orig + messages.  Two barriers per turn.
+#include <stdlib.h>
+#include <string.h>
+
+#include <vector>
+
+#include "fused.h"
+#include "ldpc_math.h"
+
+namespace ldpc {
+
+constexpr int kCsrThreads = 256;
+
+struct CsrArgs {
+    const int32_t *ell_col, *csc_slot, *row_ptr;
+    int M, N, E, cdmax;
+    const void *llr;
+    uint8_t *bits;
+    int32_t *iters;
+    uint8_t *conv;
+    double *final_lam, *trace;
+    int batch, max_iters, llr_is_f64, step_mode;
+    const double *st_lam, *st_ne_in;
+    double *st_ne_out;
+    uint8_t *st_syn;
+};
+
+template <typename CT, int VARIANT, int DMAX>
+__global__ __launch_bounds__(kCsrThreads) void fused_csr_kernel(CsrArgs A) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    CT *lam = reinterpret_cast<CT *>(smem);
+    CT *orig = lam + A.N;
+    CT *msg = orig + A.N;  // [DMAX][M]
+    const int tid = threadIdx.x;
+    const int frame = blockIdx.x;
+    const int M = A.M, N = A.N;
+    const size_t fN = (size_t)frame * N, fE = (size_t)frame * A.E;
+
+    for (int n = tid; n < N; n += kCsrThreads) {
+        CT v = A.llr_is_f64 ? (CT) reinterpret_cast<const double *>(A.llr)[fN + n] : (CT) reinterpret_cast<const float *>(A.llr)[fN + n];
+        orig[n] = v;
+        lam[n] = A.step_mode ? (CT)A.st_lam[fN + n] : v;
+    }
+    for (int m = tid; m < M; m += kCsrThreads) {
+        const int e0 = A.row_ptr[m], deg = A.row_ptr[m + 1] - e0;
+#pragma unroll
+        for (int k = 0; k < DMAX; k++) msg[k * M + m] = (A.step_mode && k < deg) ? (CT)A.st_ne_in[fE + e0 + k] : CT(0);  // Orig.hs:64-65
+    }
+    __syncthreads();
+
+    bool converged = false;
+    int n_done = 0;
+    const int turns = A.step_mode ? 1 : A.max_iters;
+    for (int n = 0;; n++) {
+        if (A.trace)
+            for (int c = tid; c < N; c += kCsrThreads) A.trace[((size_t)frame * (A.max_iters + 1) + n) * N + c] = (double)lam[c];
+        const bool last = n >= turns;
+        // ---- rows: syndrome + check-node update
+        int unsat = 0;
+        for (int m = tid; m < M; m += kCsrThreads) {
+            const int deg = A.row_ptr[m + 1] - A.row_ptr[m];
+            CT t[DMAX];
+            bool par = false;
+#pragma unroll
+            for (int k = 0; k < DMAX; k++) {
+                const int col = A.ell_col[k * M + m];
+                if (col >= 0) {
+                    CT l = lam[col];
+                    par ^= (l > CT(0));
+                    t[k] = last ? CT(0) : l - msg[k * M + m];
+                } else {
+                    t[k] = CT(INFINITY);
+                }
+            }
+            unsat |= par ? 1 : 0;
+            if (!last) {
+                cn_update_padded<CT, VARIANT, DMAX>(t, deg);
+#pragma unroll
+                for (int k = 0; k < DMAX; k++)
+                    if (k < deg) msg[k * M + m] = t[k];
+            }
+        }
+        const int any_unsat = __syncthreads_or(unsat);  // also: every message written, every lam read
+        if (A.step_mode) {
+            if (tid == 0) A.st_syn[frame] = any_unsat ? 0 : 1;
+        } else if (!any_unsat) {  // Orig.hs:69
+            converged = true; n_done = n;
+            break;
+        }
+        if (last) { n_done = n; break; }  // Orig.hs:70
+        // ---- columns: lam = foldr (+) orig (column of ne')
+        for (int c = tid; c < N; c += kCsrThreads) {
+            CT acc = orig[c];
+            for (int j = 0; j < A.cdmax; j++) {
+                const int slot = A.csc_slot[j * N + c];
+                if (slot >= 0) acc = msg[slot] + acc;
+            }
+            lam[c] = acc;
+        }
+        __syncthreads();
+        if (A.step_mode) break;
+    }
+
+    if (A.step_mode) {
+        for (int c = tid; c < N; c += kCsrThreads) A.final_lam[fN + c] = (double)lam[c];
+        for (int m = tid; m < M; m += kCsrThreads) {
+            const int e0 = A.row_ptr[m], deg = A.row_ptr[m + 1] - e0;
+            for (int k = 0; k < deg; k++) A.st_ne_out[fE + e0 + k] = (double)msg[k * M + m];
+        }
+        return;
+    }
+    for (int c = tid; c < N; c += kCsrThreads) {
+        CT v = converged ? lam[c] : orig[c];
+        A.bits[fN + c] = v > CT(0) ? 1 : 0;
+        if (A.final_lam) A.final_lam[fN + c] = (double)v;
+    }
+    if (tid == 0) {
+        if (A.iters) A.iters[frame] = n_done;
+        if (A.conv) A.conv[frame] = converged ? 1 : 0;
+    }
+}
+
+// ------------------------------------------------------------------ host side
+struct CsrState {
+    int variant = 0, dtype = 0, M = 0, N = 0, E = 0, dmax = 0, cdmax = 0;
+    int32_t *d_ell = nullptr, *d_csc = nullptr, *d_row_ptr = nullptr;
+    KernelTimer *timer = nullptr;
+};
+
+static int pick_dmax(int maxdeg) { return maxdeg <= 4 ? 4 : maxdeg <= 8 ? 8 : maxdeg <= 20 ? 20 : maxdeg <= 32 ? 32 : 0; }
+static size_t csr_lds_bytes(const ldpc_code &c, int dtype) {
+    const int dm = pick_dmax(c.max_row_deg);
+    return ((size_t)2 * c.N + (size_t)dm * c.M) * (dtype == LDPC_F64 ? 8 : 4);
+}
+
+const char *fused_csr_why_not(const ldpc_code &c, int variant, int dtype) {
+    if (dtype != LDPC_F32 && dtype != LDPC_F64) return "the generic on-chip kernel exists for f32 and f64";
+    if (pick_dmax(c.max_row_deg) == 0) return "a check row has more than 32 edges";
+    if (variant == LDPC_TANH && dtype == LDPC_F64 && c.max_row_deg > 8) return "f64 tanh rows above degree 8 stay on the flood path";
+    if (csr_lds_bytes(c, dtype) > 160 * 1024) return "lam + LLRs + messages of one frame exceed the 160 KB of LDS";
+    return nullptr;
+}
+
+void fused_csr_destroy(CsrState *s) {
+    if (!s) return;
+    (void)hipFree(s->d_ell); (void)hipFree(s->d_csc); (void)hipFree(s->d_row_ptr);
+    delete s;
+}
+
+CsrState *fused_csr_create(const ldpc_code &c, int variant, int dtype) {
+    const char *why = fused_csr_why_not(c, variant, dtype);
+    if (why) { set_error(LDPC_EUNSUPPORTED, "%s", why); return nullptr; }
+    CsrState *s = new (std::nothrow) CsrState();
+    if (!s) { set_error(LDPC_ENOMEM, "out of host memory"); return nullptr; }
+    s->variant = variant; s->dtype = dtype; s->M = c.M; s->N = c.N; s->E = c.E;
+    s->dmax = pick_dmax(c.max_row_deg); s->cdmax = c.max_col_deg;
+    std::vector<int32_t> ell((size_t)s->dmax * c.M, -1), csc((size_t)std::max(s->cdmax, 1) * c.N, -1), slot_of_edge((size_t)c.E);
+    for (int m = 0; m < c.M; m++)
+        for (int e = c.row_ptr[m]; e < c.row_ptr[m + 1]; e++) {
+            int k = e - c.row_ptr[m];
+            ell[(size_t)k * c.M + m] = c.col_idx[e];
+            slot_of_edge[e] = k * c.M + m;
+        }
+    for (int n = 0; n < c.N; n++) {
+        int j = 0;
+        for (int q = c.col_ptr[n + 1] - 1; q >= c.col_ptr[n]; q--, j++) csc[(size_t)j * c.N + n] = slot_of_edge[c.csc_edge[q]];  // descending row
+    }
+    auto up = [&](int32_t **dst, const std::vector<int32_t> &v) {
+        hipError_t e = hipMalloc((void **)dst, v.size() * 4);
+        if (e == hipSuccess) e = hipMemcpy(*dst, v.data(), v.size() * 4, hipMemcpyHostToDevice);
+        return e;
+    };
+    hipError_t e = up(&s->d_ell, ell);
+    if (e == hipSuccess) e = up(&s->d_csc, csc);
+    if (e == hipSuccess) e = up(&s->d_row_ptr, c.row_ptr);
+    if (e != hipSuccess) { set_error(LDPC_EHIP, "fused_csr_create: %s", hipGetErrorString(e)); fused_csr_destroy(s); return nullptr; }
+    return s;
+}
+
+void fused_csr_set_timer(CsrState *s, KernelTimer *t) { if (s) s->timer = t; }
+
+template <typename CT, int VARIANT, int DMAX>
+static int launch_csr(CsrState &s, hipStream_t st, CsrArgs &a) {
+    auto kern = fused_csr_kernel<CT, VARIANT, DMAX>;
+    const size_t lds = ((size_t)2 * s.N + (size_t)DMAX * s.M) * sizeof(CT);
+    static size_t attr_set = 0;
+    if (lds > 64 * 1024 && lds > attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return set_error(LDPC_EHIP, "hipFuncSetAttribute(%zu B LDS): %s", lds, hipGetErrorString(e));
+        attr_set = lds;
+    }
+    if (s.timer && !a.step_mode) s.timer->begin(st);
+    hipLaunchKernelGGL(kern, dim3(a.batch), dim3(kCsrThreads), lds, st, a);
+    if (s.timer && !a.step_mode) s.timer->end(st);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return set_error(LDPC_EHIP, "fused_csr launch: %s", hipGetErrorString(e));
+    return LDPC_OK;
+}
+
+template <typename CT, int VARIANT>
+static int dispatch_dmax(CsrState &s, hipStream_t st, CsrArgs &a) {
+    switch (s.dmax) {
+        case 4: return launch_csr<CT, VARIANT, 4>(s, st, a);
+        case 8: return launch_csr<CT, VARIANT, 8>(s, st, a);
+        case 20: if constexpr (!(VARIANT == LDPC_V_TANH && sizeof(CT) == 8)) return launch_csr<CT, VARIANT, 20>(s, st, a); break;
+        case 32: if constexpr (!(VARIANT == LDPC_V_TANH && sizeof(CT) == 8)) return launch_csr<CT, VARIANT, 32>(s, st, a); break;
+    }
+    return set_error(LDPC_EUNSUPPORTED, "no generic on-chip kernel for row degree class %d", s.dmax);
+}
+
+static int csr_run(CsrState &s, hipStream_t st, CsrArgs &a) {
+    a.ell_col = s.d_ell; a.csc_slot = s.d_csc; a.row_ptr = s.d_row_ptr; a.M = s.M; a.N = s.N; a.E = s.E; a.cdmax = s.cdmax;
+    if (s.dtype == LDPC_F64) return s.variant == LDPC_MINSUM ? dispatch_dmax<double, LDPC_V_MINSUM>(s, st, a) : dispatch_dmax<double, LDPC_V_TANH>(s, st, a);
+    return s.variant == LDPC_MINSUM ? dispatch_dmax<float, LDPC_V_MINSUM>(s, st, a) : dispatch_dmax<float, LDPC_V_TANH>(s, st, a);
+}
+
+int fused_csr_decode(CsrState &s, hipStream_t st, int max_iters, int batch, const void *d_llr, int llr_is_f64, uint8_t *d_bits,
+                     int32_t *d_iters, uint8_t *d_conv, double *d_final, double *d_trace) {
+    CsrArgs a{};
+    a.llr = d_llr; a.llr_is_f64 = llr_is_f64; a.bits = d_bits; a.iters = d_iters; a.conv = d_conv; a.final_lam = d_final; a.trace = d_trace;
+    a.batch = batch; a.max_iters = max_iters;
+    return csr_run(s, st, a);
+}
+
+int fused_csr_step(CsrState &s, hipStream_t st, int batch, const double *d_orig, const double *d_lam, const double *d_ne,
+                   double *d_ne_out, double *d_lam_out, uint8_t *d_syn) {
+    CsrArgs a{};
+    a.llr = d_orig; a.llr_is_f64 = 1; a.batch = batch; a.max_iters = 1; a.step_mode = 1;
+    a.st_lam = d_lam; a.st_ne_in = d_ne; a.st_ne_out = d_ne_out; a.final_lam = d_lam_out; a.st_syn = d_syn;
+    return csr_run(s, st, a);
+}
+
+}  // namespace ldpc

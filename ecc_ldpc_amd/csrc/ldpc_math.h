@@ -161,6 +161,90 @@ __device__ __forceinline__ void cn_tanh_f32(float (&t)[DEG]) {
     }
 }
 
+// ---------------------------------------------------------------- padded rows (generic on-chip kernel)
+// Rows of any degree <= DMAX: slots k >= deg hold t = +inf, which is neutral for both rules
+// (|t| = inf never wins a min; phi(inf) = 0 adds nothing; sign bit 0) -- only the "(D odd)" term of the
+// sign rule needs the real degree.  Results for the real slots are bit-identical to cn_update<deg>.
+template <typename CT, int VARIANT, int DMAX>
+__device__ __forceinline__ void cn_update_padded(CT (&t)[DMAX], int deg) {
+    if constexpr (VARIANT == LDPC_V_MINSUM) {
+        if constexpr (sizeof(CT) == 4) {
+            uint32_t X = 0;
+            float m1 = INFINITY, m2 = INFINITY;
+#pragma unroll
+            for (int k = 0; k < DMAX; k++) {
+                X ^= __float_as_uint(t[k]);
+                float a = fabsf(t[k]);
+                m2 = __builtin_amdgcn_fmed3f(m1, m2, a);
+                m1 = fminf(m1, a);
+            }
+            const uint32_t flip = (X ^ ((deg & 1) ? 0x80000000u : 0u)) & 0x80000000u;
+            const uint32_t c1 = __float_as_uint(0.75f * m1) ^ flip;
+            const uint32_t c2 = __float_as_uint(0.75f * m2) ^ flip;
+#pragma unroll
+            for (int k = 0; k < DMAX; k++) {
+                uint32_t c = (fabsf(t[k]) == m1) ? c2 : c1;
+                t[k] = __uint_as_float(__builtin_amdgcn_bitop3_b32(c, __float_as_uint(t[k]), 0x80000000u, 0x78));
+            }
+        } else {
+            CT m1 = CT(INFINITY), m2 = CT(INFINITY);
+            unsigned par = 0;
+#pragma unroll
+            for (int k = 0; k < DMAX; k++) {
+                CT a = fabs(t[k]);
+                par ^= (k < deg && t[k] > CT(0)) ? 1u : 0u;
+                if (a < m1) { m2 = m1; m1 = a; }
+                else if (a < m2) { m2 = a; }
+            }
+#pragma unroll
+            for (int k = 0; k < DMAX; k++) {
+                CT mag = (fabs(t[k]) == m1) ? m2 : m1;
+                unsigned neg = par ^ ((t[k] > CT(0)) ? 1u : 0u);
+                t[k] = CT(-0.75) * (neg ? -mag : mag);
+            }
+        }
+    } else if constexpr (sizeof(CT) == 8) {
+        double th[DMAX];
+#pragma unroll
+        for (int k = 0; k < DMAX; k++) th[k] = tanh(-(t[k] / 2.0));
+#pragma unroll
+        for (int k = 0; k < DMAX; k++) {
+            double prod = 1.0;
+#pragma unroll
+            for (int j = 0; j < DMAX; j++)
+                if (j != k && j < deg) prod = prod * th[j];
+            double y = 0.5 * log((1.0 + prod) / (1.0 - prod));
+            if (isinf(y)) y = (prod > 0.0 ? 1.0 : -1.0) * kAtanhClamp;
+            t[k] = -2.0 * y;
+        }
+    } else {
+        static_assert(DMAX <= 32, "sign word holds 32 edges");
+        uint32_t sg = 0, X = 0;
+#pragma unroll
+        for (int k = 0; k < DMAX; k++) {
+            uint32_t tb = __float_as_uint(t[k]);
+            X ^= tb;
+            sg = __builtin_amdgcn_alignbit(sg, tb, 31);
+            t[k] = phi_f32(fabsf(t[k]));
+        }
+        float suf[DMAX];
+        float run = 0.f;
+#pragma unroll
+        for (int k = DMAX - 1; k >= 0; k--) { suf[k] = run; run += t[k]; }
+        const uint32_t base = X ^ ((deg & 1) ? 0u : 0x80000000u);
+        float pre = 0.f;
+#pragma unroll
+        for (int k = 0; k < DMAX; k++) {
+            float S = pre + suf[k];
+            pre += t[k];
+            float mag = fminf(phi_f32(S), (float)kNeClamp);
+            uint32_t sk = (sg << (31 - (DMAX - 1 - k)));
+            uint32_t neg = ~(base ^ sk) & 0x80000000u;
+            t[k] = __uint_as_float(__float_as_uint(mag) | neg);
+        }
+    }
+}
+
 template <typename CT, int VARIANT, int DEG>
 __device__ __forceinline__ void cn_update(CT (&t)[DEG]) {
     if constexpr (VARIANT == LDPC_V_MINSUM) {

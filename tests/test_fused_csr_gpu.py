@@ -1,0 +1,100 @@
+"""GPU: the generic on-chip kernel (fused_csr.hip: any H that fits in LDS) against the oracle and the
+flood path, through the C ABI.  Same bars as the other paths."""
+import numpy as np
+import pytest
+
+from oracle import oracle
+from tests.helpers import lam_tolerance, load
+
+pytestmark = pytest.mark.gpu
+
+CASES = [("moon.7.13", 20, (1.0, 3.0, 5.0)), ("1920.1280.3.303", 50, (1.0, 2.0, 3.0)), ("jpl.1024.4.5", 50, (2.0, 3.0, 4.0))]
+
+
+def _frames(c, per_db, dbs, seed):
+    return np.concatenate([c.frames(per_db, db, seed + i)[1] for i, db in enumerate(dbs)])
+
+
+def _code(hip, c):
+    return c.hip_code(hip, prefer_qc=False)  # plain CSR graph: no QC plan -> generic kernel
+
+
+@pytest.mark.parametrize("name,iters,dbs", CASES)
+def test_auto_path(hip, name, iters, dbs):
+    c = load(name)
+    for variant in ("min", "tanh"):
+        assert hip.Decoder(_code(hip, c), variant, "f32", 8).path == "fused"
+    assert hip.Decoder(_code(hip, c), "min", "f16", 8).path == "flood"
+    big = load("jpl.4096.4.5")  # as a CSR graph: 2N + 20M floats = 168 KB > 160 KB of LDS
+    assert hip.Decoder(_code(hip, big), "min", "f32", 8).path == "flood"
+    with pytest.raises(hip.LdpcError) as e:
+        hip.Decoder(_code(hip, big), "min", "f32", 8, path="fused")
+    assert e.value.code == -5 and "LDS" in str(e.value)
+
+
+@pytest.mark.parametrize("name,iters,dbs", CASES)
+def test_minsum_f64_trajectory_is_bit_exact(hip, name, iters, dbs):
+    c = load(name)
+    llr = _frames(c, 4, dbs, 1100)
+    dec = hip.Decoder(_code(hip, c), "min", "f64", len(llr), path="fused")
+    bits, its, conv, trace = dec.decode_trace(llr, iters)
+    for f in range(len(llr)):
+        o = oracle.decode(c.graph, "min", iters, llr[f], trace=True)
+        assert its[f] == o["iters"] and bool(conv[f]) == o["converged"] and np.array_equal(bits[f], o["bits"])
+        assert np.array_equal(trace[f, : o["iters"] + 1], o["trace_lam"]), f
+
+
+@pytest.mark.parametrize("variant", ["min", "tanh"])
+@pytest.mark.parametrize("name,iters,dbs", CASES)
+def test_f32_equals_flood_and_oracle_bits(hip, name, iters, dbs, variant):
+    c = load(name)
+    llr = _frames(c, 24, dbs, 1200)
+    code = _code(hip, c)
+    a = hip.Decoder(code, variant, "f32", len(llr), path="fused").decode_batch(llr.astype(np.float32), iters)
+    b = hip.Decoder(code, variant, "f32", len(llr), path="flood").decode_batch(llr.astype(np.float32), iters)
+    assert all(np.array_equal(x, y) for x, y in zip(a, b))  # same arithmetic, same order
+    ob, oi, oc = oracle.decode_batch(c.graph, variant, iters, llr, nthreads=8)
+    assert np.array_equal(a[0], ob) and np.array_equal(a[2], oc) and (a[1] == oi).mean() >= 0.95
+
+
+@pytest.mark.parametrize("variant,dtype", [("min", "f32"), ("tanh", "f32"), ("tanh", "f64")])
+@pytest.mark.parametrize("name,iters,dbs", CASES[:2])
+def test_teacher_forced_step(hip, name, iters, dbs, variant, dtype):
+    c = load(name)
+    llr = _frames(c, 2, dbs, 1300)
+    dec = hip.Decoder(_code(hip, c), variant, dtype, 64, path="fused")
+    states = []
+    for f in range(len(llr)):
+        o = oracle.decode(c.graph, variant, iters, llr[f], trace=True)
+        ne = np.zeros(c.E)
+        for n in range(o["iters"]):
+            states.append((llr[f], o["trace_lam"][n], ne, o["trace_ne"][n], o["trace_lam"][n + 1]))
+            ne = o["trace_ne"][n]
+    states = states[:128]
+    worst = 0.0
+    for s0 in range(0, len(states), 64):
+        ch = states[s0:s0 + 64]
+        ne2, lam2, syn0 = dec.debug_step(np.stack([s[0] for s in ch]), np.stack([s[1] for s in ch]), np.stack([s[2] for s in ch]))
+        assert not syn0.any()
+        for i, s in enumerate(ch):
+            tol_lam, tol_ne = lam_tolerance(c.graph, s[3], s[4], rel=1e-5 if dtype == "f32" else 1e-12)
+            assert (np.abs(ne2[i] - s[3]) <= tol_ne).all() and (np.abs(lam2[i] - s[4]) <= tol_lam).all()
+            worst = max(worst, (np.abs(lam2[i] - s[4]) / np.maximum(1, np.abs(s[4]))).max())
+    print(f"{name} fused-csr {variant} {dtype}: worst teacher-forced relative LLR error {worst:.3e} over {len(states)} turns")
+
+
+def test_edge_cases(hip):
+    c = load("1920.1280.3.303")
+    dec = hip.Decoder(_code(hip, c), "tanh", "f32", 70, path="fused")
+    _, llr = c.frames(70, 2.0, seed=1400)
+    bits, its, conv = dec.decode_batch(llr.astype(np.float32), 50)
+    ob, oi, oc = oracle.decode_batch(c.graph, "tanh", 50, llr, nthreads=8)
+    assert np.array_equal(bits, ob) and np.array_equal(conv, oc)
+    z = np.zeros((2, c.N), np.float32)
+    z[1] = -3.0  # noiseless all-zero codeword
+    bits, its, conv = dec.decode_batch(z, 50)
+    assert its.tolist() == [0, 0] and conv.all() and not bits.any()
+    bits, its, conv = dec.decode_batch(llr[:3].astype(np.float32), 0)
+    assert np.array_equal(bits, (llr[:3] > 0).astype(np.uint8))
+    b1, it1, cv1 = dec.decode_one(llr[0], 50)
+    assert np.array_equal(b1, ob[0]) and it1 == oi[0]

@@ -22,7 +22,8 @@ def test_auto_path_is_fused_for_ar4ja_minsum(hip, name, dbs):
     assert hip.Decoder(c.hip_code(hip), "min", "f32", 8).path == "fused"
     assert hip.Decoder(c.hip_code(hip), "tanh", "f32", 8).path == "fused"
     assert hip.Decoder(c.hip_code(hip), "tanh", "f64", 8).path == "flood"
-    assert hip.Decoder(c.hip_code(hip, prefer_qc=False), "min", "f32", 8).path == "flood"  # CSR graph: no QC table
+    # a CSR graph has no QC table: generic on-chip kernel if a frame fits in LDS (jpl.1024), else flood (jpl.4096)
+    assert hip.Decoder(c.hip_code(hip, prefer_qc=False), "min", "f32", 8).path == ("fused" if name == "jpl.1024.4.5" else "flood")
     with pytest.raises(hip.LdpcError) as e:
         hip.Decoder(c.hip_code(hip), "tanh", "f64", 8, path="fused")
     assert e.value.code == -5

@@ -131,7 +131,7 @@ def test_standalone_mackay_matrix_record(hip):
     k = cols - rows, frames are all-zero codewords, decode works, encode says so."""
     ecc = hip.ECC(CODES, "ldpc/hip-tanh/1920.1280.3.303/50", max_batch=64)
     assert (ecc.message_length, ecc.codeword_length, ecc.unpunctured_length) == (640, 1920, 1920)
-    assert ecc.name == "ldpc/hip-tanh/1920.1280.3.303/50/1/3" and ecc.decoder.path == "flood"
+    assert ecc.name == "ldpc/hip-tanh/1920.1280.3.303/50/1/3" and ecc.decoder.path == "fused"
     c = load("1920.1280.3.303")
     _, llr = c.frames(8, 3.0, seed=31)
     for f in range(8):

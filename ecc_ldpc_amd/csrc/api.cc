@@ -283,10 +283,8 @@ ldpc_ctx *ldpc_ctx_create_ex(const ldpc_code *code_c, int variant, int dtype, in
     d.row_ptr = code->d_row_ptr; d.col_idx = code->d_col_idx; d.col_ptr = code->d_col_ptr; d.csc_edge = code->d_csc_edge;
     d.unsat = nullptr; d.iters = nullptr; d.conv = nullptr; d.done = nullptr;
     ctx->flood.variant = variant; ctx->flood.dtype = dtype; ctx->flood.timer = &ctx->timer;
-    CTX_HIP(hipMalloc((void **)&ctx->d_in, (size_t)max_batch * code->N * sizeof(double)));
-    CTX_HIP(hipMalloc((void **)&ctx->d_bits, (size_t)max_batch * code->N));
-    CTX_HIP(hipMalloc((void **)&ctx->d_iters, sizeof(int32_t) * (size_t)max_batch));
-    CTX_HIP(hipMalloc((void **)&ctx->d_conv, (size_t)max_batch));
+    // (the staging buffers of the host-pointer entry points are allocated on first use: a context driven
+    //  through ldpc_decode_batch_dev with 65 536 frames would otherwise park 3 GB of HBM)
     if (ctx->path == LDPC_PATH_FLOOD) {
         CTX_HIP(hipMalloc(&ctx->flood.msg, std::max<size_t>((size_t)code->E, 1) * Bp * es));
         // scratch is only touched by rows whose degree has no register kernel
@@ -353,6 +351,18 @@ static int decode_host(ldpc_ctx *ctx, int max_iters, int batch, const void *llr,
     const size_t N = (size_t)ctx->code->N;
     hipStream_t st = ctx->stream;
     double *d_final = nullptr, *d_trace = nullptr;
+    if (!ctx->d_in) {  // staging for host-pointer calls, sized for max_batch frames of float64 LLRs
+        const size_t mb = (size_t)ctx->max_batch;
+        hipError_t e = hipMalloc((void **)&ctx->d_in, mb * N * sizeof(double));
+        if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_bits, mb * N);
+        if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_iters, sizeof(int32_t) * mb);
+        if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_conv, mb);
+        if (e != hipSuccess) {
+            (void)hipFree(ctx->d_in); (void)hipFree(ctx->d_bits); (void)hipFree(ctx->d_iters); (void)hipFree(ctx->d_conv);
+            ctx->d_in = nullptr; ctx->d_bits = nullptr; ctx->d_iters = nullptr; ctx->d_conv = nullptr;
+            return set_error(LDPC_ENOMEM, "staging buffers for %zu frames: %s", mb, hipGetErrorString(e));
+        }
+    }
     HIPCHK(hipMemcpyAsync(ctx->d_in, llr, (size_t)batch * N * (is_f64 ? 8 : 4), hipMemcpyHostToDevice, st));
     if (final_lam) HIPCHK(hipMalloc((void **)&d_final, (size_t)batch * N * sizeof(double)));
     if (trace_lam) {

@@ -232,3 +232,7 @@ def cpu_baseline(args, ecc, llr_dev, gpu_value):
 
 if __name__ == "__main__":
     main()
+    # leave without interpreter/runtime teardown (two HIP clients in one process: see tests/conftest.py)
+    sys.stdout.flush()
+    sys.stderr.flush()
+    os._exit(0)

@@ -80,4 +80,7 @@ def main(argv=None):
 
 
 if __name__ == "__main__":
-    sys.exit(main())
+    rc = main()
+    sys.stdout.flush()
+    sys.stderr.flush()
+    os._exit(rc)  # skip runtime teardown (two HIP clients in one process; see tests/conftest.py)

@@ -49,3 +49,14 @@ def test_no_gpu_means_error_not_fallback():
     with pytest.raises(E.LdpcError) as e:
         E.Decoder(c, "min", "f32", 4)
     assert e.value.code == -4
+
+
+def test_header_is_c99_and_a_c_program_links(tmp_path):
+    import subprocess
+    exe = tmp_path / "abi_c_smoke"
+    src = os.path.join(ROOT, "tests", "abi_c_smoke.c")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"), src,
+                           "-o", str(exe), E.SO_PATH, "-Wl,-rpath," + os.path.dirname(E.SO_PATH), "-Wl,-rpath,/opt/rocm/lib"])
+    out = subprocess.run([str(exe)], cwd=ROOT, capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, (out.returncode, out.stdout, out.stderr)
+    assert out.stdout.strip().endswith("ok")

@@ -1,0 +1,90 @@
+"""GPU: random irregular parity-check matrices (row degrees 0..40, column degrees 0..many) through every
+path that accepts them, against the oracle.  Exercises the degree-generic code: flood.hip's re-read
+fallback for row weights outside {1..8,18}, fused_csr.hip's padded rows (classes 4/8/20/32) and the
+rejection rules (min-sum with a degree-1 row, rows above 32 edges on the on-chip kernel)."""
+import numpy as np
+import pytest
+
+from oracle import oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def random_h(rng, M, N, degrees):
+    H = np.zeros((M, N), np.uint8)
+    for m in range(M):
+        d = int(rng.choice(degrees))
+        H[m, rng.choice(N, size=min(d, N), replace=False)] = 1
+    return H
+
+
+def llrs(rng, F, N, scale):
+    x = rng.normal(1.5, scale, size=(F, N))  # mostly "bit 1" with noise: mixed converged / failed frames
+    return x.astype(np.float32).astype(np.float64)
+
+
+CASES = [
+    ("tiny mixed", 24, 40, [0, 2, 3, 4, 5, 6, 7, 8], 30),
+    ("mid degrees 9..20", 40, 96, [9, 10, 12, 15, 19, 20], 30),
+    ("high degrees 21..32", 30, 128, [21, 25, 32, 3], 25),
+    ("above 32 (flood only)", 20, 160, [33, 40, 4], 20),
+]
+
+
+@pytest.mark.parametrize("label,M,N,degs,iters", CASES)
+def test_minsum_f64_bit_exact_on_every_path(hip, label, M, N, degs, iters):
+    import zlib
+    rng = np.random.default_rng(zlib.crc32(label.encode()))
+    H = random_h(rng, M, N, degs)
+    g = oracle.Graph.from_dense(H)
+    x = llrs(rng, 20, N, 2.0)
+    code = hip.Code.from_dense(H)
+    paths = ["flood"] + (["fused"] if H.sum(1).max() <= 32 else [])
+    for path in paths:
+        dec = hip.Decoder(code, "min", "f64", len(x), path=path)
+        bits, its, conv, trace = dec.decode_trace(x, iters)
+        for f in range(len(x)):
+            o = oracle.decode(g, "min", iters, x[f], trace=True)
+            assert its[f] == o["iters"] and bool(conv[f]) == o["converged"], (label, path, f)
+            assert np.array_equal(bits[f], o["bits"])
+            assert np.array_equal(trace[f, : o["iters"] + 1], o["trace_lam"]), (label, path, f)
+    if H.sum(1).max() > 32:
+        with pytest.raises(hip.LdpcError) as e:
+            hip.Decoder(code, "min", "f64", 4, path="fused")
+        assert e.value.code == -5
+
+
+@pytest.mark.parametrize("label,M,N,degs,iters", CASES)
+@pytest.mark.parametrize("variant", ["min", "tanh"])
+def test_f32_bits_and_path_agreement(hip, label, M, N, degs, iters, variant):
+    import zlib
+    rng = np.random.default_rng(zlib.crc32(label.encode()) + 7)
+    H = random_h(rng, M, N, degs)
+    g = oracle.Graph.from_dense(H)
+    x = llrs(rng, 48, N, 2.5)
+    code = hip.Code.from_dense(H)
+    a = hip.Decoder(code, variant, "f32", len(x), path="flood").decode_batch(x.astype(np.float32), iters)
+    ob, oi, oc = oracle.decode_batch(g, variant, iters, x, nthreads=4)
+    assert np.array_equal(a[0], ob) and np.array_equal(a[2], oc)
+    if H.sum(1).max() <= 32:
+        b = hip.Decoder(code, variant, "f32", len(x), path="fused").decode_batch(x.astype(np.float32), iters)
+        assert all(np.array_equal(p, q) for p, q in zip(a, b))
+
+
+def test_tanh_f64_with_degree_one_rows(hip):
+    rng = np.random.default_rng(5)
+    H = random_h(rng, 16, 30, [1, 2, 3, 5, 8])  # degree-1 rows: product [] = 1 -> clamp (Orig.hs:86-91, Utils.hs:113-117)
+    assert (H.sum(1) == 1).any()
+    g = oracle.Graph.from_dense(H)
+    x = llrs(rng, 12, 30, 2.0)
+    code = hip.Code.from_dense(H)
+    for path in ("flood", "fused"):
+        dec = hip.Decoder(code, "tanh", "f64", len(x), path=path)
+        bits, its, conv, trace = dec.decode_trace(x, 15)
+        for f in range(len(x)):
+            o = oracle.decode(g, "tanh", 15, x[f], trace=True)
+            assert its[f] == o["iters"] and np.array_equal(bits[f], o["bits"])
+            assert np.allclose(trace[f, : o["iters"] + 1], o["trace_lam"], rtol=1e-9, atol=1e-9)
+    with pytest.raises(hip.LdpcError) as e:
+        hip.Decoder(code, "min", "f32", 4)
+    assert e.value.code == -6

@@ -22,6 +22,7 @@ ABI_SYMBOLS = [
     "ldpc_ctx_create", "ldpc_ctx_create_ex", "ldpc_ctx_destroy", "ldpc_ctx_path", "ldpc_ctx_synchronize",
     "ldpc_decode_one", "ldpc_decode_batch", "ldpc_decode_batch_f64", "ldpc_decode_batch_dev",
     "ldpc_debug_step", "ldpc_decode_trace",
+    "ldpc_host_alloc", "ldpc_host_free",
     "ldpc_ctx_set_timing", "ldpc_ctx_kernel_time", "ldpc_ctx_kernel_name",
     "ldpc_sim_create", "ldpc_sim_destroy", "ldpc_sim_generate", "ldpc_sim_tally", "ldpc_sim_encode_host",
     "ldpc_matrix_load", "ldpc_matrix_load_mackay", "ldpc_matrix_destroy", "ldpc_matrix_info", "ldpc_matrix_dense",
@@ -97,6 +98,10 @@ def lib():
     L.ldpc_decode_batch_dev.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp, vp, vp]
     L.ldpc_debug_step.argtypes = [vp, C.c_int, f64p, f64p, f64p, f64p, f64p, u8p]
     L.ldpc_decode_trace.argtypes = [vp, C.c_int, C.c_int, f64p, u8p, i32p, u8p, f64p]
+    L.ldpc_host_alloc.restype = vp
+    L.ldpc_host_alloc.argtypes = [C.c_size_t]
+    L.ldpc_host_free.restype = None
+    L.ldpc_host_free.argtypes = [vp]
     L.ldpc_ctx_set_timing.argtypes = [vp, C.c_int]
     L.ldpc_ctx_kernel_time.argtypes = [vp, ip, f64p]
     L.ldpc_ctx_kernel_name.restype = C.c_char_p
@@ -150,6 +155,27 @@ def check(rc):
 
 def ptr(a, ctype):
     return a.ctypes.data_as(C.POINTER(ctype)) if a is not None else None
+
+
+class PinnedArray:
+    """numpy view of page-locked host memory from ldpc_host_alloc (freed with the object)."""
+
+    def __init__(self, shape, dtype):
+        self.nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        self._p = lib().ldpc_host_alloc(self.nbytes)
+        if not self._p:
+            raise LdpcError(lib().ldpc_last_error_code(), last_error())
+        buf = (C.c_char * self.nbytes).from_address(self._p)
+        self.array = np.frombuffer(buf, dtype=dtype).reshape(shape)
+
+    def __del__(self):
+        try:
+            if self._p:
+                self.array = None
+                lib().ldpc_host_free(self._p)
+                self._p = None
+        except Exception:
+            pass
 
 
 def init(device: int = 0):
@@ -237,12 +263,13 @@ class Decoder:
         check(lib().ldpc_decode_one(self._h, int(max_iters), ptr(llr, C.c_double), ptr(bits, C.c_uint8), C.byref(it), C.byref(cv)))
         return bits, it.value, bool(cv.value)
 
-    def decode_batch(self, llr, max_iters, want_lam=False):
+    def decode_batch(self, llr, max_iters, want_lam=False, out_bits=None):
         """llr [F][N] float32 or float64 (host).  -> bits [F][N], iters [F], converged [F] (, lam)"""
         llr = np.asarray(llr)
         F = llr.shape[0]
         assert llr.shape == (F, self.code.N)
-        bits = np.zeros((F, self.code.N), np.uint8)
+        bits = out_bits if out_bits is not None else np.zeros((F, self.code.N), np.uint8)
+        assert bits.shape == (F, self.code.N) and bits.dtype == np.uint8 and bits.flags.c_contiguous
         iters = np.zeros(F, np.int32)
         conv = np.zeros(F, np.uint8)
         if llr.dtype == np.float32 and not want_lam:

@@ -46,10 +46,16 @@ struct ldpc_ctx {
     hipStream_t stream = nullptr;
     ldpc::FloodState flood;
     ldpc::FusedState *fused = nullptr;
-    void *d_in = nullptr;        // staging: [max_batch][N] float or double
-    uint8_t *d_bits = nullptr;   // [max_batch][N]
-    int32_t *d_iters = nullptr;  // fused path output staging [max_batch]
-    uint8_t *d_conv = nullptr;
+    // staging of the host-pointer entry points, allocated on first use.  Two slots so that the copy of
+    // chunk i+1 overlaps the decode of chunk i (fused paths are stateless on the device; the flood path
+    // keeps per-context BP state and uses slot 0 with the whole batch).
+    hipStream_t stream2 = nullptr;
+    int chunk = 0;
+    void *d_in[2] = {nullptr, nullptr};        // [chunk][N] float or double
+    uint8_t *d_bits[2] = {nullptr, nullptr};   // [chunk][N]
+    int32_t *d_iters[2] = {nullptr, nullptr};
+    uint8_t *d_conv[2] = {nullptr, nullptr};
+    double *d_final[2] = {nullptr, nullptr};   // [chunk][N], only when final LLRs are requested
     ldpc::KernelTimer timer;
 };
 
@@ -223,7 +229,9 @@ void ldpc_ctx_destroy(ldpc_ctx *ctx) {
     if (ctx->stream) hipStreamSynchronize(ctx->stream);
     hipFree(ctx->flood.msg); hipFree(ctx->flood.scratch); hipFree(ctx->flood.lam); hipFree(ctx->flood.orig);
     hipFree(ctx->flood.dev.unsat); hipFree(ctx->flood.dev.iters); hipFree(ctx->flood.dev.conv); hipFree(ctx->flood.dev.done);
-    hipFree(ctx->d_in); hipFree(ctx->d_bits); hipFree(ctx->d_iters); hipFree(ctx->d_conv);
+    if (ctx->stream2) hipStreamSynchronize(ctx->stream2);
+    for (int i = 0; i < 2; i++) { hipFree(ctx->d_in[i]); hipFree(ctx->d_bits[i]); hipFree(ctx->d_iters[i]); hipFree(ctx->d_conv[i]); hipFree(ctx->d_final[i]); }
+    if (ctx->stream2) hipStreamDestroy(ctx->stream2);
     if (ctx->fused) ldpc::fused_destroy(ctx->fused);
     ctx->timer.destroy();
     if (ctx->stream) hipStreamDestroy(ctx->stream);
@@ -314,6 +322,14 @@ ldpc_ctx *ldpc_ctx_create(const ldpc_code *code, int variant, int dtype, int max
 
 int ldpc_ctx_path(const ldpc_ctx *ctx) { return ctx ? ctx->path : set_error(LDPC_EINVAL, "null ctx"); }
 
+void *ldpc_host_alloc(size_t bytes) {
+    void *p = nullptr;
+    hipError_t e = hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault);
+    if (e != hipSuccess) { set_error(LDPC_ENOMEM, "hipHostMalloc(%zu): %s", bytes, hipGetErrorString(e)); return nullptr; }
+    return p;
+}
+void ldpc_host_free(void *p) { if (p) (void)hipHostFree(p); }
+
 int ldpc_ctx_synchronize(ldpc_ctx *ctx) {
     if (!ctx) return set_error(LDPC_EINVAL, "null ctx");
     HIPCHK(hipStreamSynchronize(ctx->stream));
@@ -342,49 +358,78 @@ static int decode_dev(ldpc_ctx *ctx, hipStream_t st, int max_iters, int batch, c
     return LDPC_OK;
 }
 
+// frames per pipelined chunk of the host-pointer entry points (fused paths)
+static constexpr int kHostChunk = 8192;
+
+static int ensure_staging(ldpc_ctx *ctx, bool want_final) {
+    const size_t N = (size_t)ctx->code->N;
+    if (!ctx->d_in[0]) {
+        const bool pipelined = ctx->path == LDPC_PATH_FUSED && ctx->max_batch > kHostChunk;
+        ctx->chunk = pipelined ? kHostChunk : ctx->max_batch;
+        const int slots = pipelined ? 2 : 1;
+        hipError_t e = hipSuccess;
+        if (pipelined) e = hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking);
+        for (int i = 0; i < slots && e == hipSuccess; i++) {
+            const size_t c = (size_t)ctx->chunk;
+            e = hipMalloc(&ctx->d_in[i], c * N * sizeof(double));
+            if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_bits[i], c * N);
+            if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_iters[i], sizeof(int32_t) * c);
+            if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_conv[i], c);
+        }
+        if (e != hipSuccess) {
+            for (int i = 0; i < 2; i++) {
+                (void)hipFree(ctx->d_in[i]); (void)hipFree(ctx->d_bits[i]); (void)hipFree(ctx->d_iters[i]); (void)hipFree(ctx->d_conv[i]);
+                ctx->d_in[i] = nullptr; ctx->d_bits[i] = nullptr; ctx->d_iters[i] = nullptr; ctx->d_conv[i] = nullptr;
+            }
+            return set_error(LDPC_ENOMEM, "staging buffers for %d frames: %s", ctx->chunk, hipGetErrorString(e));
+        }
+    }
+    if (want_final)
+        for (int i = 0; i < (ctx->stream2 ? 2 : 1); i++)
+            if (!ctx->d_final[i]) HIPCHK(hipMalloc((void **)&ctx->d_final[i], (size_t)ctx->chunk * N * sizeof(double)));
+    return LDPC_OK;
+}
+
 static int decode_host(ldpc_ctx *ctx, int max_iters, int batch, const void *llr, int is_f64, uint8_t *bits,
                        int32_t *iters, uint8_t *converged, double *final_lam, double *trace_lam) {
     int rc = check_call(ctx, max_iters, batch);
     if (rc != LDPC_OK) return rc;
     if (batch == 0) return LDPC_OK;
     if (!llr || !bits) return set_error(LDPC_EINVAL, "null llr/bits");
-    const size_t N = (size_t)ctx->code->N;
-    hipStream_t st = ctx->stream;
-    double *d_final = nullptr, *d_trace = nullptr;
-    if (!ctx->d_in) {  // staging for host-pointer calls, sized for max_batch frames of float64 LLRs
-        const size_t mb = (size_t)ctx->max_batch;
-        hipError_t e = hipMalloc((void **)&ctx->d_in, mb * N * sizeof(double));
-        if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_bits, mb * N);
-        if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_iters, sizeof(int32_t) * mb);
-        if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_conv, mb);
-        if (e != hipSuccess) {
-            (void)hipFree(ctx->d_in); (void)hipFree(ctx->d_bits); (void)hipFree(ctx->d_iters); (void)hipFree(ctx->d_conv);
-            ctx->d_in = nullptr; ctx->d_bits = nullptr; ctx->d_iters = nullptr; ctx->d_conv = nullptr;
-            return set_error(LDPC_ENOMEM, "staging buffers for %zu frames: %s", mb, hipGetErrorString(e));
-        }
-    }
-    HIPCHK(hipMemcpyAsync(ctx->d_in, llr, (size_t)batch * N * (is_f64 ? 8 : 4), hipMemcpyHostToDevice, st));
-    if (final_lam) HIPCHK(hipMalloc((void **)&d_final, (size_t)batch * N * sizeof(double)));
-    if (trace_lam) {
-        size_t tb = (size_t)batch * (max_iters + 1) * N * sizeof(double);
+    if ((rc = ensure_staging(ctx, final_lam != nullptr)) != LDPC_OK) return rc;
+    const size_t N = (size_t)ctx->code->N, es = is_f64 ? 8 : 4;
+    double *d_trace = nullptr;
+    const size_t turns = (size_t)max_iters + 1;
+    if (trace_lam) {  // verification path: one device buffer for the whole batch
+        size_t tb = (size_t)batch * turns * N * sizeof(double);
         hipError_t e = hipMalloc((void **)&d_trace, tb);
-        if (e != hipSuccess) { hipFree(d_final); return set_error(LDPC_ENOMEM, "trace buffer of %zu bytes: %s", tb, hipGetErrorString(e)); }
-        hipMemsetAsync(d_trace, 0, tb, st);
+        if (e != hipSuccess) return set_error(LDPC_ENOMEM, "trace buffer of %zu bytes: %s", tb, hipGetErrorString(e));
+        (void)hipMemsetAsync(d_trace, 0, tb, ctx->stream);
+        (void)hipStreamSynchronize(ctx->stream);
     }
-    rc = decode_dev(ctx, st, max_iters, batch, ctx->d_in, is_f64, ctx->d_bits, ctx->d_iters, ctx->d_conv, d_final, d_trace);
-    if (rc == LDPC_OK) {
-        hipError_t e = hipMemcpyAsync(bits, ctx->d_bits, (size_t)batch * N, hipMemcpyDeviceToHost, st);
-        if (e == hipSuccess && iters) e = hipMemcpyAsync(iters, ctx->d_iters, sizeof(int32_t) * (size_t)batch, hipMemcpyDeviceToHost, st);
-        if (e == hipSuccess && converged) e = hipMemcpyAsync(converged, ctx->d_conv, (size_t)batch, hipMemcpyDeviceToHost, st);
-        if (e == hipSuccess && final_lam) e = hipMemcpyAsync(final_lam, d_final, (size_t)batch * N * sizeof(double), hipMemcpyDeviceToHost, st);
-        if (e == hipSuccess && trace_lam) e = hipMemcpyAsync(trace_lam, d_trace, (size_t)batch * (max_iters + 1) * N * sizeof(double), hipMemcpyDeviceToHost, st);
-        if (e == hipSuccess) e = hipStreamSynchronize(st);
-        if (e != hipSuccess) rc = set_error(LDPC_EHIP, "decode: %s", hipGetErrorString(e));
-    } else {
-        hipStreamSynchronize(st);
+    hipError_t e = hipSuccess;
+    int slot = 0;
+    for (int f0 = 0; f0 < batch && rc == LDPC_OK && e == hipSuccess; f0 += ctx->chunk, slot ^= (ctx->stream2 ? 1 : 0)) {
+        const int nb = std::min(ctx->chunk, batch - f0);
+        hipStream_t st = slot ? ctx->stream2 : ctx->stream;
+        // stream order protects the slot: this copy is queued behind the slot's previous D2H
+        e = hipMemcpyAsync(ctx->d_in[slot], (const char *)llr + (size_t)f0 * N * es, (size_t)nb * N * es, hipMemcpyHostToDevice, st);
+        if (e != hipSuccess) break;
+        rc = decode_dev(ctx, st, max_iters, nb, ctx->d_in[slot], is_f64, ctx->d_bits[slot], ctx->d_iters[slot], ctx->d_conv[slot],
+                        final_lam ? ctx->d_final[slot] : nullptr, d_trace ? d_trace + (size_t)f0 * turns * N : nullptr);
+        if (rc != LDPC_OK) break;
+        e = hipMemcpyAsync(bits + (size_t)f0 * N, ctx->d_bits[slot], (size_t)nb * N, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess && iters) e = hipMemcpyAsync(iters + f0, ctx->d_iters[slot], sizeof(int32_t) * (size_t)nb, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess && converged) e = hipMemcpyAsync(converged + f0, ctx->d_conv[slot], (size_t)nb, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess && final_lam) e = hipMemcpyAsync(final_lam + (size_t)f0 * N, ctx->d_final[slot], (size_t)nb * N * sizeof(double), hipMemcpyDeviceToHost, st);
     }
-    hipFree(d_final);
-    hipFree(d_trace);
+    hipError_t e1 = hipStreamSynchronize(ctx->stream);
+    hipError_t e2 = ctx->stream2 ? hipStreamSynchronize(ctx->stream2) : hipSuccess;
+    if (e == hipSuccess) e = e1 != hipSuccess ? e1 : e2;
+    if (rc == LDPC_OK && e == hipSuccess && trace_lam)
+        e = hipMemcpy(trace_lam, d_trace, (size_t)batch * turns * N * sizeof(double), hipMemcpyDeviceToHost);
+    if (rc == LDPC_OK && e != hipSuccess) rc = set_error(LDPC_EHIP, "decode: %s", hipGetErrorString(e));
+    (void)hipFree(d_trace);
     return rc;
 }
 

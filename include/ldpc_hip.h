@@ -121,6 +121,11 @@ int ldpc_decode_batch_f64(ldpc_ctx *ctx, int max_iters, int batch, const double 
  * d_llr on another stream must pass that stream here (or synchronise first). */
 int ldpc_decode_batch_dev(ldpc_ctx *ctx, int max_iters, int batch, const float *d_llr,
                           uint8_t *d_bits, int32_t *d_iters, uint8_t *d_converged, void *stream);
+/* page-locked host memory for the host-pointer entry points: with buffers from ldpc_host_alloc the chunked
+ * H2D / decode / D2H pipeline inside ldpc_decode_batch runs at PCIe speed instead of the pageable-copy
+ * rate (the reference pokes pageable Storable vectors, GPU/CUDA/Arraylet2.hs:158-159).  NULL on failure. */
+void *ldpc_host_alloc(size_t bytes);
+void ldpc_host_free(void *p);
 /* wait for everything enqueued on the context's stream */
 int ldpc_ctx_synchronize(ldpc_ctx *ctx);
 

@@ -208,3 +208,29 @@ def test_record_kernel_still_matches(hip, monkeypatch):
     monkeypatch.setenv("LDPC_FUSED_KERNEL", "rec")
     b = hip.Decoder(code, "min", "f32", len(llr), path="fused").decode_batch(llr, 50)
     assert all(np.array_equal(x, y) for x, y in zip(a, b))
+
+
+def test_concurrent_contexts_on_separate_streams(hip):
+    """Several decoder replicas (the reference's maxThreadCount > 1, Utils.hs:53) working at once on their
+    own streams must not disturb each other: fused kernels keep no per-context device state, the flood path
+    keeps it per context."""
+    import torch
+    c = load("jpl.1024.4.5")
+    dev = torch.device("cuda", 0)
+    code = c.hip_code(hip)
+    B = 512
+    jobs = []
+    for i, (variant, path) in enumerate([("min", "fused"), ("tanh", "fused"), ("min", "flood"), ("min", "fused")]):
+        _, llr = c.frames(B, 2.5 + 0.5 * i, seed=2000 + i)
+        x = torch.tensor(llr, dtype=torch.float32, device=dev)
+        jobs.append(dict(dec=hip.Decoder(code, variant, "f32", B, path=path), x=x, llr=llr, variant=variant,
+                         bits=torch.empty((B, c.N), dtype=torch.uint8, device=dev), it=torch.empty(B, dtype=torch.int32, device=dev),
+                         cv=torch.empty(B, dtype=torch.uint8, device=dev), stream=torch.cuda.Stream(device=dev)))
+    torch.cuda.synchronize()
+    for rep in range(3):  # interleave launches of all contexts
+        for j in jobs:
+            j["dec"].decode_batch_dev(j["x"].data_ptr(), j["bits"].data_ptr(), B, 50, j["it"].data_ptr(), j["cv"].data_ptr(), j["stream"].cuda_stream)
+    torch.cuda.synchronize()
+    for j in jobs:
+        ref = j["dec"].decode_batch(j["llr"].astype(np.float32), 50)  # same context, alone, host path
+        assert np.array_equal(j["bits"].cpu().numpy(), ref[0]) and np.array_equal(j["it"].cpu().numpy(), ref[1])

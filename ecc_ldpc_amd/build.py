@@ -9,7 +9,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libldpc_hip.so")
-SOURCES = ["api.cc", "host.cc", "flood.hip", "fused.hip", "fused_msg.hip", "fused_csr.hip", "sim.hip"]
+SOURCES = ["api.cc", "host.cc", "flood.hip", "fused.hip", "fused_msg.hip", "fused_split.hip", "fused_csr.hip", "sim.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-Wall", "-Wno-unused-function", "-Wno-unused-value",
          "-ffp-contract=off",  # parity: a*b+c must round twice, like the reference's Double/float_ty ops

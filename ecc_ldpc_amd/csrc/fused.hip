@@ -352,6 +352,7 @@ struct FusedState {
     int variant = 0, dtype = 0, max_batch = 0, sz = 0, M = 0, N = 0, E = 0;
     CsrState *csr = nullptr;  // set when the code has no QC plan: generic on-chip kernel (fused_csr.hip)
     int static_id = 0;    // compiled-in rotation table matching this code (0 = none: table-driven kernel)
+    bool use_split = false;  // four waves per frame, block rows split between wave pairs (fused_split.hip)
     bool use_msg = true;  // per-edge-message kernel (fused_msg.hip) vs compressed-record kernel (this file)
     KernelTimer *timer = nullptr;
     uint32_t *d_tab = nullptr;
@@ -451,6 +452,10 @@ FusedState *fused_create(const ldpc_code &c, int variant, int dtype, int max_bat
         const char *d = getenv("LDPC_FUSED_TABLE");  // LDPC_FUSED_TABLE=dyn forces the table-driven kernel
         s->static_id = (d && !strcmp(d, "dyn")) ? 0 : fused_msg_static_id(c.sz, rot.data(), bcv.data(), (int)rot.size());
     }
+    {   // LDPC_FUSED_KERNEL=msg keeps the two-wave kernel where the four-wave split kernel exists
+        const char *k = getenv("LDPC_FUSED_KERNEL");
+        s->use_split = s->use_msg && fused_split_has(variant, dtype, c.sz, s->static_id) && !(k && !strcmp(k, "msg"));
+    }
     for (int br = 0; br < c.block_rows; br++)
         for (int bc = 0; bc < c.block_cols; bc++) {
             int off = c.offsets[(size_t)br * c.block_cols + bc];
@@ -480,6 +485,7 @@ int fused_decode(FusedState &s, hipStream_t st, int max_iters, int batch, const 
     FusedArgs a{};
     a.tab = s.d_tab; a.llr = d_llr; a.llr_is_f64 = llr_is_f64; a.bits = d_bits; a.iters = d_iters; a.conv = d_conv;
     a.final_lam = d_final; a.trace = d_trace; a.batch = batch; a.max_iters = max_iters; a.step_mode = 0;
+    if (s.use_split) return fused_split_launch(s.variant, st, a, s.timer);
     if (s.use_msg) return fused_msg_launch(s.variant, s.dtype, s.sz, s.static_id, st, a, s.timer);
     return dispatch(s, st, a);
 }
@@ -541,6 +547,7 @@ int fused_step(FusedState &s, hipStream_t st, int batch, const double *d_orig, c
         FusedArgs a{};
         a.tab = s.d_tab; a.llr = d_orig; a.llr_is_f64 = 1; a.batch = batch; a.max_iters = 1; a.step_mode = 1;
         a.st_lam = d_lam; a.st_ne_in = d_ne; a.st_ne_out = d_ne_out; a.final_lam = d_lam_out; a.st_syn = d_syn;
+        if (s.use_split) return fused_split_launch(s.variant, st, a, nullptr);
         return fused_msg_launch(s.variant, s.dtype, s.sz, s.static_id, st, a, nullptr);
     }
     if (s.dtype == LDPC_F64) return step_typed<double>(s, st, batch, d_orig, d_lam, d_ne, d_ne_out, d_lam_out, d_syn);

@@ -105,4 +105,8 @@ bool fused_msg_has(int variant, int dtype, int sz);
 int fused_msg_static_id(int sz, const uint16_t *rot, const uint8_t *bc, int nedge);
 int fused_msg_launch(int variant, int dtype, int sz, int static_id, hipStream_t st, FusedArgs &a, KernelTimer *timer);
 
+// four-wave variant with the block rows split between two wave pairs (fused_split.hip)
+bool fused_split_has(int variant, int dtype, int sz, int static_id);
+int fused_split_launch(int variant, hipStream_t st, FusedArgs &a, KernelTimer *timer);
+
 }  // namespace ldpc

@@ -1,0 +1,287 @@
+// fused_split.hip -- per-edge-message fused kernel with a frame's BLOCK ROWS split between two wave pairs.
+//
+// fused_msg.hip keeps all 156 messages of a thread's circulant row in VGPRs: 256 VGPRs, 2 waves per SIMD,
+// and with only two waves per SIMD ~47 % of the VALU issue slots stay empty while waves sit in LDS round
+// trips and barriers (profiles/r01_fused_v2_f32_minsum_pmc.json).  Here a frame (sz = 128) is owned by
+// FOUR waves: pair 0 (threads 0..127) holds the even block rows, pair 1 (threads 128..255) the odd ones,
+// thread (pair, r) = row r of every circulant of its pair's block rows.  78 messages + <= 24 channel-LLR
+// registers per thread -> 128 VGPRs -> 4 waves per SIMD, 16 waves per CU (4 frames, as before).
+// No cross-lane combine is needed (a check row is still handled by one thread) and the graph stays a
+// compile-time table; the two pairs run different straight-line code behind one wave-uniform branch, so
+// the total code size is unchanged.
+//
+// Phase B keeps the column "rounds" of fused_msg.hip (round q = q-th contribution of every block column
+// in descending row order = Orig.hs:96 per column): in a round each pair adds the edges it owns; all
+// targets of a round are distinct columns; one s_barrier (4 waves) per round.  Even/odd ownership makes
+// consecutive contributions of a column alternate between the pairs, which balances the rounds.
+#include "fused_rows.h"
+
+#ifndef SPLIT_ORIG_REGS
+#define SPLIT_ORIG_REGS 1
+#endif
+#ifndef SPLIT_WAVES_PER_EU
+#define SPLIT_WAVES_PER_EU 4
+#endif
+
+namespace ldpc {
+
+// ownership and per-pair register slots, all compile time
+template <class Plan, class T>
+struct Split {
+    static constexpr int br_of(int e) {
+        int br = 0;
+        for (int b = 0; b < Plan::NBR; b++) if (Plan::ebeg(b) <= e) br = b;
+        return br;
+    }
+    static constexpr int owner_br(int br) { return br & 1; }
+    static constexpr int owner(int e) { return owner_br(br_of(e)); }
+    static constexpr int slot(int e) {  // index of e among its owner's edges, plan order
+        int c = 0;
+        for (int j = 0; j < e; j++) c += owner(j) == owner(e) ? 1 : 0;
+        return c;
+    }
+    static constexpr int nmsg(int p) {
+        int c = 0;
+        for (int e = 0; e < T::NEDGE; e++) c += owner(e) == p ? 1 : 0;
+        return c;
+    }
+    static constexpr int NMSG = nmsg(0) > nmsg(1) ? nmsg(0) : nmsg(1);
+    // channel LLR of the column a thread writes in round 0 of block column bc: held by the owner of that edge
+    static constexpr int oowner(int bc) { return owner(Rounds<T>::round0_edge(bc)); }
+    static constexpr int oslot(int bc) {
+        int c = 0;
+        for (int j = 0; j < bc; j++) c += oowner(j) == oowner(bc) ? 1 : 0;
+        return c;
+    }
+    static constexpr int norig(int p) {
+        int c = 0;
+        for (int bc = 0; bc < T::NBC; bc++) c += oowner(bc) == p ? 1 : 0;
+        return c;
+    }
+    static constexpr int NORIG = norig(0) > norig(1) ? norig(0) : norig(1);
+    // edges of round q owned by pair p, highest edge index first
+    static constexpr int count(int q, int p) {
+        int c = 0;
+        for (int e = 0; e < T::NEDGE; e++) c += (Rounds<T>::round_of(e) == q && owner(e) == p) ? 1 : 0;
+        return c;
+    }
+    static constexpr int nth(int q, int p, int i) {
+        int c = 0;
+        for (int e = T::NEDGE - 1; e >= 0; e--)
+            if (Rounds<T>::round_of(e) == q && owner(e) == p) { if (c == i) return e; c++; }
+        return -1;
+    }
+};
+
+template <typename CT, int SZ, class Plan, class T, int P, int Q, int I0, int I1>
+__device__ __forceinline__ void split_round_chunk(char *lds, uint32_t p4, uint32_t vmask, const CT *msg, const CT *orig_rot, const float *gllr, uint32_t r0) {
+    using S = Split<Plan, T>;
+    constexpr uint32_t ES = sizeof(CT);
+    asm volatile("" : "+v"(p4));
+    if constexpr (Q == 0) {
+        static_for<I0, I1>([&](auto ic) {
+            // (constexpr VARIABLES: a constexpr function call in a subscript is not a constant expression and was
+            //  left as a run-time loop, which kept msg[] in scratch memory)
+            constexpr int e = S::nth(Q, P, decltype(ic)::value);
+            constexpr int ms = S::slot(e), os = S::oslot(T::bc[e]);
+            CT o;
+            if constexpr (SPLIT_ORIG_REGS) o = orig_rot[os]; else o = (CT)gllr[T::bc[e] * SZ + ((r0 + T::rot[e]) & (SZ - 1))];
+            lds_st<CT>(lds + T::bc[e] * SZ * ES, (p4 + T::rot[e] * ES) & vmask, msg[ms] + o);
+        });
+        return;
+    }
+    CT cur[I1 - I0];
+    uint32_t adr[I1 - I0];
+    static_for<I0, I1>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        constexpr int e = S::nth(Q, P, i);
+        adr[i - I0] = (p4 + T::rot[e] * ES) & vmask;
+        cur[i - I0] = lds_ld<CT>(lds + T::bc[e] * SZ * ES, adr[i - I0]);
+    });
+    static_for<I0, I1>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        constexpr int e = S::nth(Q, P, i);
+        constexpr int ms = S::slot(e);
+        lds_st<CT>(lds + T::bc[e] * SZ * ES, adr[i - I0], msg[ms] + cur[i - I0]);
+    });
+    asm volatile("" ::: "memory");
+}
+template <typename CT, int SZ, class Plan, class T, int P, int Q, int I0>
+__device__ __forceinline__ void split_round(char *lds, uint32_t p4, uint32_t vmask, const CT *msg, const CT *orig_rot, const float *gllr, uint32_t r0) {
+    constexpr int CNT = Split<Plan, T>::count(Q, P), CH = 8;
+    if constexpr (I0 < CNT) {
+        split_round_chunk<CT, SZ, Plan, T, P, Q, I0, (I0 + CH < CNT ? I0 + CH : CNT)>(lds, p4, vmask, msg, orig_rot, gllr, r0);
+        split_round<CT, SZ, Plan, T, P, Q, I0 + CH>(lds, p4, vmask, msg, orig_rot, gllr, r0);
+    }
+}
+
+// The whole decode of one pair: P is a compile-time constant, so every ownership test below is resolved
+// at compile time and the two pairs are two independent straight-line programs (one wave-uniform branch
+// in the kernel).  Keeping them as separate regions matters for the register allocator: with both pairs'
+// code merged in one loop body the 105 loop-carried registers met in phi nodes at every branch merge and
+// were spilled wholesale.
+template <typename CT, int VARIANT, class Plan, int SZ, class T, int P>
+__device__ __forceinline__ void split_body(const FusedArgs &A, char *lds, const uint32_t tid) {
+    using S = Split<Plan, T>;
+    constexpr int N = Plan::NBC * SZ, THREADS = 2 * SZ, NW = THREADS / 64;
+    constexpr uint32_t ES = sizeof(CT), vmask = SZ * ES - 1;
+    constexpr int LAM_BYTES = Plan::NBC * SZ * (int)ES;
+    const uint32_t r0 = tid & (SZ - 1);
+    const long long frame = blockIdx.x;
+    const uint32_t p4 = r0 * ES;
+    const size_t fN = (size_t)frame * N, fE = (size_t)frame * Plan::NEDGE * SZ;
+    auto llr_at = [&](size_t gi) -> CT {
+        return A.llr_is_f64 ? (CT) reinterpret_cast<const double *>(A.llr)[gi] : (CT) reinterpret_cast<const float *>(A.llr)[gi];
+    };
+
+    // ---- lam <- LLRs (or the given lam): pair P fills the block columns bc with bc % 2 == P
+    static_for<0, Plan::NBC>([&](auto bcc) {
+        constexpr int bc = decltype(bcc)::value;
+        if constexpr ((bc & 1) == P) {
+            CT v = A.step_mode ? (CT)A.st_lam[fN + bc * SZ + r0] : llr_at(fN + bc * SZ + r0);
+            lds_st<CT>(lds, p4 | (bc * SZ * ES), v);
+        }
+    });
+    // ---- messages (own block rows) and round-0 channel LLRs (own round-0 edges)
+    CT msg[S::NMSG];
+    CT orig[SPLIT_ORIG_REGS ? S::NORIG : 1];
+#pragma unroll
+    for (int i = 0; i < S::NMSG; i++) msg[i] = CT(0);  // Orig.hs:64-65
+#pragma unroll
+    for (int i = 0; i < (SPLIT_ORIG_REGS ? S::NORIG : 1); i++) orig[i] = CT(0);
+    static_for<0, Plan::NBC>([&](auto bcc) {
+        constexpr int bc = decltype(bcc)::value;
+        if constexpr (SPLIT_ORIG_REGS && S::oowner(bc) == P) {
+            constexpr int e0 = Rounds<T>::round0_edge(bc);
+            constexpr int os = S::oslot(bc);
+            orig[os] = llr_at(fN + bc * SZ + ((r0 + T::rot[e0]) & (SZ - 1)));
+        }
+    });
+    if (A.step_mode) {
+        static_for<0, Plan::NBR>([&](auto brc) {
+            constexpr int br = decltype(brc)::value;
+            if constexpr (S::owner_br(br) == P) {
+                constexpr int D = Plan::deg(br);
+                static_for<0, D>([&](auto kc) {
+                    constexpr int k = decltype(kc)::value;
+                    constexpr int ms = S::slot(Plan::ebeg(br) + k);
+                    msg[ms] = (CT)A.st_ne_in[fE + (size_t)SZ * Plan::ebeg(br) + (size_t)D * r0 + k];
+                });
+            }
+        });
+    }
+    __syncthreads();
+
+    volatile uint32_t *flags = reinterpret_cast<volatile uint32_t *>(lds + LAM_BYTES);
+    bool active = true, converged = false;
+    int n_done = 0;
+    const int turns = A.step_mode ? 1 : A.max_iters;
+
+    for (int n = 0;; n++) {
+        if (!active) break;
+        if (A.trace) {
+            static_for<0, Plan::NBC>([&](auto bcc) {
+                constexpr int bc = decltype(bcc)::value;
+                if constexpr ((bc & 1) == P)
+                    A.trace[((size_t)frame * (A.max_iters + 1) + n) * N + bc * SZ + r0] = (double)lds_ld<CT>(lds, p4 | (bc * SZ * ES));
+            });
+        }
+        const bool last = (n >= turns);
+        // ---- phase A over the pair's block rows
+        bool unsat = false;
+        static_for<0, Plan::NBR>([&](auto brc) {
+            constexpr int br = decltype(brc)::value;
+            if constexpr (S::owner_br(br) == P) {
+                constexpr int D = Plan::deg(br), ms0 = S::slot(Plan::ebeg(br));
+                StatRow<CT, SZ, T, Plan::ebeg(br)> row;
+                if (last) unsat |= rows_a<CT, VARIANT, D, 1, 0, true>(lds, row, p4, vmask, (CT *)nullptr);
+                else unsat |= rows_a<CT, VARIANT, D, 1, 0, false>(lds, row, p4, vmask, &msg[ms0]);
+            }
+        });
+        const bool wave_unsat = __ballot(unsat) != 0ull;
+        if ((tid & 63) == 0) flags[tid >> 6] = wave_unsat ? 1u : 0u;
+        __syncthreads();  // syndrome OR over the frame's four waves; also fences phase A reads from phase B writes
+        bool frame_unsat = false;
+#pragma unroll
+        for (int w = 0; w < NW; w++) frame_unsat |= flags[w] != 0u;
+        if (A.step_mode) {
+            if (tid == 0) A.st_syn[frame] = frame_unsat ? 0 : 1;
+        } else if (!frame_unsat) {  // Orig.hs:69
+            converged = true; active = false; n_done = n;
+        }
+        if (last) {  // Orig.hs:70
+            if (active) { active = false; n_done = n; }
+            break;
+        }
+        if (active) {
+            static_for<0, Rounds<T>::num_rounds()>([&](auto qc) {
+                split_round<CT, SZ, Plan, T, P, decltype(qc)::value, 0>(lds, p4, vmask, msg, orig, reinterpret_cast<const float *>(A.llr) + fN, r0);
+                __syncthreads();  // the next round adds into the same columns (all four waves)
+            });
+        }
+        if (A.step_mode) break;
+    }
+
+    if (A.step_mode) {
+        static_for<0, Plan::NBC>([&](auto bcc) {
+            constexpr int bc = decltype(bcc)::value;
+            if constexpr ((bc & 1) == P) A.final_lam[fN + bc * SZ + r0] = (double)lds_ld<CT>(lds, p4 | (bc * SZ * ES));
+        });
+        static_for<0, Plan::NBR>([&](auto brc) {
+            constexpr int br = decltype(brc)::value;
+            if constexpr (S::owner_br(br) == P) {
+                constexpr int D = Plan::deg(br);
+                static_for<0, D>([&](auto kc) {
+                    constexpr int k = decltype(kc)::value;
+                    constexpr int ms = S::slot(Plan::ebeg(br) + k);
+                    A.st_ne_out[fE + (size_t)SZ * Plan::ebeg(br) + (size_t)D * r0 + k] = (double)msg[ms];
+                });
+            }
+        });
+        return;
+    }
+    // ---- result: hard(lam) for a converged frame, hard(channel LLR) otherwise (Orig.hs:59,69-70)
+    static_for<0, Plan::NBC>([&](auto bcc) {
+        constexpr int bc = decltype(bcc)::value;
+        if constexpr ((bc & 1) == P) {
+            size_t gi = fN + bc * SZ + r0;
+            CT v = converged ? lds_ld<CT>(lds, p4 | (bc * SZ * ES)) : llr_at(gi);
+            A.bits[gi] = v > CT(0) ? 1 : 0;
+            if (A.final_lam) A.final_lam[gi] = (double)v;
+        }
+    });
+    if (tid == 0) {
+        if (A.iters) A.iters[frame] = n_done;
+        if (A.conv) A.conv[frame] = converged ? 1 : 0;
+    }
+}
+
+template <typename CT, int VARIANT, class Plan, int SZ, class T>
+__global__ __launch_bounds__(2 * SZ, SPLIT_WAVES_PER_EU) void fused_split_kernel(FusedArgs A) {
+    static_assert(SZ >= 64 && (SZ & (SZ - 1)) == 0, "one thread per circulant row and pair");
+    constexpr int NW = 2 * SZ / 64;
+    __shared__ __attribute__((aligned(16))) char lds[Plan::NBC * SZ * (int)sizeof(CT) + 4 * NW];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t pair = __builtin_amdgcn_readfirstlane(tid / SZ);  // wave-uniform
+    // both programs execute the same number of barriers (same loop structure and round count)
+    if (pair == 0) split_body<CT, VARIANT, Plan, SZ, T, 0>(A, lds, tid);
+    else split_body<CT, VARIANT, Plan, SZ, T, 1>(A, lds, tid);
+}
+
+bool fused_split_has(int variant, int dtype, int sz, int static_id) {
+    return dtype == LDPC_F32 && sz == 128 && static_id == 2 && (variant == LDPC_MINSUM || variant == LDPC_TANH);
+}
+
+int fused_split_launch(int variant, hipStream_t st, FusedArgs &a, KernelTimer *timer) {
+    if (timer && !a.step_mode) timer->begin(st);
+    if (variant == LDPC_MINSUM)
+        hipLaunchKernelGGL((fused_split_kernel<float, LDPC_V_MINSUM, PlanAR4JA45, 128, TabJpl4096>), dim3(a.batch), dim3(256), 0, st, a);
+    else
+        hipLaunchKernelGGL((fused_split_kernel<float, LDPC_V_TANH, PlanAR4JA45, 128, TabJpl4096>), dim3(a.batch), dim3(256), 0, st, a);
+    if (timer && !a.step_mode) timer->end(st);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return set_error(LDPC_EHIP, "fused_split launch: %s", hipGetErrorString(e));
+    return LDPC_OK;
+}
+
+}  // namespace ldpc

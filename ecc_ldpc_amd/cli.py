@@ -80,7 +80,4 @@ def main(argv=None):
 
 
 if __name__ == "__main__":
-    rc = main()
-    sys.stdout.flush()
-    sys.stderr.flush()
-    os._exit(rc)  # skip runtime teardown (two HIP clients in one process; see tests/conftest.py)
+    sys.exit(main())

@@ -176,11 +176,14 @@ def measured_traffic(args, dec, B):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
     (profiles/*_pmc.json: FETCH_SIZE and WRITE_SIZE collected in separate --pmc runs of this same
     command), scaled by frames per launch; None when no profile of this configuration is committed."""
-    if not (dec.path == "fused" and args.code == "jpl.4096.4.5" and args.variant == "minsum" and args.dtype == "f32"):
+    if not (dec.path == "fused" and args.variant == "minsum" and args.dtype == "f32"):
+        return None
+    tag = {"jpl.4096.4.5": "r01_split2_jpl4096_f32_minsum", "jpl.1024.4.5": "r01_split2_jpl1024_f32_minsum"}.get(args.code)
+    if tag is None:
         return None
     try:
-        prof = json.load(open(os.path.join(ROOT, "profiles", "r01_fused_split_f32_minsum_pmc.json")))
-        h = prof["hbm_bytes_per_launch"]
+        prof = json.load(open(os.path.join(ROOT, "profiles", tag + "_pmc.json")))
+        h = prof["hbm_bytes_per_launch"]   # collected at 65536 frames per launch (tools/profile.sh)
         return int((h["FETCH_SIZE_raw_bytes"] + h["WRITE_SIZE_bytes"]) * B / 65536)
     except Exception:
         return None

@@ -519,7 +519,8 @@ int ldpc_ctx_kernel_time(ldpc_ctx *ctx, int *launches, double *total_ms) {
 
 const char *ldpc_ctx_kernel_name(const ldpc_ctx *ctx) {
     if (!ctx) return "";
-    return ctx->path == LDPC_PATH_FUSED ? "fused_" : "flood_cn_kernel";  // fused_msg_kernel / fused_decode_kernel
+    if (ctx->path == LDPC_PATH_FUSED && ctx->fused) return ldpc::fused_kernel_name(*ctx->fused);
+    return "flood_cn_kernel";
 }
 
 // ------------------------------------------------------------------------------- frame source

@@ -18,6 +18,9 @@ int fused_decode(FusedState &s, hipStream_t st, int max_iters, int batch, const 
 int fused_step(FusedState &s, hipStream_t st, int batch, const double *d_orig, const double *d_lam,
                const double *d_ne, double *d_ne_out, double *d_lam_out, uint8_t *d_syn);
 
+// name of the kernel fused_decode launches for this state (as rocprofv3 lists it, without template arguments)
+const char *fused_kernel_name(const FusedState &s);
+
 // generic on-chip kernel for any H that fits in LDS (fused_csr.hip); reached through the functions above
 struct CsrState;
 const char *fused_csr_why_not(const ldpc_code &code, int variant, int dtype);

@@ -479,13 +479,20 @@ void fused_destroy(FusedState *s) {
 
 void fused_set_timer(FusedState *s, KernelTimer *t) { if (s) { s->timer = t; fused_csr_set_timer(s->csr, t); } }
 
+const char *fused_kernel_name(const FusedState &s) {
+    if (s.csr) return "fused_csr_kernel";
+    if (s.use_split) return "fused_split_kernel";
+    if (s.use_msg) return "fused_msg_kernel";
+    return "fused_decode_kernel";
+}
+
 int fused_decode(FusedState &s, hipStream_t st, int max_iters, int batch, const void *d_llr, int llr_is_f64, uint8_t *d_bits,
                  int32_t *d_iters, uint8_t *d_conv, double *d_final, double *d_trace) {
     if (s.csr) return fused_csr_decode(*s.csr, st, max_iters, batch, d_llr, llr_is_f64, d_bits, d_iters, d_conv, d_final, d_trace);
     FusedArgs a{};
     a.tab = s.d_tab; a.llr = d_llr; a.llr_is_f64 = llr_is_f64; a.bits = d_bits; a.iters = d_iters; a.conv = d_conv;
     a.final_lam = d_final; a.trace = d_trace; a.batch = batch; a.max_iters = max_iters; a.step_mode = 0;
-    if (s.use_split) return fused_split_launch(s.variant, st, a, s.timer);
+    if (s.use_split) return fused_split_launch(s.variant, s.sz, st, a, s.timer);
     if (s.use_msg) return fused_msg_launch(s.variant, s.dtype, s.sz, s.static_id, st, a, s.timer);
     return dispatch(s, st, a);
 }
@@ -547,7 +554,7 @@ int fused_step(FusedState &s, hipStream_t st, int batch, const double *d_orig, c
         FusedArgs a{};
         a.tab = s.d_tab; a.llr = d_orig; a.llr_is_f64 = 1; a.batch = batch; a.max_iters = 1; a.step_mode = 1;
         a.st_lam = d_lam; a.st_ne_in = d_ne; a.st_ne_out = d_ne_out; a.final_lam = d_lam_out; a.st_syn = d_syn;
-        if (s.use_split) return fused_split_launch(s.variant, st, a, nullptr);
+        if (s.use_split) return fused_split_launch(s.variant, s.sz, st, a, nullptr);
         return fused_msg_launch(s.variant, s.dtype, s.sz, s.static_id, st, a, nullptr);
     }
     if (s.dtype == LDPC_F64) return step_typed<double>(s, st, batch, d_orig, d_lam, d_ne, d_ne_out, d_lam_out, d_syn);

@@ -107,6 +107,6 @@ int fused_msg_launch(int variant, int dtype, int sz, int static_id, hipStream_t 
 
 // four-wave variant with the block rows split between two wave pairs (fused_split.hip)
 bool fused_split_has(int variant, int dtype, int sz, int static_id);
-int fused_split_launch(int variant, hipStream_t st, FusedArgs &a, KernelTimer *timer);
+int fused_split_launch(int variant, int sz, hipStream_t st, FusedArgs &a, KernelTimer *timer);
 
 }  // namespace ldpc

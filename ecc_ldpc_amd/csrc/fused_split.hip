@@ -6,6 +6,8 @@
 // FOUR waves: pair 0 (threads 0..127) holds the even block rows, pair 1 (threads 128..255) the odd ones,
 // thread (pair, r) = row r of every circulant of its pair's block rows.  78 messages + <= 24 channel-LLR
 // registers per thread -> 128 VGPRs -> 4 waves per SIMD, 16 waves per CU (4 frames, as before).
+// For sz < 64 a workgroup holds 64/sz frames interleaved lane by lane (sz = 32: wave 0 = pair 0 and wave 1 =
+// pair 1 of two frames); loop control then runs on a workgroup-uniform "done" mask, see split_body.
 // No cross-lane combine is needed (a check row is still handled by one thread) and the graph stays a
 // compile-time table; the two pairs run different straight-line code behind one wave-uniform branch, so
 // the total code size is unchanged.
@@ -76,7 +78,7 @@ struct Split {
 template <typename CT, int SZ, class Plan, class T, int P, int Q, int I0, int I1>
 __device__ __forceinline__ void split_round_chunk(char *lds, uint32_t p4, uint32_t vmask, const CT *msg, const CT *orig_rot, const float *gllr, uint32_t r0) {
     using S = Split<Plan, T>;
-    constexpr uint32_t ES = sizeof(CT);
+    constexpr uint32_t ES = sizeof(CT), CPW = SZ >= 64 ? 1 : 64 / SZ, V = SZ * CPW;
     asm volatile("" : "+v"(p4));
     if constexpr (Q == 0) {
         static_for<I0, I1>([&](auto ic) {
@@ -86,7 +88,7 @@ __device__ __forceinline__ void split_round_chunk(char *lds, uint32_t p4, uint32
             constexpr int ms = S::slot(e), os = S::oslot(T::bc[e]);
             CT o;
             if constexpr (SPLIT_ORIG_REGS) o = orig_rot[os]; else o = (CT)gllr[T::bc[e] * SZ + ((r0 + T::rot[e]) & (SZ - 1))];
-            lds_st<CT>(lds + T::bc[e] * SZ * ES, (p4 + T::rot[e] * ES) & vmask, msg[ms] + o);
+            lds_st<CT>(lds + T::bc[e] * V * ES, (p4 + T::rot[e] * CPW * ES) & vmask, msg[ms] + o);
         });
         return;
     }
@@ -95,14 +97,14 @@ __device__ __forceinline__ void split_round_chunk(char *lds, uint32_t p4, uint32
     static_for<I0, I1>([&](auto ic) {
         constexpr int i = decltype(ic)::value;
         constexpr int e = S::nth(Q, P, i);
-        adr[i - I0] = (p4 + T::rot[e] * ES) & vmask;
-        cur[i - I0] = lds_ld<CT>(lds + T::bc[e] * SZ * ES, adr[i - I0]);
+        adr[i - I0] = (p4 + T::rot[e] * CPW * ES) & vmask;
+        cur[i - I0] = lds_ld<CT>(lds + T::bc[e] * V * ES, adr[i - I0]);
     });
     static_for<I0, I1>([&](auto ic) {
         constexpr int i = decltype(ic)::value;
         constexpr int e = S::nth(Q, P, i);
         constexpr int ms = S::slot(e);
-        lds_st<CT>(lds + T::bc[e] * SZ * ES, adr[i - I0], msg[ms] + cur[i - I0]);
+        lds_st<CT>(lds + T::bc[e] * V * ES, adr[i - I0], msg[ms] + cur[i - I0]);
     });
     asm volatile("" ::: "memory");
 }
@@ -123,13 +125,30 @@ __device__ __forceinline__ void split_round(char *lds, uint32_t p4, uint32_t vma
 template <typename CT, int VARIANT, class Plan, int SZ, class T, int P>
 __device__ __forceinline__ void split_body(const FusedArgs &A, char *lds, const uint32_t tid) {
     using S = Split<Plan, T>;
-    constexpr int N = Plan::NBC * SZ, THREADS = 2 * SZ, NW = THREADS / 64;
-    constexpr uint32_t ES = sizeof(CT), vmask = SZ * ES - 1;
-    constexpr int LAM_BYTES = Plan::NBC * SZ * (int)ES;
-    const uint32_t r0 = tid & (SZ - 1);
-    const long long frame = blockIdx.x;
-    const uint32_t p4 = r0 * ES;
-    const size_t fN = (size_t)frame * N, fE = (size_t)frame * Plan::NEDGE * SZ;
+    constexpr int CPW = SZ >= 64 ? 1 : 64 / SZ, V = SZ * CPW;  // frames per workgroup, threads per pair
+    constexpr int N = Plan::NBC * SZ, THREADS = 2 * V, NW = THREADS / 64;
+    constexpr uint32_t ES = sizeof(CT), vmask = V * ES - 1;
+    constexpr int LAM_BYTES = Plan::NBC * V * (int)ES;
+    // Only p4 (the lane's LDS byte offset inside a block column) lives across the iteration loop; everything else
+    // about the lane's place -- frame, row, global offsets -- is recomputed from it where needed (Where), so that
+    // it does not occupy registers next to the messages.
+    const uint32_t p4 = (tid & (V - 1)) * ES;
+    struct Where {
+        uint32_t sub, r0; long long frame; bool valid; size_t fN, fE;
+        __device__ __forceinline__ Where(uint32_t p, int batch) {
+            asm volatile("" : "+v"(p));            // keep the compiler from carrying these over from an earlier Where
+            const uint32_t lane = p / ES;          // position inside the pair
+            sub = lane % CPW;                      // frame inside the workgroup (frames interleave lane by lane)
+            r0 = lane / CPW;                       // circulant row / own column inside a block
+            frame = (long long)blockIdx.x * CPW + sub;
+            valid = frame < batch;
+            fN = (size_t)(valid ? frame : 0) * N;  // lanes of a frame past the batch shadow frame 0 and store nothing
+            fE = (size_t)(valid ? frame : 0) * Plan::NEDGE * SZ;
+        }
+    };
+    const Where w0(p4, A.batch);
+    const uint32_t r0 = w0.r0;
+    const size_t fN = w0.fN, fE = w0.fE;
     auto llr_at = [&](size_t gi) -> CT {
         return A.llr_is_f64 ? (CT) reinterpret_cast<const double *>(A.llr)[gi] : (CT) reinterpret_cast<const float *>(A.llr)[gi];
     };
@@ -139,7 +158,7 @@ __device__ __forceinline__ void split_body(const FusedArgs &A, char *lds, const 
         constexpr int bc = decltype(bcc)::value;
         if constexpr ((bc & 1) == P) {
             CT v = A.step_mode ? (CT)A.st_lam[fN + bc * SZ + r0] : llr_at(fN + bc * SZ + r0);
-            lds_st<CT>(lds, p4 | (bc * SZ * ES), v);
+            lds_st<CT>(lds, p4 | (bc * V * ES), v);
         }
     });
     // ---- messages (own block rows) and round-0 channel LLRs (own round-0 edges)
@@ -173,17 +192,28 @@ __device__ __forceinline__ void split_body(const FusedArgs &A, char *lds, const 
     __syncthreads();
 
     volatile uint32_t *flags = reinterpret_cast<volatile uint32_t *>(lds + LAM_BYTES);
-    bool active = true, converged = false;
-    int n_done = 0;
+    // done: bit s = frame s of this workgroup has finished.  Workgroup-uniform (derived from the shared flags), so
+    // loop control and barriers stay uniform with several frames.  A finished frame keeps its answer in `snap`;
+    // its lanes then keep computing on their own (disjoint) LDS columns until the workgroup's other frames are
+    // done -- masking them off instead makes every message register live across divergent control flow.
+    constexpr uint32_t FULL = (1u << CPW) - 1;
+    uint32_t done = 0;
+#pragma unroll
+    for (int s2 = 0; s2 < CPW; s2++) done |= ((long long)blockIdx.x * CPW + s2 < A.batch) ? 0u : (1u << s2);
+    // bits 0..21: hard(lam) of this lane's columns at the moment its frame converged; bit 22: converged;
+    // bits 23..: the iteration it converged at
+    static_assert(Plan::NBC <= 44, "result word layout");
+    uint32_t res = 0;
     const int turns = A.step_mode ? 1 : A.max_iters;
 
     for (int n = 0;; n++) {
-        if (!active) break;
-        if (A.trace) {
+        if (done == FULL) break;
+        if (A.trace && !((done >> ((p4 / ES) % CPW)) & 1u)) {
+            const Where w(p4, A.batch);
             static_for<0, Plan::NBC>([&](auto bcc) {
                 constexpr int bc = decltype(bcc)::value;
                 if constexpr ((bc & 1) == P)
-                    A.trace[((size_t)frame * (A.max_iters + 1) + n) * N + bc * SZ + r0] = (double)lds_ld<CT>(lds, p4 | (bc * SZ * ES));
+                    A.trace[((size_t)w.frame * (A.max_iters + 1) + n) * N + bc * SZ + w.r0] = (double)lds_ld<CT>(lds, p4 | (bc * V * ES));
             });
         }
         const bool last = (n >= turns);
@@ -198,34 +228,63 @@ __device__ __forceinline__ void split_body(const FusedArgs &A, char *lds, const 
                 else unsat |= rows_a<CT, VARIANT, D, 1, 0, false>(lds, row, p4, vmask, &msg[ms0]);
             }
         });
-        const bool wave_unsat = __ballot(unsat) != 0ull;
-        if ((tid & 63) == 0) flags[tid >> 6] = wave_unsat ? 1u : 0u;
-        __syncthreads();  // syndrome OR over the frame's four waves; also fences phase A reads from phase B writes
-        bool frame_unsat = false;
+        // per wave: bit s = some lane of frame s saw an odd row parity (frames interleave lane by lane)
+        const unsigned long long ub = __ballot(unsat);
+        uint32_t wbits = 0;
 #pragma unroll
-        for (int w = 0; w < NW; w++) frame_unsat |= flags[w] != 0u;
+        for (int s2 = 0; s2 < CPW; s2++) {
+            unsigned long long m = 0;
+            for (int i = 0; i < 64; i += CPW) m |= 1ull << i;
+            wbits |= ((ub & (m << s2)) != 0ull) ? (1u << s2) : 0u;
+        }
+        if ((tid & 63) == 0) flags[tid >> 6] = wbits;
+        __syncthreads();  // syndrome OR over the workgroup's waves; also fences phase A reads from phase B writes
+        uint32_t fbits = 0;
+#pragma unroll
+        for (int w = 0; w < NW; w++) fbits |= flags[w];
+        fbits = __builtin_amdgcn_readfirstlane(fbits);
         if (A.step_mode) {
-            if (tid == 0) A.st_syn[frame] = frame_unsat ? 0 : 1;
-        } else if (!frame_unsat) {  // Orig.hs:69
-            converged = true; active = false; n_done = n;
+            const Where w(p4, A.batch);
+            if (w.valid && w.r0 == 0 && P == 0) A.st_syn[w.frame] = ((fbits >> w.sub) & 1u) ? 0 : 1;
+        } else {
+            const uint32_t newly = ~fbits & ~done & FULL;  // Orig.hs:69: frames whose syndrome is zero now
+            if ((newly >> ((p4 / ES) % CPW)) & 1u) {
+                res = (1u << 22) | ((uint32_t)n << 23);
+                static_for<0, Plan::NBC>([&](auto bcc) {
+                    constexpr int bc = decltype(bcc)::value;
+                    if constexpr ((bc & 1) == P) {
+                        CT v = lds_ld<CT>(lds, p4 | (bc * V * ES));
+                        res |= (v > CT(0) ? 1u : 0u) << (bc >> 1);
+                    }
+                });
+                if (A.final_lam) {
+                    const Where w(p4, A.batch);
+                    static_for<0, Plan::NBC>([&](auto bcc) {
+                        constexpr int bc = decltype(bcc)::value;
+                        if constexpr ((bc & 1) == P) A.final_lam[w.fN + bc * SZ + w.r0] = (double)lds_ld<CT>(lds, p4 | (bc * V * ES));
+                    });
+                }
+            }
+            done |= newly;
+            // the snapshot read columns that the OTHER pair rewrites in round 0 when the workgroup goes on
+            if (CPW > 1 && newly != 0u && done != FULL) __syncthreads();
         }
-        if (last) {  // Orig.hs:70
-            if (active) { active = false; n_done = n; }
-            break;
-        }
-        if (active) {
+        if (last) break;  // Orig.hs:70
+        if (done != FULL) {
             static_for<0, Rounds<T>::num_rounds()>([&](auto qc) {
                 split_round<CT, SZ, Plan, T, P, decltype(qc)::value, 0>(lds, p4, vmask, msg, orig, reinterpret_cast<const float *>(A.llr) + fN, r0);
-                __syncthreads();  // the next round adds into the same columns (all four waves)
+                __syncthreads();  // the next round adds into the same columns
             });
         }
         if (A.step_mode) break;
     }
 
+    const Where w(p4, A.batch);
+    if (!w.valid) return;
     if (A.step_mode) {
         static_for<0, Plan::NBC>([&](auto bcc) {
             constexpr int bc = decltype(bcc)::value;
-            if constexpr ((bc & 1) == P) A.final_lam[fN + bc * SZ + r0] = (double)lds_ld<CT>(lds, p4 | (bc * SZ * ES));
+            if constexpr ((bc & 1) == P) A.final_lam[w.fN + bc * SZ + w.r0] = (double)lds_ld<CT>(lds, p4 | (bc * V * ES));
         });
         static_for<0, Plan::NBR>([&](auto brc) {
             constexpr int br = decltype(brc)::value;
@@ -234,50 +293,70 @@ __device__ __forceinline__ void split_body(const FusedArgs &A, char *lds, const 
                 static_for<0, D>([&](auto kc) {
                     constexpr int k = decltype(kc)::value;
                     constexpr int ms = S::slot(Plan::ebeg(br) + k);
-                    A.st_ne_out[fE + (size_t)SZ * Plan::ebeg(br) + (size_t)D * r0 + k] = (double)msg[ms];
+                    A.st_ne_out[w.fE + (size_t)SZ * Plan::ebeg(br) + (size_t)D * w.r0 + k] = (double)msg[ms];
                 });
             }
         });
         return;
     }
-    // ---- result: hard(lam) for a converged frame, hard(channel LLR) otherwise (Orig.hs:59,69-70)
+    // ---- result: hard(lam at convergence) for a converged frame, hard(channel LLR) otherwise (Orig.hs:59,69-70)
+    const bool converged = (res >> 22) & 1u;
     static_for<0, Plan::NBC>([&](auto bcc) {
         constexpr int bc = decltype(bcc)::value;
         if constexpr ((bc & 1) == P) {
-            size_t gi = fN + bc * SZ + r0;
-            CT v = converged ? lds_ld<CT>(lds, p4 | (bc * SZ * ES)) : llr_at(gi);
-            A.bits[gi] = v > CT(0) ? 1 : 0;
-            if (A.final_lam) A.final_lam[gi] = (double)v;
+            size_t gi = w.fN + bc * SZ + w.r0;
+            if (converged) {
+                A.bits[gi] = (res >> (bc >> 1)) & 1u;
+            } else {
+                CT v = llr_at(gi);
+                A.bits[gi] = v > CT(0) ? 1 : 0;
+                if (A.final_lam) A.final_lam[gi] = (double)v;
+            }
         }
     });
-    if (tid == 0) {
-        if (A.iters) A.iters[frame] = n_done;
-        if (A.conv) A.conv[frame] = converged ? 1 : 0;
+    if (w.r0 == 0 && P == 0) {
+        if (A.iters) A.iters[w.frame] = converged ? (int)(res >> 23) : turns;
+        if (A.conv) A.conv[w.frame] = converged ? 1 : 0;
     }
 }
 
+template <int SZ> struct SplitGeom {
+    static constexpr int CPW = SZ >= 64 ? 1 : 64 / SZ, V = SZ * CPW, THREADS = 2 * V, NW = THREADS / 64;
+};
+
 template <typename CT, int VARIANT, class Plan, int SZ, class T>
-__global__ __launch_bounds__(2 * SZ, SPLIT_WAVES_PER_EU) void fused_split_kernel(FusedArgs A) {
-    static_assert(SZ >= 64 && (SZ & (SZ - 1)) == 0, "one thread per circulant row and pair");
-    constexpr int NW = 2 * SZ / 64;
-    __shared__ __attribute__((aligned(16))) char lds[Plan::NBC * SZ * (int)sizeof(CT) + 4 * NW];
+__global__ __launch_bounds__((SplitGeom<SZ>::THREADS), SPLIT_WAVES_PER_EU) void fused_split_kernel(FusedArgs A) {
+    using G = SplitGeom<SZ>;
+    static_assert((SZ & (SZ - 1)) == 0 && SZ >= 16, "circulant size must be a power of two");
+    __shared__ __attribute__((aligned(16))) char lds[Plan::NBC * G::V * (int)sizeof(CT) + 4 * G::NW];
     const uint32_t tid = threadIdx.x;
-    const uint32_t pair = __builtin_amdgcn_readfirstlane(tid / SZ);  // wave-uniform
+    const uint32_t pair = __builtin_amdgcn_readfirstlane(tid / G::V);  // wave-uniform (V is a multiple of 64)
     // both programs execute the same number of barriers (same loop structure and round count)
     if (pair == 0) split_body<CT, VARIANT, Plan, SZ, T, 0>(A, lds, tid);
     else split_body<CT, VARIANT, Plan, SZ, T, 1>(A, lds, tid);
 }
 
 bool fused_split_has(int variant, int dtype, int sz, int static_id) {
-    return dtype == LDPC_F32 && sz == 128 && static_id == 2 && (variant == LDPC_MINSUM || variant == LDPC_TANH);
+    if (dtype != LDPC_F32 || !(variant == LDPC_MINSUM || variant == LDPC_TANH)) return false;
+    return (sz == 128 && static_id == 2) || (sz == 32 && static_id == 1);
 }
 
-int fused_split_launch(int variant, hipStream_t st, FusedArgs &a, KernelTimer *timer) {
+template <int VARIANT, int SZ, class T>
+static void launch_split(hipStream_t st, FusedArgs &a) {
+    using G = SplitGeom<SZ>;
+    const int grid = (a.batch + G::CPW - 1) / G::CPW;
+    hipLaunchKernelGGL((fused_split_kernel<float, VARIANT, PlanAR4JA45, SZ, T>), dim3(grid), dim3(G::THREADS), 0, st, a);
+}
+
+int fused_split_launch(int variant, int sz, hipStream_t st, FusedArgs &a, KernelTimer *timer) {
     if (timer && !a.step_mode) timer->begin(st);
-    if (variant == LDPC_MINSUM)
-        hipLaunchKernelGGL((fused_split_kernel<float, LDPC_V_MINSUM, PlanAR4JA45, 128, TabJpl4096>), dim3(a.batch), dim3(256), 0, st, a);
-    else
-        hipLaunchKernelGGL((fused_split_kernel<float, LDPC_V_TANH, PlanAR4JA45, 128, TabJpl4096>), dim3(a.batch), dim3(256), 0, st, a);
+    if (sz == 128) {
+        if (variant == LDPC_MINSUM) launch_split<LDPC_V_MINSUM, 128, TabJpl4096>(st, a);
+        else launch_split<LDPC_V_TANH, 128, TabJpl4096>(st, a);
+    } else {
+        if (variant == LDPC_MINSUM) launch_split<LDPC_V_MINSUM, 32, TabJpl1024>(st, a);
+        else launch_split<LDPC_V_TANH, 32, TabJpl1024>(st, a);
+    }
     if (timer && !a.step_mode) timer->end(st);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return set_error(LDPC_EHIP, "fused_split launch: %s", hipGetErrorString(e));

@@ -54,14 +54,21 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if args.gpus > 1 and world == 1:
         raise SystemExit("for --gpus > 1 launch through torch.distributed.run (one process per GPU)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # LDPC_BENCH_REHEARSE=1: run the N > 1 code path on a box with fewer GPUs than ranks (ranks share devices,
+    # gloo instead of RCCL).  For checking the launch/sharding/tally logic only; its number is not a result.
+    rehearse = os.environ.get("LDPC_BENCH_REHEARSE") == "1"
+    dev_index = local_rank % torch.cuda.device_count() if rehearse else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)  # nccl == RCCL on ROCm
-    E.init(local_rank)
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)  # nccl == RCCL on ROCm
+    E.init(dev_index)
 
     suffix = "" if args.dtype == "f32" else "-" + args.dtype
     name = f"ldpc/hip-{args.variant}{suffix}/{args.code}/{args.iters}"
@@ -82,18 +89,19 @@ def main():
     torch.cuda.set_stream(stream)
     sp = stream.cuda_stream
     nbuf = max(1, min(args.steps + args.warmup, 4))
-    llr = [torch.empty((B, N), dtype=torch.float32, device=dev) for _ in range(nbuf)]
+    f16 = args.dtype == "f16"   # configs[3] "fp16 LLRs": the frame source writes fp16, the decoder reads fp16
+    llr = [torch.empty((B, N), dtype=torch.float16 if f16 else torch.float32, device=dev) for _ in range(nbuf)]
     msg = [torch.empty((B, k), dtype=torch.uint8, device=dev) for _ in range(nbuf)]
     bits = torch.empty((B, N), dtype=torch.uint8, device=dev)
     iters_t = torch.empty((B,), dtype=torch.int32, device=dev)
     conv_t = torch.empty((B,), dtype=torch.uint8, device=dev)
     for i in range(nbuf):  # disjoint global frame ids per rank and buffer
         first = (rank * nbuf + i) * B
-        sim.generate(args.seed, first, B, args.ebn0, llr[i].data_ptr(), msg[i].data_ptr(), sp)
+        sim.generate(args.seed, first, B, args.ebn0, llr[i].data_ptr(), msg[i].data_ptr(), sp, llr_f16=f16)
     torch.cuda.synchronize()
 
     def step(i):
-        dec.decode_batch_dev(llr[i % nbuf].data_ptr(), bits.data_ptr(), B, args.iters, iters_t.data_ptr(), conv_t.data_ptr(), sp)
+        dec.decode_batch_dev(llr[i % nbuf].data_ptr(), bits.data_ptr(), B, args.iters, iters_t.data_ptr(), conv_t.data_ptr(), sp, llr_f16=f16)
 
     def barrier():
         if world > 1:
@@ -155,6 +163,7 @@ def main():
             "config": {"workload": f"{args.code} rate {args.rate} ({k},{n_tx}) {args.variant} flooding BP, {args.iters} iters, "
                                    f"Eb/N0={args.ebn0} dB, {B} frames/GPU/step", "code_name": ecc.name, "path": dec.path,
                        "batch_per_gpu": B, "parallelism": f"frames sharded over {world} GPU(s), tallies all-reduced"},
+            **({"rehearsal": "ranks share GPUs over gloo; not a measurement"} if rehearse else {}),
             "roofline": roofline,
             "hbm_roofline_mbit_s": round(HBM_PEAK_GBS * 1e9 / B_cw * k / 1e6, 1),
             "frac_of_hbm_roofline_throughput": round(value / world / (HBM_PEAK_GBS * 1e9 / B_cw * k / 1e6), 4),

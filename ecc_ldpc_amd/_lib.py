@@ -21,6 +21,7 @@ ABI_SYMBOLS = [
     "ldpc_code_create_qc", "ldpc_code_create_csr", "ldpc_code_destroy", "ldpc_code_dims", "ldpc_code_csr",
     "ldpc_ctx_create", "ldpc_ctx_create_ex", "ldpc_ctx_destroy", "ldpc_ctx_path", "ldpc_ctx_synchronize",
     "ldpc_decode_one", "ldpc_decode_batch", "ldpc_decode_batch_f64", "ldpc_decode_batch_dev",
+    "ldpc_decode_batch_f16", "ldpc_decode_batch_dev_f16", "ldpc_sim_generate_f16",
     "ldpc_debug_step", "ldpc_decode_trace",
     "ldpc_host_alloc", "ldpc_host_free",
     "ldpc_ctx_set_timing", "ldpc_ctx_kernel_time", "ldpc_ctx_kernel_name",
@@ -96,6 +97,8 @@ def lib():
     L.ldpc_decode_batch.argtypes = [vp, C.c_int, C.c_int, f32p, u8p, i32p, u8p]
     L.ldpc_decode_batch_f64.argtypes = [vp, C.c_int, C.c_int, f64p, u8p, i32p, u8p, f64p]
     L.ldpc_decode_batch_dev.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp, vp, vp]
+    L.ldpc_decode_batch_f16.argtypes = [vp, C.c_int, C.c_int, vp, u8p, i32p, u8p]
+    L.ldpc_decode_batch_dev_f16.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp, vp, vp]
     L.ldpc_debug_step.argtypes = [vp, C.c_int, f64p, f64p, f64p, f64p, f64p, u8p]
     L.ldpc_decode_trace.argtypes = [vp, C.c_int, C.c_int, f64p, u8p, i32p, u8p, f64p]
     L.ldpc_host_alloc.restype = vp
@@ -111,6 +114,7 @@ def lib():
     L.ldpc_sim_destroy.restype = None
     L.ldpc_sim_destroy.argtypes = [vp]
     L.ldpc_sim_generate.argtypes = [vp, C.c_uint64, C.c_uint64, C.c_int, C.c_double, vp, vp, vp]
+    L.ldpc_sim_generate_f16.argtypes = [vp, C.c_uint64, C.c_uint64, C.c_int, C.c_double, vp, vp, vp]
     L.ldpc_sim_tally.argtypes = [vp, C.c_int, vp, vp, vp, vp]
     L.ldpc_sim_encode_host.argtypes = [vp, u8p, u8p]
     L.ldpc_matrix_load.restype = vp
@@ -264,7 +268,7 @@ class Decoder:
         return bits, it.value, bool(cv.value)
 
     def decode_batch(self, llr, max_iters, want_lam=False, out_bits=None):
-        """llr [F][N] float32 or float64 (host).  -> bits [F][N], iters [F], converged [F] (, lam)"""
+        """llr [F][N] float16, float32 or float64 (host).  -> bits [F][N], iters [F], converged [F] (, lam)"""
         llr = np.asarray(llr)
         F = llr.shape[0]
         assert llr.shape == (F, self.code.N)
@@ -272,6 +276,10 @@ class Decoder:
         assert bits.shape == (F, self.code.N) and bits.dtype == np.uint8 and bits.flags.c_contiguous
         iters = np.zeros(F, np.int32)
         conv = np.zeros(F, np.uint8)
+        if llr.dtype == np.float16 and not want_lam:
+            llr = np.ascontiguousarray(llr)
+            check(lib().ldpc_decode_batch_f16(self._h, int(max_iters), F, llr.ctypes.data_as(C.c_void_p), ptr(bits, C.c_uint8), ptr(iters, C.c_int32), ptr(conv, C.c_uint8)))
+            return bits, iters, conv
         if llr.dtype == np.float32 and not want_lam:
             llr = np.ascontiguousarray(llr)
             check(lib().ldpc_decode_batch(self._h, int(max_iters), F, ptr(llr, C.c_float), ptr(bits, C.c_uint8), ptr(iters, C.c_int32), ptr(conv, C.c_uint8)))
@@ -281,8 +289,10 @@ class Decoder:
         check(lib().ldpc_decode_batch_f64(self._h, int(max_iters), F, ptr(llr, C.c_double), ptr(bits, C.c_uint8), ptr(iters, C.c_int32), ptr(conv, C.c_uint8), ptr(lam, C.c_double)))
         return (bits, iters, conv, lam) if want_lam else (bits, iters, conv)
 
-    def decode_batch_dev(self, d_llr_ptr, d_bits_ptr, batch, max_iters, d_iters_ptr=None, d_conv_ptr=None, stream=None):
-        check(lib().ldpc_decode_batch_dev(self._h, int(max_iters), int(batch), d_llr_ptr, d_bits_ptr, d_iters_ptr, d_conv_ptr, stream))
+    def decode_batch_dev(self, d_llr_ptr, d_bits_ptr, batch, max_iters, d_iters_ptr=None, d_conv_ptr=None, stream=None, llr_f16=False):
+        """device pointers; d_llr [batch][N] float32, or float16 with llr_f16=True"""
+        fn = lib().ldpc_decode_batch_dev_f16 if llr_f16 else lib().ldpc_decode_batch_dev
+        check(fn(self._h, int(max_iters), int(batch), d_llr_ptr, d_bits_ptr, d_iters_ptr, d_conv_ptr, stream))
 
     def synchronize(self):
         check(lib().ldpc_ctx_synchronize(self._h))
@@ -392,8 +402,9 @@ class Sim:
             raise LdpcError(lib().ldpc_last_error_code(), last_error())
         self._h = _handle
 
-    def generate(self, seed, first_frame, batch, ebn0_db, d_llr_ptr, d_msg_ptr=None, stream=None):
-        check(lib().ldpc_sim_generate(self._h, int(seed), int(first_frame), int(batch), float(ebn0_db), d_llr_ptr, d_msg_ptr, stream))
+    def generate(self, seed, first_frame, batch, ebn0_db, d_llr_ptr, d_msg_ptr=None, stream=None, llr_f16=False):
+        fn = lib().ldpc_sim_generate_f16 if llr_f16 else lib().ldpc_sim_generate
+        check(fn(self._h, int(seed), int(first_frame), int(batch), float(ebn0_db), d_llr_ptr, d_msg_ptr, stream))
 
     def tally(self, batch, d_bits_ptr, d_iters_ptr, d_tally_ptr, stream=None):
         check(lib().ldpc_sim_tally(self._h, int(batch), d_bits_ptr, d_iters_ptr, d_tally_ptr, stream))

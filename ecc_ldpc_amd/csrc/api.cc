@@ -345,13 +345,13 @@ static int check_call(ldpc_ctx *ctx, int max_iters, int batch) {
     return LDPC_OK;
 }
 
-// device-side core: d_llr is float32 or float64 [batch][N]; outputs device pointers (may be null)
-static int decode_dev(ldpc_ctx *ctx, hipStream_t st, int max_iters, int batch, const void *d_llr, int is_f64,
+// device-side core: d_llr is [batch][N] of element type fmt (ldpc::LLR_F32 / LLR_F64 / LLR_F16); outputs device pointers (may be null)
+static int decode_dev(ldpc_ctx *ctx, hipStream_t st, int max_iters, int batch, const void *d_llr, int fmt,
                       uint8_t *d_bits, int32_t *d_iters, uint8_t *d_conv, double *d_final, double *d_trace) {
     if (batch == 0) return LDPC_OK;
     if (ctx->path == LDPC_PATH_FUSED)
-        return ldpc::fused_decode(*ctx->fused, st, max_iters, batch, d_llr, is_f64, d_bits, d_iters, d_conv, d_final, d_trace);
-    int rc = ldpc::flood_decode(ctx->flood, st, max_iters, batch, d_llr, is_f64, d_bits, d_final, d_trace);
+        return ldpc::fused_decode(*ctx->fused, st, max_iters, batch, d_llr, fmt, d_bits, d_iters, d_conv, d_final, d_trace);
+    int rc = ldpc::flood_decode(ctx->flood, st, max_iters, batch, d_llr, fmt, d_bits, d_final, d_trace);
     if (rc != LDPC_OK) return rc;
     if (d_iters) HIPCHK(hipMemcpyAsync(d_iters, ctx->flood.dev.iters, sizeof(int32_t) * (size_t)batch, hipMemcpyDeviceToDevice, st));
     if (d_conv) HIPCHK(hipMemcpyAsync(d_conv, ctx->flood.dev.conv, (size_t)batch, hipMemcpyDeviceToDevice, st));
@@ -390,14 +390,14 @@ static int ensure_staging(ldpc_ctx *ctx, bool want_final) {
     return LDPC_OK;
 }
 
-static int decode_host(ldpc_ctx *ctx, int max_iters, int batch, const void *llr, int is_f64, uint8_t *bits,
+static int decode_host(ldpc_ctx *ctx, int max_iters, int batch, const void *llr, int fmt, uint8_t *bits,
                        int32_t *iters, uint8_t *converged, double *final_lam, double *trace_lam) {
     int rc = check_call(ctx, max_iters, batch);
     if (rc != LDPC_OK) return rc;
     if (batch == 0) return LDPC_OK;
     if (!llr || !bits) return set_error(LDPC_EINVAL, "null llr/bits");
     if ((rc = ensure_staging(ctx, final_lam != nullptr)) != LDPC_OK) return rc;
-    const size_t N = (size_t)ctx->code->N, es = is_f64 ? 8 : 4;
+    const size_t N = (size_t)ctx->code->N, es = fmt == ldpc::LLR_F64 ? 8 : (fmt == ldpc::LLR_F16 ? 2 : 4);
     double *d_trace = nullptr;
     const size_t turns = (size_t)max_iters + 1;
     if (trace_lam) {  // verification path: one device buffer for the whole batch
@@ -415,7 +415,7 @@ static int decode_host(ldpc_ctx *ctx, int max_iters, int batch, const void *llr,
         // stream order protects the slot: this copy is queued behind the slot's previous D2H
         e = hipMemcpyAsync(ctx->d_in[slot], (const char *)llr + (size_t)f0 * N * es, (size_t)nb * N * es, hipMemcpyHostToDevice, st);
         if (e != hipSuccess) break;
-        rc = decode_dev(ctx, st, max_iters, nb, ctx->d_in[slot], is_f64, ctx->d_bits[slot], ctx->d_iters[slot], ctx->d_conv[slot],
+        rc = decode_dev(ctx, st, max_iters, nb, ctx->d_in[slot], fmt, ctx->d_bits[slot], ctx->d_iters[slot], ctx->d_conv[slot],
                         final_lam ? ctx->d_final[slot] : nullptr, d_trace ? d_trace + (size_t)f0 * turns * N : nullptr);
         if (rc != LDPC_OK) break;
         e = hipMemcpyAsync(bits + (size_t)f0 * N, ctx->d_bits[slot], (size_t)nb * N, hipMemcpyDeviceToHost, st);
@@ -435,38 +435,53 @@ static int decode_host(ldpc_ctx *ctx, int max_iters, int batch, const void *llr,
 
 int ldpc_decode_batch(ldpc_ctx *ctx, int max_iters, int batch, const float *llr, uint8_t *bits, int32_t *iters,
                       uint8_t *converged) {
-    return decode_host(ctx, max_iters, batch, llr, 0, bits, iters, converged, nullptr, nullptr);
+    return decode_host(ctx, max_iters, batch, llr, ldpc::LLR_F32, bits, iters, converged, nullptr, nullptr);
+}
+
+int ldpc_decode_batch_f16(ldpc_ctx *ctx, int max_iters, int batch, const uint16_t *llr, uint8_t *bits, int32_t *iters,
+                          uint8_t *converged) {
+    return decode_host(ctx, max_iters, batch, llr, ldpc::LLR_F16, bits, iters, converged, nullptr, nullptr);
 }
 
 int ldpc_decode_batch_f64(ldpc_ctx *ctx, int max_iters, int batch, const double *llr, uint8_t *bits, int32_t *iters,
                           uint8_t *converged, double *final_lam) {
-    return decode_host(ctx, max_iters, batch, llr, 1, bits, iters, converged, final_lam, nullptr);
+    return decode_host(ctx, max_iters, batch, llr, ldpc::LLR_F64, bits, iters, converged, final_lam, nullptr);
 }
 
 int ldpc_decode_trace(ldpc_ctx *ctx, int max_iters, int batch, const double *llr, uint8_t *bits, int32_t *iters,
                       uint8_t *converged, double *trace_lam) {
     if (!trace_lam) return set_error(LDPC_EINVAL, "null trace_lam");
-    return decode_host(ctx, max_iters, batch, llr, 1, bits, iters, converged, nullptr, trace_lam);
+    return decode_host(ctx, max_iters, batch, llr, ldpc::LLR_F64, bits, iters, converged, nullptr, trace_lam);
 }
 
 int ldpc_decode_one(ldpc_ctx *ctx, int max_iters, const double *llr, uint8_t *bits, int *iters, int *converged) {
     int32_t it = 0;
     uint8_t cv = 0;
-    int rc = decode_host(ctx, max_iters, 1, llr, 1, bits, &it, &cv, nullptr, nullptr);
+    int rc = decode_host(ctx, max_iters, 1, llr, ldpc::LLR_F64, bits, &it, &cv, nullptr, nullptr);
     if (rc != LDPC_OK) return rc;
     if (iters) *iters = it;
     if (converged) *converged = cv;
     return LDPC_OK;
 }
 
-int ldpc_decode_batch_dev(ldpc_ctx *ctx, int max_iters, int batch, const float *d_llr, uint8_t *d_bits,
-                          int32_t *d_iters, uint8_t *d_converged, void *stream) {
+static int decode_dev_checked(ldpc_ctx *ctx, int max_iters, int batch, const void *d_llr, int fmt, uint8_t *d_bits,
+                              int32_t *d_iters, uint8_t *d_converged, void *stream) {
     int rc = check_call(ctx, max_iters, batch);
     if (rc != LDPC_OK) return rc;
     if (batch == 0) return LDPC_OK;
     if (!d_llr || !d_bits) return set_error(LDPC_EINVAL, "null d_llr/d_bits");
     hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
-    return decode_dev(ctx, st, max_iters, batch, d_llr, 0, d_bits, d_iters, d_converged, nullptr, nullptr);
+    return decode_dev(ctx, st, max_iters, batch, d_llr, fmt, d_bits, d_iters, d_converged, nullptr, nullptr);
+}
+
+int ldpc_decode_batch_dev(ldpc_ctx *ctx, int max_iters, int batch, const float *d_llr, uint8_t *d_bits,
+                          int32_t *d_iters, uint8_t *d_converged, void *stream) {
+    return decode_dev_checked(ctx, max_iters, batch, d_llr, ldpc::LLR_F32, d_bits, d_iters, d_converged, stream);
+}
+
+int ldpc_decode_batch_dev_f16(ldpc_ctx *ctx, int max_iters, int batch, const uint16_t *d_llr, uint8_t *d_bits,
+                              int32_t *d_iters, uint8_t *d_converged, void *stream) {
+    return decode_dev_checked(ctx, max_iters, batch, d_llr, ldpc::LLR_F16, d_bits, d_iters, d_converged, stream);
 }
 
 int ldpc_debug_step(ldpc_ctx *ctx, int batch, const double *orig, const double *lam, const double *ne, double *ne_out,
@@ -567,12 +582,22 @@ ldpc_sim *ldpc_sim_create(const ldpc_code *code, int k, int n_tx, int p, const u
     return s;
 }
 
-int ldpc_sim_generate(ldpc_sim *sim, uint64_t seed, uint64_t first_frame, int batch, double ebn0_db, float *d_llr,
-                      uint8_t *d_msg, void *stream) {
+static int sim_generate_any(ldpc_sim *sim, uint64_t seed, uint64_t first_frame, int batch, double ebn0_db, void *d_llr,
+                            int llr_f16, uint8_t *d_msg, void *stream) {
     if (!sim || !d_llr || batch < 0 || batch > sim->max_batch) return set_error(LDPC_EINVAL, "ldpc_sim_generate: bad arguments");
     if (batch == 0) return LDPC_OK;
     HIPCHK(hipSetDevice(sim->device));
-    return ldpc::sim_generate(sim->dev, sim->d_msgw, (hipStream_t)stream, seed, first_frame, batch, ebn0_db, d_llr, d_msg);
+    return ldpc::sim_generate(sim->dev, sim->d_msgw, (hipStream_t)stream, seed, first_frame, batch, ebn0_db, d_llr, llr_f16, d_msg);
+}
+
+int ldpc_sim_generate(ldpc_sim *sim, uint64_t seed, uint64_t first_frame, int batch, double ebn0_db, float *d_llr,
+                      uint8_t *d_msg, void *stream) {
+    return sim_generate_any(sim, seed, first_frame, batch, ebn0_db, d_llr, 0, d_msg, stream);
+}
+
+int ldpc_sim_generate_f16(ldpc_sim *sim, uint64_t seed, uint64_t first_frame, int batch, double ebn0_db, uint16_t *d_llr,
+                          uint8_t *d_msg, void *stream) {
+    return sim_generate_any(sim, seed, first_frame, batch, ebn0_db, d_llr, 1, d_msg, stream);
 }
 
 int ldpc_sim_tally(ldpc_sim *sim, int batch, const uint8_t *d_bits, const int32_t *d_iters, uint64_t *d_tally, void *stream) {

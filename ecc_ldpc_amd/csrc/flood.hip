@@ -222,8 +222,10 @@ __global__ __launch_bounds__(256) void load_llr_kernel(const IT *__restrict__ in
     const int n0 = blockIdx.x * 64, b0 = blockIdx.y * 64;
     for (int r = ty; r < 64; r += 4) {
         int b = b0 + r, n = n0 + tx;
-        IT v = (b < batch && n < N) ? in[(size_t)b * N + n] : IT(0);
-        if constexpr (sizeof(IT) == 8) tiled[r][tx] = v; else tile[r][tx] = v;
+        const bool ok = b < batch && n < N;
+        if constexpr (sizeof(IT) == 8) tiled[r][tx] = ok ? in[(size_t)b * N + n] : 0.0;
+        else if constexpr (sizeof(IT) == 2) tile[r][tx] = ok ? __half2float(in[(size_t)b * N + n]) : 0.f;
+        else tile[r][tx] = ok ? in[(size_t)b * N + n] : 0.f;
     }
     __syncthreads();
     for (int r = ty; r < 64; r += 4) {
@@ -339,13 +341,15 @@ static int run_turns(FloodState &s, hipStream_t st, int max_iters, int batch, do
 
 template <typename ST, int VARIANT>
 static int decode_impl(FloodState &s, hipStream_t st, int max_iters, int batch, const void *d_llr,
-                       int llr_is_f64, uint8_t *d_bits, double *d_final, double *d_trace) {
+                       int llr_fmt, uint8_t *d_bits, double *d_final, double *d_trace) {
     FloodDev d = s.dev;
     hipLaunchKernelGGL(flood_reset_kernel, dim3((d.Bp + 255) / 256), dim3(256), 0, st, d, batch);
     HIPCHK(hipMemsetAsync(s.msg, 0, (size_t)d.E * d.Bp * sizeof(ST), st)); // Orig.hs:64-65 orig_ne = 0
     const dim3 tgrid((d.N + 63) / 64, (d.Bp + 63) / 64);
-    if (llr_is_f64)
+    if (llr_fmt == LLR_F64)
         hipLaunchKernelGGL((load_llr_kernel<double, ST>), tgrid, dim3(256), 0, st, (const double *)d_llr, (ST *)s.orig, (ST *)s.lam, batch, d.N, d.Bp);
+    else if (llr_fmt == LLR_F16)
+        hipLaunchKernelGGL((load_llr_kernel<__half, ST>), tgrid, dim3(256), 0, st, (const __half *)d_llr, (ST *)s.orig, (ST *)s.lam, batch, d.N, d.Bp);
     else
         hipLaunchKernelGGL((load_llr_kernel<float, ST>), tgrid, dim3(256), 0, st, (const float *)d_llr, (ST *)s.orig, (ST *)s.lam, batch, d.N, d.Bp);
     int rc = run_turns<ST, VARIANT>(s, st, max_iters, batch, d_trace);
@@ -384,9 +388,9 @@ static int step_impl(FloodState &s, hipStream_t st, int batch, const double *d_o
         default: return set_error(LDPC_EINVAL, "bad dtype %d", s.dtype);                    \
     }
 
-int flood_decode(FloodState &s, hipStream_t st, int max_iters, int batch, const void *d_llr, int llr_is_f64,
+int flood_decode(FloodState &s, hipStream_t st, int max_iters, int batch, const void *d_llr, int llr_fmt,
                  uint8_t *d_bits, double *d_final, double *d_trace) {
-    DISPATCH(decode_impl, s, st, max_iters, batch, d_llr, llr_is_f64, d_bits, d_final, d_trace)
+    DISPATCH(decode_impl, s, st, max_iters, batch, d_llr, llr_fmt, d_bits, d_final, d_trace)
 }
 int flood_step(FloodState &s, hipStream_t st, int batch, const double *d_orig, const double *d_lam,
                const double *d_ne, double *d_ne_out, double *d_lam_out, uint8_t *d_syn) {

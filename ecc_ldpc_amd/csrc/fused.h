@@ -13,7 +13,7 @@ FusedState *fused_create(const ldpc_code &code, int variant, int dtype, int max_
 void fused_destroy(FusedState *s);
 void fused_set_timer(FusedState *s, KernelTimer *t);
 // d_llr [batch][N] float32/float64; outputs may be null except d_bits
-int fused_decode(FusedState &s, hipStream_t st, int max_iters, int batch, const void *d_llr, int llr_is_f64,
+int fused_decode(FusedState &s, hipStream_t st, int max_iters, int batch, const void *d_llr, int llr_fmt,
                  uint8_t *d_bits, int32_t *d_iters, uint8_t *d_conv, double *d_final, double *d_trace);
 int fused_step(FusedState &s, hipStream_t st, int batch, const double *d_orig, const double *d_lam,
                const double *d_ne, double *d_ne_out, double *d_lam_out, uint8_t *d_syn);
@@ -27,7 +27,8 @@ const char *fused_csr_why_not(const ldpc_code &code, int variant, int dtype);
 CsrState *fused_csr_create(const ldpc_code &code, int variant, int dtype);
 void fused_csr_destroy(CsrState *s);
 void fused_csr_set_timer(CsrState *s, KernelTimer *t);
-int fused_csr_decode(CsrState &s, hipStream_t st, int max_iters, int batch, const void *d_llr, int llr_is_f64, uint8_t *d_bits,
+void fused_csr_set_round16(CsrState *s, int on);  // LDPC_F16 context: LLRs count as stored in fp16
+int fused_csr_decode(CsrState &s, hipStream_t st, int max_iters, int batch, const void *d_llr, int llr_fmt, uint8_t *d_bits,
                      int32_t *d_iters, uint8_t *d_conv, double *d_final, double *d_trace);
 int fused_csr_step(CsrState &s, hipStream_t st, int batch, const double *d_orig, const double *d_lam, const double *d_ne,
                    double *d_ne_out, double *d_lam_out, uint8_t *d_syn);

@@ -188,15 +188,9 @@ __global__ __launch_bounds__((FusedCfg<CT, Plan, SZ>::THREADS), (FusedCfg<CT, Pl
 
     // ---- channel LLRs -> registers (orig) ; records <- 0 (Min.hs:59-60 orig_ne = 0)
     CT orig[Cfg::NORIG];  // lanes of padding frames read frame 0 (never written back)
-    if (A.llr_is_f64) {
-        const double *src = reinterpret_cast<const double *>(A.llr) + fN + r0;
 #pragma unroll
-        for (int i = 0; i < Cfg::NORIG; i++) orig[i] = (CT)src[(i / RPL) * SZ + RSTEP * (i % RPL)];
-    } else {
-        const float *src = reinterpret_cast<const float *>(A.llr) + fN + r0;
-#pragma unroll
-        for (int i = 0; i < Cfg::NORIG; i++) orig[i] = (CT)src[(i / RPL) * SZ + RSTEP * (i % RPL)];
-    }
+    for (int i = 0; i < Cfg::NORIG; i++)
+        orig[i] = maybe_round_f16<CT>(load_llr<CT>(A.llr, fN + r0 + (i / RPL) * SZ + RSTEP * (i % RPL), A.llr_fmt), A.llr_round16);
     CT m1s[Cfg::NREC], m2s[Cfg::NREC];
     uint32_t sgi[Cfg::NREC];
 #pragma unroll
@@ -349,7 +343,8 @@ __global__ __launch_bounds__((FusedCfg<CT, Plan, SZ>::THREADS), (FusedCfg<CT, Pl
 
 // ------------------------------------------------------------------ host side
 struct FusedState {
-    int variant = 0, dtype = 0, max_batch = 0, sz = 0, M = 0, N = 0, E = 0;
+    int variant = 0, dtype = 0, max_batch = 0, sz = 0, M = 0, N = 0, E = 0;  // dtype: the COMPUTE type (f32/f64)
+    int round16 = 0;          // LDPC_F16 context: fp16 channel LLRs, f32 state (nothing else of a fused decode lives in HBM)
     CsrState *csr = nullptr;  // set when the code has no QC plan: generic on-chip kernel (fused_csr.hip)
     int static_id = 0;    // compiled-in rotation table matching this code (0 = none: table-driven kernel)
     bool use_split = false;  // four waves per frame, block rows split between wave pairs (fused_split.hip)
@@ -377,8 +372,13 @@ static const char *plan_why_not(const ldpc_code &c, int variant, int dtype) {
     if (!plan_matches_ar4ja45(c)) return "block structure is not the AR4JA rate-4/5 plan (12x44 blocks, row weights 3,3,3,3,18x8)";
     return nullptr;
 }
+// LDPC_F16 = "fp16 storage in HBM, f32 arithmetic".  The only thing a fused decode keeps in HBM is the channel
+// LLRs, so a fused F16 context is the f32 kernel fed fp16-rounded LLRs.
+static inline int compute_dtype(int dtype) { return dtype == LDPC_F16 ? LDPC_F32 : dtype; }
+
 // a fused (on-chip) kernel exists if the code matches a compiled QC plan, or failing that if a frame fits in LDS
 const char *fused_why_not(const ldpc_code &c, int variant, int dtype) {
+    dtype = compute_dtype(dtype);
     const char *p = plan_why_not(c, variant, dtype);
     if (!p) return nullptr;
     const char *g = fused_csr_why_not(c, variant, dtype);
@@ -427,10 +427,13 @@ FusedState *fused_create(const ldpc_code &c, int variant, int dtype, int max_bat
     if (why) { set_error(LDPC_EUNSUPPORTED, "%s", why); return nullptr; }
     FusedState *s = new (std::nothrow) FusedState();
     if (!s) { set_error(LDPC_ENOMEM, "out of host memory"); return nullptr; }
+    s->round16 = dtype == LDPC_F16;
+    dtype = compute_dtype(dtype);
     s->variant = variant; s->dtype = dtype; s->max_batch = max_batch; s->sz = c.sz; s->M = c.M; s->N = c.N; s->E = c.E;
     if (plan_why_not(c, variant, dtype) != nullptr) {  // no QC plan: generic on-chip kernel
         s->csr = fused_csr_create(c, variant, dtype);
         if (!s->csr) { delete s; return nullptr; }
+        fused_csr_set_round16(s->csr, s->round16);
         return s;
     }
     s->row_ptr = c.row_ptr;
@@ -486,11 +489,11 @@ const char *fused_kernel_name(const FusedState &s) {
     return "fused_decode_kernel";
 }
 
-int fused_decode(FusedState &s, hipStream_t st, int max_iters, int batch, const void *d_llr, int llr_is_f64, uint8_t *d_bits,
+int fused_decode(FusedState &s, hipStream_t st, int max_iters, int batch, const void *d_llr, int llr_fmt, uint8_t *d_bits,
                  int32_t *d_iters, uint8_t *d_conv, double *d_final, double *d_trace) {
-    if (s.csr) return fused_csr_decode(*s.csr, st, max_iters, batch, d_llr, llr_is_f64, d_bits, d_iters, d_conv, d_final, d_trace);
+    if (s.csr) return fused_csr_decode(*s.csr, st, max_iters, batch, d_llr, llr_fmt, d_bits, d_iters, d_conv, d_final, d_trace);
     FusedArgs a{};
-    a.tab = s.d_tab; a.llr = d_llr; a.llr_is_f64 = llr_is_f64; a.bits = d_bits; a.iters = d_iters; a.conv = d_conv;
+    a.tab = s.d_tab; a.llr = d_llr; a.llr_fmt = llr_fmt; a.llr_round16 = s.round16; a.bits = d_bits; a.iters = d_iters; a.conv = d_conv;
     a.final_lam = d_final; a.trace = d_trace; a.batch = batch; a.max_iters = max_iters; a.step_mode = 0;
     if (s.use_split) return fused_split_launch(s.variant, s.sz, st, a, s.timer);
     if (s.use_msg) return fused_msg_launch(s.variant, s.dtype, s.sz, s.static_id, st, a, s.timer);
@@ -538,7 +541,7 @@ static int step_typed(FusedState &s, hipStream_t st, int batch, const double *d_
     if (e != hipSuccess) rc = set_error(LDPC_EHIP, "fused_step: %s", hipGetErrorString(e));
     if (rc == LDPC_OK) {
         FusedArgs a{};
-        a.tab = s.d_tab; a.llr = d_orig; a.llr_is_f64 = 1; a.batch = batch; a.max_iters = 1; a.step_mode = 1;
+        a.tab = s.d_tab; a.llr = d_orig; a.llr_fmt = LLR_F64; a.llr_round16 = 0; a.batch = batch; a.max_iters = 1; a.step_mode = 1;
         a.st_lam = d_lam; a.st_m1 = dm1; a.st_m2 = dm2; a.st_sg = dsg; a.st_ne_out = d_ne_out; a.final_lam = d_lam_out; a.st_syn = d_syn;
         rc = dispatch(s, st, a);
     }
@@ -552,7 +555,7 @@ int fused_step(FusedState &s, hipStream_t st, int batch, const double *d_orig, c
     if (s.csr) return fused_csr_step(*s.csr, st, batch, d_orig, d_lam, d_ne, d_ne_out, d_lam_out, d_syn);
     if (s.use_msg) {  // per-edge messages: the state goes in and out as it is
         FusedArgs a{};
-        a.tab = s.d_tab; a.llr = d_orig; a.llr_is_f64 = 1; a.batch = batch; a.max_iters = 1; a.step_mode = 1;
+        a.tab = s.d_tab; a.llr = d_orig; a.llr_fmt = LLR_F64; a.llr_round16 = 0; a.batch = batch; a.max_iters = 1; a.step_mode = 1;
         a.st_lam = d_lam; a.st_ne_in = d_ne; a.st_ne_out = d_ne_out; a.final_lam = d_lam_out; a.st_syn = d_syn;
         if (s.use_split) return fused_split_launch(s.variant, s.sz, st, a, nullptr);
         return fused_msg_launch(s.variant, s.dtype, s.sz, s.static_id, st, a, nullptr);

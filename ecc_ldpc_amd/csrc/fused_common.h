@@ -40,13 +40,14 @@ __device__ __forceinline__ void static_rfor(F &&f) {  // N-1 down to I
 typedef const __attribute__((address_space(4))) uint32_t *ctab_t;
 struct FusedArgs {
     const uint32_t *tab;
-    const void *llr;  // [batch][N] float or double
+    const void *llr;  // [batch][N], element type llr_fmt (LLR_F32 / LLR_F64 / LLR_F16)
     uint8_t *bits;    // [batch][N]
     int32_t *iters;   // may be null
     uint8_t *conv;    // may be null
     double *final_lam;  // may be null [batch][N]
     double *trace;      // may be null [batch][max_iters+1][N]
-    int batch, max_iters, llr_is_f64;
+    int batch, max_iters, llr_fmt;
+    int llr_round16;  // LDPC_F16 context: the LLRs count as stored in fp16 (round on load; a no-op for LLR_F16 input)
     // teacher-forced single step (verification): state in, state out
     int step_mode;
     const double *st_lam;  // [batch][N]

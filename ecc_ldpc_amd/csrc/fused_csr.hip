@@ -35,7 +35,7 @@ struct CsrArgs {
     int32_t *iters;
     uint8_t *conv;
     double *final_lam, *trace;
-    int batch, max_iters, llr_is_f64, step_mode;
+    int batch, max_iters, llr_fmt, llr_round16, step_mode;
     const double *st_lam, *st_ne_in;
     double *st_ne_out;
     uint8_t *st_syn;
@@ -56,7 +56,7 @@ __global__ __launch_bounds__(kCsrThreads) void fused_csr_kernel(CsrArgs A) {
     const size_t fN = (size_t)frame * N, fE = (size_t)frame * A.E;
 
     for (int n = tid; n < N; n += kCsrThreads) {
-        CT v = A.llr_is_f64 ? (CT) reinterpret_cast<const double *>(A.llr)[fN + n] : (CT) reinterpret_cast<const float *>(A.llr)[fN + n];
+        CT v = maybe_round_f16<CT>(load_llr<CT>(A.llr, fN + n, A.llr_fmt), A.llr_round16);
         orig[n] = v;
         lam[n] = A.step_mode ? (CT)A.st_lam[fN + n] : v;
     }
@@ -186,7 +186,7 @@ __global__ __launch_bounds__(kCsrThreads) void fused_csr_kernel(CsrArgs A) {
 
 // ------------------------------------------------------------------ host side
 struct CsrState {
-    int variant = 0, dtype = 0, M = 0, N = 0, E = 0, dmax = 0, cdmax = 0;
+    int variant = 0, dtype = 0, M = 0, N = 0, E = 0, dmax = 0, cdmax = 0, round16 = 0;
     int32_t *d_ell = nullptr, *d_csc = nullptr, *d_row_ptr = nullptr;
     KernelTimer *timer = nullptr;
 };
@@ -242,6 +242,7 @@ CsrState *fused_csr_create(const ldpc_code &c, int variant, int dtype) {
 }
 
 void fused_csr_set_timer(CsrState *s, KernelTimer *t) { if (s) s->timer = t; }
+void fused_csr_set_round16(CsrState *s, int on) { if (s) s->round16 = on; }
 
 template <typename CT, int VARIANT, int DMAX, int RPT, int CPT>
 static int launch_csr(CsrState &s, hipStream_t st, CsrArgs &a) {
@@ -293,10 +294,10 @@ static int csr_run(CsrState &s, hipStream_t st, CsrArgs &a) {
     return s.variant == LDPC_MINSUM ? dispatch_dmax<float, LDPC_V_MINSUM>(s, st, a) : dispatch_dmax<float, LDPC_V_TANH>(s, st, a);
 }
 
-int fused_csr_decode(CsrState &s, hipStream_t st, int max_iters, int batch, const void *d_llr, int llr_is_f64, uint8_t *d_bits,
+int fused_csr_decode(CsrState &s, hipStream_t st, int max_iters, int batch, const void *d_llr, int llr_fmt, uint8_t *d_bits,
                      int32_t *d_iters, uint8_t *d_conv, double *d_final, double *d_trace) {
     CsrArgs a{};
-    a.llr = d_llr; a.llr_is_f64 = llr_is_f64; a.bits = d_bits; a.iters = d_iters; a.conv = d_conv; a.final_lam = d_final; a.trace = d_trace;
+    a.llr = d_llr; a.llr_fmt = llr_fmt; a.llr_round16 = s.round16; a.bits = d_bits; a.iters = d_iters; a.conv = d_conv; a.final_lam = d_final; a.trace = d_trace;
     a.batch = batch; a.max_iters = max_iters;
     return csr_run(s, st, a);
 }
@@ -304,7 +305,7 @@ int fused_csr_decode(CsrState &s, hipStream_t st, int max_iters, int batch, cons
 int fused_csr_step(CsrState &s, hipStream_t st, int batch, const double *d_orig, const double *d_lam, const double *d_ne,
                    double *d_ne_out, double *d_lam_out, uint8_t *d_syn) {
     CsrArgs a{};
-    a.llr = d_orig; a.llr_is_f64 = 1; a.batch = batch; a.max_iters = 1; a.step_mode = 1;
+    a.llr = d_orig; a.llr_fmt = LLR_F64; a.llr_round16 = 0; a.batch = batch; a.max_iters = 1; a.step_mode = 1;
     a.st_lam = d_lam; a.st_ne_in = d_ne; a.st_ne_out = d_ne_out; a.final_lam = d_lam_out; a.st_syn = d_syn;
     return csr_run(s, st, a);
 }

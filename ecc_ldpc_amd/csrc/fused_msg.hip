@@ -53,19 +53,14 @@ __global__ __launch_bounds__((MsgCfg<CT, VARIANT, Plan, SZ>::THREADS), (MsgCfg<C
     // block column, i.e. own column rotated by that circulant's offset.
     constexpr bool kRot = IsStatic<Tab>::value && RPL == 1;
     auto llr_at = [&](size_t gi) -> CT {
-        return A.llr_is_f64 ? (CT) reinterpret_cast<const double *>(A.llr)[gi] : (CT) reinterpret_cast<const float *>(A.llr)[gi];
+        return maybe_round_f16<CT>(load_llr<CT>(A.llr, gi, A.llr_fmt), A.llr_round16);
     };
     CT orig[Cfg::NORIG];
     if constexpr (kRot) {
         // loaded after the LDS fill below (keeps the prologue's register pressure down)
-    } else if (A.llr_is_f64) {
-        const double *src = reinterpret_cast<const double *>(A.llr) + fN + r0;
-#pragma unroll
-        for (int i = 0; i < Cfg::NORIG; i++) orig[i] = (CT)src[(i / RPL) * SZ + RSTEP * (i % RPL)];
     } else {
-        const float *src = reinterpret_cast<const float *>(A.llr) + fN + r0;
 #pragma unroll
-        for (int i = 0; i < Cfg::NORIG; i++) orig[i] = (CT)src[(i / RPL) * SZ + RSTEP * (i % RPL)];
+        for (int i = 0; i < Cfg::NORIG; i++) orig[i] = llr_at(fN + r0 + (i / RPL) * SZ + RSTEP * (i % RPL));
     }
     // messages: index ebeg(br)*RPL + h*D + k ; Orig.hs:64-65 orig_ne = 0
     CT msg[Cfg::NMSG];

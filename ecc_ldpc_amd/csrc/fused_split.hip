@@ -150,7 +150,7 @@ __device__ __forceinline__ void split_body(const FusedArgs &A, char *lds, const 
     const uint32_t r0 = w0.r0;
     const size_t fN = w0.fN, fE = w0.fE;
     auto llr_at = [&](size_t gi) -> CT {
-        return A.llr_is_f64 ? (CT) reinterpret_cast<const double *>(A.llr)[gi] : (CT) reinterpret_cast<const float *>(A.llr)[gi];
+        return maybe_round_f16<CT>(load_llr<CT>(A.llr, gi, A.llr_fmt), A.llr_round16);
     };
 
     // ---- lam <- LLRs (or the given lam): pair P fills the block columns bc with bc % 2 == P

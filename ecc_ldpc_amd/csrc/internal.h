@@ -8,6 +8,9 @@
 #include "../../include/ldpc_hip.h"
 
 namespace ldpc {
+// element type of the [batch][N] channel-LLR array a decode entry point hands to the kernels
+enum { LLR_F32 = 0, LLR_F64 = 1, LLR_F16 = 2 };
+
 
 int set_error(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
 
@@ -66,7 +69,7 @@ struct FloodState {
     void *msg = nullptr, *scratch = nullptr, *lam = nullptr, *orig = nullptr;
 };
 
-int flood_decode(FloodState &s, hipStream_t st, int max_iters, int batch, const void *d_llr, int llr_is_f64,
+int flood_decode(FloodState &s, hipStream_t st, int max_iters, int batch, const void *d_llr, int llr_fmt,
                  uint8_t *d_bits, double *d_final, double *d_trace);
 int flood_step(FloodState &s, hipStream_t st, int batch, const double *d_orig, const double *d_lam,
                const double *d_ne, double *d_ne_out, double *d_lam_out, uint8_t *d_syn);

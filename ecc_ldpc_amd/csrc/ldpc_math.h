@@ -21,6 +21,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <hip/hip_fp16.h>
+#include "internal.h"
 
 #define LDPC_V_TANH 0
 #define LDPC_V_MINSUM 1
@@ -53,6 +54,23 @@ template <> struct Store<__half> {
 };
 
 template <typename CT> __device__ __forceinline__ bool hard(CT x) { return x > CT(0); }
+
+// ---------------------------------------------------------------- channel LLR input formats
+// (LLR_F32 / LLR_F64 / LLR_F16: internal.h)
+template <typename CT> __device__ __forceinline__ CT load_llr(const void *base, size_t i, int fmt) {
+    if (fmt == LLR_F64) return (CT) reinterpret_cast<const double *>(base)[i];
+    if (fmt == LLR_F16) return (CT) __half2float(reinterpret_cast<const __half *>(base)[i]);
+    return (CT) reinterpret_cast<const float *>(base)[i];
+}
+// value a float LLR has after being stored as fp16 (LDPC_F16 contexts): saturating round-to-nearest-even
+__device__ __forceinline__ float round_f16(float v) {
+    v = fminf(fmaxf(v, -65504.f), 65504.f);
+    return __half2float(__float2half_rn(v));
+}
+template <typename CT> __device__ __forceinline__ CT maybe_round_f16(CT v, int on) {
+    if constexpr (sizeof(CT) == 4) return on ? round_f16(v) : v;
+    else return v;
+}
 
 // ---------------------------------------------------------------- phi (float)
 // phi(x) = -ln(tanh(x/2)),  x >= 0.  Branch-free, 4 hardware transcendentals (v_exp, 2 v_rcp, v_log;

@@ -7,7 +7,7 @@ struct SimDev {
     const uint32_t *gt;  // [p][kwords] column j of G packed over message bits; null = all-zero codewords
 };
 int sim_generate(const SimDev &s, uint32_t *msgw, hipStream_t st, uint64_t seed, uint64_t first_frame, int batch,
-                 double ebn0_db, float *d_llr, uint8_t *d_msg);
+                 double ebn0_db, void *d_llr, int llr_f16, uint8_t *d_msg);
 int sim_tally(const SimDev &s, const uint32_t *msgw, hipStream_t st, int batch, const uint8_t *d_bits, const int32_t *d_iters,
               unsigned long long *d_tally);
 }  // namespace ldpc

@@ -13,6 +13,7 @@
 // with no scatter.
 #include "internal.h"
 #include "sim.h"
+#include <hip/hip_fp16.h>
 
 namespace ldpc {
 
@@ -51,7 +52,8 @@ __global__ void sim_msg_kernel(uint32_t *msgw, int kwords, int k, uint64_t seed,
 }
 
 // one thread per (frame, transmitted or punctured position n)
-__global__ __launch_bounds__(256) void sim_frame_kernel(SimDev s, const uint32_t *__restrict__ msgw, float *__restrict__ llr,
+template <typename OT>
+__global__ __launch_bounds__(256) void sim_frame_kernel(SimDev s, const uint32_t *__restrict__ msgw, OT *__restrict__ llr,
                                                         uint8_t *__restrict__ msg_bytes, uint64_t seed, uint64_t first_frame,
                                                         int batch, float sigma, float llr_scale) {
     const int n = blockIdx.x * blockDim.x + threadIdx.x;
@@ -83,7 +85,8 @@ __global__ __launch_bounds__(256) void sim_frame_kernel(SimDev s, const uint32_t
     } else if (n < s.k && msg_bytes) {
         msg_bytes[(size_t)f * s.k + n] = (uint8_t)((msgw[(size_t)f * s.kwords + (n >> 5)] >> (n & 31)) & 1u);
     }
-    llr[(size_t)f * s.N + n] = out;
+    if constexpr (sizeof(OT) == 2) llr[(size_t)f * s.N + n] = __float2half_rn(fminf(fmaxf(out, -65504.f), 65504.f));  // = round_f16
+    else llr[(size_t)f * s.N + n] = out;
 }
 
 // tally[0..3] += {frames, frame errors, message-bit errors, sum of iterations}; one wave per frame
@@ -107,13 +110,18 @@ __global__ __launch_bounds__(256) void sim_tally_kernel(SimDev s, const uint32_t
 }
 
 int sim_generate(const SimDev &s, uint32_t *msgw, hipStream_t st, uint64_t seed, uint64_t first_frame, int batch,
-                 double ebn0_db, float *d_llr, uint8_t *d_msg) {
+                 double ebn0_db, void *d_llr, int llr_f16, uint8_t *d_msg) {
     const double R = (double)s.k / (double)s.n_tx;
     const double sigma2 = 1.0 / (2.0 * R * pow(10.0, ebn0_db / 10.0));
     size_t nw = (size_t)batch * s.kwords;
     hipLaunchKernelGGL(sim_msg_kernel, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, st, msgw, s.kwords, s.k, seed, first_frame, batch, s.gt ? 0 : 1);
-    hipLaunchKernelGGL(sim_frame_kernel, dim3((s.N + 255) / 256, batch), dim3(256), 0, st, s, msgw, d_llr, d_msg, seed, first_frame, batch,
-                       (float)sqrt(sigma2), (float)(2.0 / sigma2));
+    const dim3 grid((s.N + 255) / 256, batch);
+    if (llr_f16)
+        hipLaunchKernelGGL(sim_frame_kernel<__half>, grid, dim3(256), 0, st, s, msgw, (__half *)d_llr, d_msg, seed, first_frame, batch,
+                           (float)sqrt(sigma2), (float)(2.0 / sigma2));
+    else
+        hipLaunchKernelGGL(sim_frame_kernel<float>, grid, dim3(256), 0, st, s, msgw, (float *)d_llr, d_msg, seed, first_frame, batch,
+                           (float)sqrt(sigma2), (float)(2.0 / sigma2));
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return set_error(LDPC_EHIP, "sim_generate: %s", hipGetErrorString(e));
     return LDPC_OK;

@@ -52,7 +52,11 @@ typedef enum { LDPC_TANH = 0, LDPC_MINSUM = 1 } ldpc_variant;
 /* arithmetic / storage type of LLRs and messages on the device.
  * F32: the cudabits kernels' `typedef float float_ty` (cudabits/common.h:1).
  * F64: parity mode, same type as the CPU reference (Double).
- * F16: fp16 storage of messages/LLRs in HBM, fp32 arithmetic (BASELINE.json configs[3]). */
+ * F16: fp16 storage of whatever the decoder keeps in HBM, fp32 arithmetic (BASELINE.json configs[3]):
+ *      every LLR given to an F16 context counts as stored in fp16 (saturating round-to-nearest-even on load);
+ *      the flood path also keeps lam and the messages in fp16 between its kernels, the fused paths keep them
+ *      on-chip in f32 -- so for F16 the two paths are two different (documented) decoders, each with its own
+ *      emulation in oracle/emulate_f16.py, whereas for F32/F64 they agree bit for bit. */
 typedef enum { LDPC_F32 = 0, LDPC_F64 = 1, LDPC_F16 = 2 } ldpc_dtype;
 /* which kernel family a context uses */
 typedef enum {
@@ -121,6 +125,14 @@ int ldpc_decode_batch_f64(ldpc_ctx *ctx, int max_iters, int batch, const double 
  * d_llr on another stream must pass that stream here (or synchronise first). */
 int ldpc_decode_batch_dev(ldpc_ctx *ctx, int max_iters, int batch, const float *d_llr,
                           uint8_t *d_bits, int32_t *d_iters, uint8_t *d_converged, void *stream);
+/* fp16 channel LLRs (IEEE binary16 bit patterns; BASELINE.json configs[3] "min-sum fp16 LLRs"): the same two
+ * throughput entry points with half the bytes per frame over PCIe / out of HBM.  Accepted by a context of any
+ * dtype (the values convert exactly to f32/f64).  No counterpart in the reference, whose CUDA path pokes
+ * float32 (GPU/CUDA/Arraylet2.hs:151-160). */
+int ldpc_decode_batch_f16(ldpc_ctx *ctx, int max_iters, int batch, const uint16_t *llr, uint8_t *bits,
+                          int32_t *iters, uint8_t *converged);
+int ldpc_decode_batch_dev_f16(ldpc_ctx *ctx, int max_iters, int batch, const uint16_t *d_llr,
+                              uint8_t *d_bits, int32_t *d_iters, uint8_t *d_converged, void *stream);
 /* page-locked host memory for the host-pointer entry points: with buffers from ldpc_host_alloc the chunked
  * H2D / decode / D2H pipeline inside ldpc_decode_batch runs at PCIe speed instead of the pageable-copy
  * rate (the reference pokes pageable Storable vectors, GPU/CUDA/Arraylet2.hs:158-159).  NULL on failure. */
@@ -169,6 +181,10 @@ void ldpc_sim_destroy(ldpc_sim *sim);
  * the next ldpc_sim_tally call. */
 int ldpc_sim_generate(ldpc_sim *sim, uint64_t seed, uint64_t first_frame, int batch, double ebn0_db,
                       float *d_llr, uint8_t *d_msg, void *stream);
+/* same frames, LLRs written as fp16 (= the float32 values of ldpc_sim_generate, saturated to +-65504 and rounded
+ * to nearest even) for ldpc_decode_batch_dev_f16 */
+int ldpc_sim_generate_f16(ldpc_sim *sim, uint64_t seed, uint64_t first_frame, int batch, double ebn0_db,
+                          uint16_t *d_llr, uint8_t *d_msg, void *stream);
 /* d_tally[4] (device, uint64) += {frames, frame errors, message-bit errors, sum of iterations}
  * for the frames of the last ldpc_sim_generate call; d_iters may be NULL. */
 int ldpc_sim_tally(ldpc_sim *sim, int batch, const uint8_t *d_bits, const int32_t *d_iters,

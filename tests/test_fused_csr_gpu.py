@@ -24,7 +24,7 @@ def test_auto_path(hip, name, iters, dbs):
     c = load(name)
     for variant in ("min", "tanh"):
         assert hip.Decoder(_code(hip, c), variant, "f32", 8).path == "fused"
-    assert hip.Decoder(_code(hip, c), "min", "f16", 8).path == "flood"
+    assert hip.Decoder(_code(hip, c), "min", "f16", 8).path == "fused"   # fp16 LLRs, state on-chip in f32
     big = load("jpl.4096.4.5")  # as a CSR graph: 2N + 20M floats = 168 KB > 160 KB of LDS
     assert hip.Decoder(_code(hip, big), "min", "f32", 8).path == "flood"
     with pytest.raises(hip.LdpcError) as e:

@@ -24,6 +24,12 @@
 #ifndef SPLIT_WAVES_PER_EU
 #define SPLIT_WAVES_PER_EU 4
 #endif
+// the tanh rule needs ~3 transient registers per edge of a row (q, suffix product, suffix complement): at 128
+// VGPRs it spills ~450 registers (2.44 Gbit/s on jpl.4096), at 3 waves per SIMD / 168 VGPRs 90 (4.16), at
+// 2 waves / 223 VGPRs none (4.26)
+#ifndef SPLIT_TANH_WAVES_PER_EU
+#define SPLIT_TANH_WAVES_PER_EU 2
+#endif
 
 namespace ldpc {
 
@@ -325,7 +331,8 @@ template <int SZ> struct SplitGeom {
 };
 
 template <typename CT, int VARIANT, class Plan, int SZ, class T>
-__global__ __launch_bounds__((SplitGeom<SZ>::THREADS), SPLIT_WAVES_PER_EU) void fused_split_kernel(FusedArgs A) {
+__global__ __launch_bounds__((SplitGeom<SZ>::THREADS), (VARIANT == LDPC_V_TANH ? SPLIT_TANH_WAVES_PER_EU : SPLIT_WAVES_PER_EU))
+void fused_split_kernel(FusedArgs A) {
     using G = SplitGeom<SZ>;
     static_assert((SZ & (SZ - 1)) == 0 && SZ >= 16, "circulant size must be a power of two");
     __shared__ __attribute__((aligned(16))) char lds[Plan::NBC * G::V * (int)sizeof(CT) + 4 * G::NW];

@@ -12,12 +12,11 @@
 // Two numerics families:
 //   * double: the reference's own formulas, same operation order (parity mode; min-sum is
 //     bit-exact with the CPU reference, tanh differs only by the device libm's last ulp).
-//   * float : min-sum uses the same formulas; the tanh rule is evaluated in the phi domain
-//     (phi(x) = -ln tanh(x/2) = 2 atanh(e^-x)):  |ne'| = phi( sum_{j/=n} phi(|t_j|) ), which is
-//     the same real-valued function as the tanh product but does not saturate where fp32 tanh
-//     rounds to 1.  The +-37.43 clamp is applied where the double
-//     reference applies it (its product rounds to exactly +-1 <=> every factor has
-//     |t_j|/2 >= 19.0615, i.e. the true value is >= 37.43 anyway).
+//   * float : min-sum uses the same formulas; the tanh rule is evaluated in a product/complement
+//     form (cn_tanh_f32 below): the same real-valued function as the tanh product, but it does not
+//     saturate where an fp32 tanh rounds to 1.  The +-37.43 clamp is
+//     applied where the double reference applies it (its product rounds to exactly +-1 <=> every factor
+//     has |t_j|/2 >= 19.0615, i.e. the true value is >= 37.43 anyway).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <hip/hip_fp16.h>
@@ -72,33 +71,6 @@ template <typename CT> __device__ __forceinline__ CT maybe_round_f16(CT v, int o
     else return v;
 }
 
-// ---------------------------------------------------------------- phi (float)
-// phi(x) = -ln(tanh(x/2)),  x >= 0.  Branch-free, 4 hardware transcendentals (v_exp, 2 v_rcp, v_log;
-// ~1 ulp each), two regimes sharing ONE logarithm:
-//   x <  0.5 : phi = -ln(x/2) + x^2/12 - 7x^4/1440 + 31x^6/90720        (1 - e^-x would cancel here)
-//   x >= 0.5 : phi = log1p(w), w = 2e/(1-e), e = e^-x;  log1p(w) = ln(1+w) * w/((1+w)-1), or w itself
-//              once 1+w rounds to 1 (the classic correction of the rounding of 1+w)
-// phi(0) = +inf and phi(+inf) = 0 EXACTLY: a zero factor makes the reference's tanh product, and so
-// its messages, exactly zero (Orig.hs:86-91) and that has to survive.  Emulated in float32 against the
-// double formula: relative error <= 1.1e-6 for x <= 20 (worst 10..20, from the rounding of x*log2 e),
-// absolute error <= 1.7e-6 everywhere.
-__device__ __forceinline__ float phi_f32(float x) {
-    const float e = __builtin_amdgcn_exp2f(x * -1.44269504088896340736f);
-    const float d = fmaxf(1.0f - e, 1.4901161193847656e-08f);
-    const float w = (e + e) * __builtin_amdgcn_rcpf(d);
-    const float u = 1.0f + w;
-    const float um1 = u - 1.0f;
-    const bool small = x < 0.5f;
-    const float lg = __builtin_amdgcn_logf(small ? 0.5f * x : u) * 0.69314718055994530942f;
-    const float x2 = x * x;
-    float p = fmaf(-x2, 31.0f / 90720.0f, 7.0f / 1440.0f);
-    p = fmaf(-x2, p, 1.0f / 12.0f);
-    const float rs = fmaf(x2, p, -lg);
-    float rb = lg * (w * __builtin_amdgcn_rcpf(um1));
-    rb = (um1 == 0.0f) ? w : rb;
-    return small ? rs : rb;
-}
-
 // ---------------------------------------------------------------- check-node update, DEG known
 // t[k] = lam_k - ne_k (the reference's list element is -(t[k]) for min-sum and
 // tanh(-(t[k]/2)) for the tanh rule).  Results overwrite t[k] with ne'_k.
@@ -144,9 +116,34 @@ __device__ __forceinline__ void cn_tanh_f64(double (&t)[DEG]) {
     }
 }
 
-// tanh rule, float, phi domain with prefix/suffix leave-one-out sums (no subtraction, so no
-// cancellation when one small |t| dominates the sum).  In place: t[k] becomes phi(|t_k|) after its sign
-// went into a bit word; one extra array holds the suffix sums.
+// tanh rule, float: "product / complement" form.  With a_j = |t_j|, e_j = e^-a_j:
+//     h_j = tanh(a_j / 2) = (1 - e_j) / (1 + e_j),     q_j = 1 - h_j = 2 e_j / (1 + e_j)
+//     p   = prod_{j /= k} h_j                           (relatively accurate while it is small)
+//     c   = 1 - prod_{j /= k} (1 - q_j)                 (relatively accurate while IT is small: built with
+//                                                        c (+) q = c + q (1 - c), a sum of positive terms)
+//     |ne'_k| = 2 atanh p = ln((1 + p) / (1 - p)) = ln(1 + 2 p / c)
+// This is the same real function as Orig.hs:86-91 but never forms 1 - p by subtraction, so it does not saturate
+// where an fp32 tanh product rounds to 1; p and c come from prefix/suffix
+// recurrences (leave-one-out without division).  4 hardware transcendentals per edge (v_exp, 2 v_rcp, v_log);
+// the phi-domain form this replaces needed 8.  A zero t_j gives e = 1, q = 1, h = 0 EXACTLY, hence p = 0 and
+// ne' = 0 exactly for the other edges of the row, as in the reference (a zero factor zeroes its product).
+// c = 0 (every other |t| enormous) gives ln(inf) -> the +-37.43 clamp, which is where the double reference
+// clamps as well (its product rounds to exactly +-1).  Emulated in float32 with +-1 ulp transcendentals against
+// the exact value: error <= 1e-6 * max(1, |ne'|) for row weights 3..18 and |t| up to 100.
+struct TanhPC {
+    // q = 1 - tanh(a/2) for a >= 0 (a = +inf -> 0)
+    static __device__ __forceinline__ float q_of(float a) {
+        const float e = __builtin_amdgcn_exp2f(a * -1.44269504088896340736f);
+        return (e + e) * __builtin_amdgcn_rcpf(1.0f + e);
+    }
+    static __device__ __forceinline__ float join(float c, float q) { return fmaf(q, 1.0f - c, c); }  // c (+) q
+    static __device__ __forceinline__ float mag(float p, float c) {
+        const float w = (p + p) * __builtin_amdgcn_rcpf(c);
+        const float m = __builtin_amdgcn_logf(1.0f + w) * 0.69314718055994530942f;
+        return fminf(m, (float)kNeClamp);  // also turns the NaN/inf of c == 0 into the clamp value
+    }
+};
+
 template <int DEG>
 __device__ __forceinline__ void cn_tanh_f32(float (&t)[DEG]) {
     static_assert(DEG <= 32, "sign word holds 32 edges");
@@ -156,22 +153,27 @@ __device__ __forceinline__ void cn_tanh_f32(float (&t)[DEG]) {
         uint32_t tb = __float_as_uint(t[k]);
         X ^= tb;
         sg = __builtin_amdgcn_alignbit(sg, tb, 31);
-        t[k] = phi_f32(fabsf(t[k]));
+        t[k] = TanhPC::q_of(fabsf(t[k]));
     }
-    float suf[DEG];
-    float run = 0.f;
+    float psuf[DEG], csuf[DEG];
+    float pr = 1.f, cr = 0.f;
 #pragma unroll
-    for (int k = DEG - 1; k >= 0; k--) { suf[k] = run; run += t[k]; }
+    for (int k = DEG - 1; k >= 0; k--) {
+        psuf[k] = pr; csuf[k] = cr;
+        pr *= 1.0f - t[k];
+        cr = TanhPC::join(cr, t[k]);
+    }
     // factor_j = tanh(-(t_j/2)) is negative iff t_j > 0; with zero factors the magnitude is 0 and the sign
     // is irrelevant, so "t_j > 0" may be read off the sign bit: negative factors among j != k are
     // (DEG-1) - sum_{j != k} signbit_j.  ne'_k = -sign(prod) * mag: positive iff that count is odd.
     const uint32_t base = X ^ ((DEG & 1) ? 0u : 0x80000000u);  // bit 31: parity((DEG-1) + all sign bits)
-    float pre = 0.f;
+    pr = 1.f; cr = 0.f;
 #pragma unroll
     for (int k = 0; k < DEG; k++) {
-        float S = pre + suf[k];
-        pre += t[k];
-        float mag = fminf(phi_f32(S), (float)kNeClamp);
+        const float q = t[k];
+        const float mag = TanhPC::mag(pr * psuf[k], TanhPC::join(cr, csuf[k]));
+        pr *= 1.0f - q;
+        cr = TanhPC::join(cr, q);
         // count parity for edge k = base ^ signbit_k ; ne' > 0 iff odd -> sign bit of ne' = NOT that
         uint32_t sk = (sg << (31 - (DEG - 1 - k)));
         uint32_t neg = ~(base ^ sk) & 0x80000000u;
@@ -243,19 +245,24 @@ __device__ __forceinline__ void cn_update_padded(CT (&t)[DMAX], int deg) {
             uint32_t tb = __float_as_uint(t[k]);
             X ^= tb;
             sg = __builtin_amdgcn_alignbit(sg, tb, 31);
-            t[k] = phi_f32(fabsf(t[k]));
+            t[k] = TanhPC::q_of(fabsf(t[k]));   // padding: a = +inf -> e = 0 -> q = 0, h = 1: neutral
         }
-        float suf[DMAX];
-        float run = 0.f;
+        float psuf[DMAX], csuf[DMAX];
+        float pr = 1.f, cr = 0.f;
 #pragma unroll
-        for (int k = DMAX - 1; k >= 0; k--) { suf[k] = run; run += t[k]; }
+        for (int k = DMAX - 1; k >= 0; k--) {
+            psuf[k] = pr; csuf[k] = cr;
+            pr *= 1.0f - t[k];
+            cr = TanhPC::join(cr, t[k]);
+        }
         const uint32_t base = X ^ ((deg & 1) ? 0u : 0x80000000u);
-        float pre = 0.f;
+        pr = 1.f; cr = 0.f;
 #pragma unroll
         for (int k = 0; k < DMAX; k++) {
-            float S = pre + suf[k];
-            pre += t[k];
-            float mag = fminf(phi_f32(S), (float)kNeClamp);
+            const float q = t[k];
+            const float mag = TanhPC::mag(pr * psuf[k], TanhPC::join(cr, csuf[k]));
+            pr *= 1.0f - q;
+            cr = TanhPC::join(cr, q);
             uint32_t sk = (sg << (31 - (DMAX - 1 - k)));
             uint32_t neg = ~(base ^ sk) & 0x80000000u;
             t[k] = __uint_as_float(__float_as_uint(mag) | neg);

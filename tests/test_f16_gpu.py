@@ -53,8 +53,11 @@ def test_flood_f16_minsum_teacher_forced_step(hip, name, iters, dbs):
 
 @pytest.mark.parametrize("name,iters,dbs", CASES)
 def test_flood_f16_tanh_teacher_forced_step(hip, name, iters, dbs):
-    """tanh rule: the kernel's f32 phi arithmetic is not reproducible bit for bit, so each stored message must be
-    the fp16 neighbour of the exactly computed value: within one fp16 ulp everywhere, identical almost always."""
+    """tanh rule: the kernel's f32 arithmetic (hardware exp/rcp/log) is not reproducible bit for bit, so each stored
+    message must be an fp16 neighbour of the exactly computed value: within one fp16 ulp everywhere, identical
+    almost always (the f32 result carries ~6e-8 ABSOLUTE error from forming 1 + w, i.e. up to ~1e-5 relative on
+    the small messages of weight-18 rows, against an fp16 half-ulp of 2.4e-4: a few per cent land on the other
+    neighbour)."""
     c = load(name)
     rng = np.random.default_rng(78)
     F = 6
@@ -78,7 +81,7 @@ def test_flood_f16_tanh_teacher_forced_step(hip, name, iters, dbs):
     want = em.r16(exact.astype(np.float32)).astype(np.float64)
     ulp = np.maximum(np.abs(want), 2.0 ** -14) * 2.0 ** -10
     assert (np.abs(ne2 - want) <= ulp).all()
-    assert (ne2 == want).mean() > 0.97
+    assert (ne2 == want).mean() > 0.94
     # lam' = r16(orig + sum of the kernel's OWN stored messages, descending rows, f32): exact given ne2
     acc = orig.copy()
     for m in reversed(range(g.M)):

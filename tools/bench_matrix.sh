@@ -4,11 +4,15 @@ mkdir -p gpurun_out; out=gpurun_out/bench_matrix.jsonl; : > $out
 run() { echo "# $*" >&2; python bench.py --cpu-seconds 0 "$@" 2>/dev/null | tail -1 >> $out; }
 run --steps 6 --warmup 2                                              # headline: jpl.4096 min-sum f32 (fused)
 LDPC_HIP_PATH=flood run --steps 3 --warmup 1 --batch 16384            # same on the generic flood path
-run --steps 3 --warmup 1 --batch 16384 --dtype f16                    # configs[3]: fp16 storage (flood)
+run --steps 6 --warmup 2 --dtype f16                                  # configs[3]: fp16 LLRs, fused (state on-chip in f32)
+LDPC_HIP_PATH=flood run --steps 3 --warmup 1 --batch 16384 --dtype f16 # configs[3] on the flood path: fp16 lam/messages in HBM
 run --steps 3 --warmup 1 --batch 16384 --variant tanh                 # tanh rule, fused
 LDPC_HIP_PATH=flood run --steps 3 --warmup 1 --batch 16384 --variant tanh
 run --steps 6 --warmup 2 --code jpl.1024.4.5                          # configs[1]
-for db in 1 2 3 4; do run --steps 3 --warmup 1 --code 1920.1280.3.303 --rate none --variant tanh --ebn0 $db; done   # configs[2]
+run --steps 3 --warmup 1 --batch 16384 --code jpl.1024.4.5 --variant tanh
+for db in 1 2 3 4; do run --steps 3 --warmup 1 --code 1920.1280.3.303 --rate none --variant tanh --ebn0 $db; done   # configs[2], generic on-chip kernel
+LDPC_HIP_PATH=flood run --steps 3 --warmup 1 --code 1920.1280.3.303 --rate none --variant tanh --ebn0 1
+run --steps 3 --warmup 1 --code 1920.1280.3.303 --rate none --variant minsum --ebn0 1
 python - <<'PY'
 import json
 for l in open('gpurun_out/bench_matrix.jsonl'):

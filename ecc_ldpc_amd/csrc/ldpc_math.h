@@ -183,7 +183,7 @@ __device__ __forceinline__ void cn_tanh_f32(float (&t)[DEG]) {
 
 // ---------------------------------------------------------------- padded rows (generic on-chip kernel)
 // Rows of any degree <= DMAX: slots k >= deg hold t = +inf, which is neutral for both rules
-// (|t| = inf never wins a min; phi(inf) = 0 adds nothing; sign bit 0) -- only the "(D odd)" term of the
+// (|t| = inf never wins a min; q(inf) = 0 is the neutral factor; sign bit 0) -- only the "(D odd)" term of the
 // sign rule needs the real degree.  Results for the real slots are bit-identical to cn_update<deg>.
 template <typename CT, int VARIANT, int DMAX>
 __device__ __forceinline__ void cn_update_padded(CT (&t)[DMAX], int deg) {

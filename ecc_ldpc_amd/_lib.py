@@ -149,7 +149,7 @@ def lib():
 
 
 def last_error() -> str:
-    return lib().ldpc_last_error().decode()
+    return lib().ldpc_last_error().decode(errors="replace")
 
 
 def check(rc):

@@ -21,6 +21,9 @@ int set_error(int code, const char *fmt, ...) {
     va_start(ap, fmt);
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
+    // messages may quote bytes of a damaged input file: keep the text printable ASCII
+    for (char *q = g_err; *q; q++)
+        if ((unsigned char)*q < 0x20 || (unsigned char)*q > 0x7e) *q = '?';
     return code;
 }
 }  // namespace ldpc
@@ -128,7 +131,8 @@ static int finish_code(ldpc_code *c) {
 }
 
 ldpc_code *ldpc_code_create_csr(int M, int N, const int32_t *row_ptr, const int32_t *col_idx) {
-    if (M <= 0 || N <= 0 || !row_ptr || !col_idx || row_ptr[0] != 0 || row_ptr[M] < 0) {
+    if (M <= 0 || N <= 0 || M > (1 << 24) || N > (1 << 24) || !row_ptr || !col_idx || row_ptr[0] != 0 || row_ptr[M] < 0 ||
+        row_ptr[M] > (1 << 30)) {
         set_error(LDPC_EINVAL, "ldpc_code_create_csr: bad arguments (M=%d N=%d)", M, N);
         return nullptr;
     }
@@ -146,6 +150,19 @@ ldpc_code *ldpc_code_create_csr(int M, int N, const int32_t *row_ptr, const int3
 ldpc_code *ldpc_code_create_qc(int sz, int block_rows, int block_cols, const int32_t *offsets) {
     if (sz <= 0 || block_rows <= 0 || block_cols <= 0 || !offsets) {
         set_error(LDPC_EINVAL, "ldpc_code_create_qc: bad arguments (sz=%d %dx%d)", sz, block_rows, block_cols);
+        return nullptr;
+    }
+    // expanded sizes must stay well inside int32 (edge ids are int32): M, N <= 2^24, E <= 2^30
+    const long long kMaxDim = 1ll << 24;
+    if ((long long)sz * block_rows > kMaxDim || (long long)sz * block_cols > kMaxDim ||
+        (long long)block_rows * block_cols > (1ll << 24)) {
+        set_error(LDPC_EUNSUPPORTED, "ldpc_code_create_qc: %d x %d blocks of size %d expand beyond 2^24 rows/columns", block_rows, block_cols, sz);
+        return nullptr;
+    }
+    long long nnz_blocks = 0;
+    for (int i = 0; i < block_rows * block_cols; i++) nnz_blocks += offsets[i] >= 0;
+    if (nnz_blocks * sz > (1ll << 30)) {
+        set_error(LDPC_EUNSUPPORTED, "ldpc_code_create_qc: %lld edges exceed 2^30", nnz_blocks * sz);
         return nullptr;
     }
     for (int i = 0; i < block_rows * block_cols; i++)
@@ -217,8 +234,11 @@ static int code_upload(ldpc_code *c, int device) {
     };
     int rc;
     if ((rc = up(&c->d_row_ptr, c->row_ptr)) || (rc = up(&c->d_col_idx, c->col_idx)) ||
-        (rc = up(&c->d_col_ptr, c->col_ptr)) || (rc = up(&c->d_csc_edge, c->csc_edge)))
+        (rc = up(&c->d_col_ptr, c->col_ptr)) || (rc = up(&c->d_csc_edge, c->csc_edge))) {
+        (void)hipFree(c->d_row_ptr); (void)hipFree(c->d_col_idx); (void)hipFree(c->d_col_ptr); (void)hipFree(c->d_csc_edge);
+        c->d_row_ptr = c->d_col_idx = c->d_col_ptr = c->d_csc_edge = nullptr;   // a half-uploaded graph is not kept
         return rc;
+    }
     c->device = device;
     return LDPC_OK;
 }
@@ -498,17 +518,19 @@ int ldpc_debug_step(ldpc_ctx *ctx, int batch, const double *orig, const double *
     if (hipMalloc((void **)&d_syn, B) != hipSuccess) { hipFree(buf); return set_error(LDPC_ENOMEM, "hipMalloc"); }
     double *d_orig = buf, *d_lam = buf + B * N, *d_lam_out = buf + 2 * B * N, *d_ne = buf + 3 * B * N, *d_ne_out = d_ne + B * E;
     hipStream_t st = ctx->stream;
-    hipMemcpyAsync(d_orig, orig, B * N * 8, hipMemcpyHostToDevice, st);
-    hipMemcpyAsync(d_lam, lam, B * N * 8, hipMemcpyHostToDevice, st);
-    hipMemcpyAsync(d_ne, ne, B * E * 8, hipMemcpyHostToDevice, st);
-    if (ctx->path == LDPC_PATH_FUSED)
+    hipError_t ce = hipMemcpyAsync(d_orig, orig, B * N * 8, hipMemcpyHostToDevice, st);
+    if (ce == hipSuccess) ce = hipMemcpyAsync(d_lam, lam, B * N * 8, hipMemcpyHostToDevice, st);
+    if (ce == hipSuccess) ce = hipMemcpyAsync(d_ne, ne, B * E * 8, hipMemcpyHostToDevice, st);
+    if (ce != hipSuccess) rc = set_error(LDPC_EHIP, "debug_step upload: %s", hipGetErrorString(ce));
+    else if (ctx->path == LDPC_PATH_FUSED)
         rc = ldpc::fused_step(*ctx->fused, st, batch, d_orig, d_lam, d_ne, d_ne_out, d_lam_out, d_syn);
     else
         rc = ldpc::flood_step(ctx->flood, st, batch, d_orig, d_lam, d_ne, d_ne_out, d_lam_out, d_syn);
     if (rc == LDPC_OK) {
-        hipMemcpyAsync(ne_out, d_ne_out, B * E * 8, hipMemcpyDeviceToHost, st);
-        hipMemcpyAsync(lam_out, d_lam_out, B * N * 8, hipMemcpyDeviceToHost, st);
-        if (syndrome_zero) hipMemcpyAsync(syndrome_zero, d_syn, B, hipMemcpyDeviceToHost, st);
+        ce = hipMemcpyAsync(ne_out, d_ne_out, B * E * 8, hipMemcpyDeviceToHost, st);
+        if (ce == hipSuccess) ce = hipMemcpyAsync(lam_out, d_lam_out, B * N * 8, hipMemcpyDeviceToHost, st);
+        if (ce == hipSuccess && syndrome_zero) ce = hipMemcpyAsync(syndrome_zero, d_syn, B, hipMemcpyDeviceToHost, st);
+        if (ce != hipSuccess) rc = set_error(LDPC_EHIP, "debug_step download: %s", hipGetErrorString(ce));
     }
     hipError_t e = hipStreamSynchronize(st);
     if (rc == LDPC_OK && e != hipSuccess) rc = set_error(LDPC_EHIP, "debug_step: %s", hipGetErrorString(e));

@@ -51,6 +51,10 @@ static int limb_top(const std::vector<uint32_t> &l) {  // index of highest set b
     return -1;
 }
 
+// largest matrix the loaders expand to bytes (the reference's Matrix Bool is dense too); bigger graphs come in as CSR
+static constexpr size_t kMaxDenseBytes = (size_t)1 << 31;
+static constexpr size_t kMaxDim = (size_t)1 << 24;   // rows / columns of an expanded matrix (int32 edge ids stay safe)
+
 struct ldpc_matrix {
     int rows = 0, cols = 0;                       // EXPANDED size (getNRows/getNCols, Loader.hs:31-46)
     int sz = 0, brows = 0, bcols = 0;             // quasi-cyclic description when sz > 0
@@ -102,6 +106,8 @@ static int parse_q(const std::string &text, ldpc_matrix *m) {
     if (!have_sz || rows.empty()) return set_error(LDPC_EFORMAT, ".q: empty matrix");
     m->brows = (int)rows.size();
     m->bcols = (int)rows[0].size();
+    if ((size_t)m->brows * m->sz > kMaxDim || (size_t)m->bcols * m->sz > kMaxDim)
+        return set_error(LDPC_EUNSUPPORTED, ".q: %d x %d blocks of size %d expand beyond %zu rows/columns", m->brows, m->bcols, m->sz, kMaxDim);
     m->blocks.resize((size_t)m->brows * m->bcols);
     for (int r = 0; r < m->brows; r++) {
         if ((int)rows[r].size() != m->bcols) return set_error(LDPC_EFORMAT, ".q: ragged row %d", r);
@@ -129,6 +135,12 @@ static int parse_alist_reference(const std::string &text, ldpc_matrix *m) {
     auto item = [&](long &v) { if (pos >= t.size()) return false; v = t[pos++]; return true; };
     long n, mm, ign;
     if (!item(n) || !item(mm) || !item(ign) || !item(ign) || n <= 0 || mm <= 0) return set_error(LDPC_EFORMAT, "alist: truncated header");
+    // the counts alone need n + mm tokens: checked BEFORE anything is sized by the header (a damaged header must
+    // not turn into a multi-gigabyte allocation)
+    if ((unsigned long)n > t.size() || (unsigned long)mm > t.size() || (size_t)n + (size_t)mm > t.size() - pos)
+        return set_error(LDPC_EFORMAT, "alist: header says %ld x %ld but the file holds %zu numbers", n, mm, t.size());
+    if ((size_t)n * (size_t)mm > kMaxDenseBytes)
+        return set_error(LDPC_EUNSUPPORTED, "alist: %ld x %ld is beyond the dense loader's limit; pass the graph as CSR", n, mm);
     std::vector<long> num_n((size_t)n), num_m((size_t)mm);
     for (auto &v : num_n) if (!item(v)) return set_error(LDPC_EFORMAT, "alist: truncated row counts");
     for (auto &v : num_m) if (!item(v)) return set_error(LDPC_EFORMAT, "alist: truncated column counts");
@@ -155,6 +167,10 @@ static int parse_alist_mackay(const std::string &text, ldpc_matrix *m) {
     if (t.size() < 4) return set_error(LDPC_EFORMAT, "alist: truncated header");
     long N = t[0], M = t[1], maxc = t[2], maxr = t[3];
     if (N <= 0 || M <= 0 || maxc <= 0 || maxr <= 0) return set_error(LDPC_EFORMAT, "alist: bad header");
+    if ((unsigned long)N > t.size() || (unsigned long)M > t.size() || (unsigned long)maxc > t.size() || (unsigned long)maxr > t.size())
+        return set_error(LDPC_EFORMAT, "alist: header %ld %ld %ld %ld is larger than the file (%zu numbers)", N, M, maxc, maxr, t.size());
+    if ((size_t)N * (size_t)M > kMaxDenseBytes)
+        return set_error(LDPC_EUNSUPPORTED, "alist: %ld x %ld is beyond the dense loader's limit; pass the graph as CSR", M, N);
     size_t need = 4 + (size_t)N + M + (size_t)N * maxc + (size_t)M * maxr;
     if (t.size() < need) return set_error(LDPC_EFORMAT, "alist: %zu tokens, MacKay layout needs %zu", t.size(), need);
     size_t pos = 4;

@@ -4,6 +4,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import sys
 
 import numpy as np
 
@@ -69,6 +70,15 @@ def lib():
     global _lib
     if _lib is not None:
         return _lib
+    if not os.path.exists(SO_PATH) and "LDPC_SO" not in os.environ:
+        # a fresh checkout (built artefacts are not in git): compile the product, never substitute for it
+        try:
+            from . import build as _build
+            print(f"[ecc_ldpc_amd] {SO_PATH} missing: building it with hipcc", file=sys.stderr, flush=True)
+            _build.build(verbose=False)
+        except Exception as e:
+            raise ImportError(f"{SO_PATH} is missing and could not be built ({e}); run `python ecc_ldpc_amd/build.py` "
+                              "(the HIP library is the only decode path; there is no fallback)") from e
     if not os.path.exists(SO_PATH):
         raise ImportError(f"{SO_PATH} is missing: build it with `python ecc_ldpc_amd/build.py` "
                           "(the HIP library is the only decode path; there is no fallback)")

@@ -13,17 +13,20 @@ s2 = 1.0 / (2 * 0.8 * 10 ** 0.2)
 llr = np.zeros((B, N), np.float32)
 llr[:, :n_tx] = (2.0 * (-1.0 + rng.normal(0, np.sqrt(s2), (B, n_tx)).astype(np.float32)) / s2)
 ecc.decoder.decode_batch(llr[:1024], 50)
-pin_in = E.PinnedArray((B, N), np.float32)
 pin_out = E.PinnedArray((B, N), np.uint8)
-pin_in.array[:] = llr
-for rep in range(6):
-    pinned = rep >= 3
-    t0 = time.perf_counter()
-    if pinned:
-        bits, its, conv = ecc.decoder.decode_batch(pin_in.array, 50, out_bits=pin_out.array)
-    else:
-        bits, its, conv = ecc.decoder.decode_batch(llr, 50)
-    dt = time.perf_counter() - t0
-    print(f"ldpc_decode_batch host->host ({'pinned  ' if pinned else 'pageable'}): {B} frames in {dt * 1e3:7.1f} ms = {B * k / dt / 1e6:8.1f} Mbit/s  "
-          f"(H2D {llr.nbytes / 1e6:.0f} MB, D2H {bits.nbytes / 1e6:.0f} MB; mean iters {its.mean():.1f})", flush=True)
+for dt_np, label in ((np.float32, "f32 LLRs"), (np.float16, "fp16 LLRs")):
+    src = llr.astype(dt_np)
+    pin_in = E.PinnedArray((B, N), dt_np)
+    pin_in.array[:] = src
+    for rep in range(6):
+        pinned = rep >= 3
+        t0 = time.perf_counter()
+        if pinned:
+            bits, its, conv = ecc.decoder.decode_batch(pin_in.array, 50, out_bits=pin_out.array)
+        else:
+            bits, its, conv = ecc.decoder.decode_batch(src, 50)
+        dt = time.perf_counter() - t0
+        print(f"ldpc_decode_batch host->host {label} ({'pinned  ' if pinned else 'pageable'}): {B} frames in {dt * 1e3:7.1f} ms = {B * k / dt / 1e6:8.1f} Mbit/s  "
+              f"(H2D {src.nbytes / 1e6:.0f} MB, D2H {bits.nbytes / 1e6:.0f} MB; mean iters {its.mean():.1f})", flush=True)
+    del pin_in
 os._exit(0)

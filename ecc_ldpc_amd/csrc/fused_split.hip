@@ -155,18 +155,6 @@ __device__ __forceinline__ void split_body(const FusedArgs &A, char *lds, const 
     const Where w0(p4, A.batch);
     const uint32_t r0 = w0.r0;
     const size_t fN = w0.fN, fE = w0.fE;
-    auto llr_at = [&](size_t gi) -> CT {
-        return maybe_round_f16<CT>(load_llr<CT>(A.llr, gi, A.llr_fmt), A.llr_round16);
-    };
-
-    // ---- lam <- LLRs (or the given lam): pair P fills the block columns bc with bc % 2 == P
-    static_for<0, Plan::NBC>([&](auto bcc) {
-        constexpr int bc = decltype(bcc)::value;
-        if constexpr ((bc & 1) == P) {
-            CT v = A.step_mode ? (CT)A.st_lam[fN + bc * SZ + r0] : llr_at(fN + bc * SZ + r0);
-            lds_st<CT>(lds, p4 | (bc * V * ES), v);
-        }
-    });
     // ---- messages (own block rows) and round-0 channel LLRs (own round-0 edges)
     CT msg[S::NMSG];
     CT orig[SPLIT_ORIG_REGS ? S::NORIG : 1];
@@ -174,13 +162,26 @@ __device__ __forceinline__ void split_body(const FusedArgs &A, char *lds, const 
     for (int i = 0; i < S::NMSG; i++) msg[i] = CT(0);  // Orig.hs:64-65
 #pragma unroll
     for (int i = 0; i < (SPLIT_ORIG_REGS ? S::NORIG : 1); i++) orig[i] = CT(0);
-    static_for<0, Plan::NBC>([&](auto bcc) {
-        constexpr int bc = decltype(bcc)::value;
-        if constexpr (SPLIT_ORIG_REGS && S::oowner(bc) == P) {
-            constexpr int e0 = Rounds<T>::round0_edge(bc);
-            constexpr int os = S::oslot(bc);
-            orig[os] = llr_at(fN + bc * SZ + ((r0 + T::rot[e0]) & (SZ - 1)));
-        }
+    // ---- lam <- LLRs (or the given lam): pair P fills the block columns bc with bc % 2 == P.  One dispatch on the
+    // LLR element type around ALL of the thread's loads (46 of them): they issue back to back.
+    with_llr_format(A.llr_fmt, [&](auto fc) {
+        constexpr int FMT = decltype(fc)::value;
+        static_for<0, Plan::NBC>([&](auto bcc) {
+            constexpr int bc = decltype(bcc)::value;
+            if constexpr ((bc & 1) == P) {
+                CT v = maybe_round_f16<CT>(load_llr_as<CT, FMT>(A.llr, fN + bc * SZ + r0), A.llr_round16);
+                if (A.step_mode) v = (CT)A.st_lam[fN + bc * SZ + r0];
+                lds_st<CT>(lds, p4 | (bc * V * ES), v);
+            }
+        });
+        static_for<0, Plan::NBC>([&](auto bcc) {
+            constexpr int bc = decltype(bcc)::value;
+            if constexpr (SPLIT_ORIG_REGS && S::oowner(bc) == P) {
+                constexpr int e0 = Rounds<T>::round0_edge(bc);
+                constexpr int os = S::oslot(bc);
+                orig[os] = maybe_round_f16<CT>(load_llr_as<CT, FMT>(A.llr, fN + bc * SZ + ((r0 + T::rot[e0]) & (SZ - 1))), A.llr_round16);
+            }
+        });
     });
     if (A.step_mode) {
         static_for<0, Plan::NBR>([&](auto brc) {
@@ -307,19 +308,25 @@ __device__ __forceinline__ void split_body(const FusedArgs &A, char *lds, const 
     }
     // ---- result: hard(lam at convergence) for a converged frame, hard(channel LLR) otherwise (Orig.hs:59,69-70)
     const bool converged = (res >> 22) & 1u;
-    static_for<0, Plan::NBC>([&](auto bcc) {
-        constexpr int bc = decltype(bcc)::value;
-        if constexpr ((bc & 1) == P) {
-            size_t gi = w.fN + bc * SZ + w.r0;
-            if (converged) {
-                A.bits[gi] = (res >> (bc >> 1)) & 1u;
-            } else {
-                CT v = llr_at(gi);
-                A.bits[gi] = v > CT(0) ? 1 : 0;
-                if (A.final_lam) A.final_lam[gi] = (double)v;
-            }
-        }
-    });
+    if (converged) {
+        static_for<0, Plan::NBC>([&](auto bcc) {
+            constexpr int bc = decltype(bcc)::value;
+            if constexpr ((bc & 1) == P) A.bits[w.fN + bc * SZ + w.r0] = (res >> (bc >> 1)) & 1u;
+        });
+    } else {
+        with_llr_format(A.llr_fmt, [&](auto fc) {
+            constexpr int FMT = decltype(fc)::value;
+            static_for<0, Plan::NBC>([&](auto bcc) {
+                constexpr int bc = decltype(bcc)::value;
+                if constexpr ((bc & 1) == P) {
+                    const size_t gi = w.fN + bc * SZ + w.r0;
+                    const CT v = maybe_round_f16<CT>(load_llr_as<CT, FMT>(A.llr, gi), A.llr_round16);
+                    A.bits[gi] = v > CT(0) ? 1 : 0;
+                    if (A.final_lam) A.final_lam[gi] = (double)v;
+                }
+            });
+        });
+    }
     if (w.r0 == 0 && P == 0) {
         if (A.iters) A.iters[w.frame] = converged ? (int)(res >> 23) : turns;
         if (A.conv) A.conv[w.frame] = converged ? 1 : 0;

@@ -21,6 +21,7 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_fp16.h>
 #include "internal.h"
+#include <type_traits>
 
 #define LDPC_V_TANH 0
 #define LDPC_V_MINSUM 1
@@ -60,6 +61,18 @@ template <typename CT> __device__ __forceinline__ CT load_llr(const void *base, 
     if (fmt == LLR_F64) return (CT) reinterpret_cast<const double *>(base)[i];
     if (fmt == LLR_F16) return (CT) __half2float(reinterpret_cast<const __half *>(base)[i]);
     return (CT) reinterpret_cast<const float *>(base)[i];
+}
+// compile-time format: lets a caller dispatch on the format ONCE around a batch of loads, so that the loads
+// of one thread issue back to back instead of each sitting behind its own three-way branch
+template <typename CT, int FMT> __device__ __forceinline__ CT load_llr_as(const void *base, size_t i) {
+    if constexpr (FMT == LLR_F64) return (CT) reinterpret_cast<const double *>(base)[i];
+    else if constexpr (FMT == LLR_F16) return (CT) __half2float(reinterpret_cast<const __half *>(base)[i]);
+    else return (CT) reinterpret_cast<const float *>(base)[i];
+}
+template <class F> __device__ __forceinline__ void with_llr_format(int fmt, F &&f) {
+    if (fmt == LLR_F64) f(std::integral_constant<int, LLR_F64>{});
+    else if (fmt == LLR_F16) f(std::integral_constant<int, LLR_F16>{});
+    else f(std::integral_constant<int, LLR_F32>{});
 }
 // value a float LLR has after being stored as fp16 (LDPC_F16 contexts): saturating round-to-nearest-even
 __device__ __forceinline__ float round_f16(float v) {

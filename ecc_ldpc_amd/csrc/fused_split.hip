@@ -21,6 +21,16 @@
 #ifndef SPLIT_ORIG_REGS
 #define SPLIT_ORIG_REGS 1
 #endif
+// wave priority while in phase A (check rows: long stretches of independent VALU work) and in phase B (column
+// rounds: short, LDS-bound, barrier-separated).  Measured on jpl.4096, 65 536 frames: A=0/B=0 20.72 ms,
+// A=0/B=2 20.90, A=2/B=0 20.24 (A = 1, 2 or 3 alike).  The priority is raised after the first phase B only:
+// a workgroup that starts (global loads, first syndrome) at high priority costs 0.1-0.2 ms.
+#ifndef SPLIT_PRIO_A
+#define SPLIT_PRIO_A 2
+#endif
+#ifndef SPLIT_PRIO_B
+#define SPLIT_PRIO_B 0
+#endif
 #ifndef SPLIT_WAVES_PER_EU
 #define SPLIT_WAVES_PER_EU 4
 #endif
@@ -278,10 +288,12 @@ __device__ __forceinline__ void split_body(const FusedArgs &A, char *lds, const 
         }
         if (last) break;  // Orig.hs:70
         if (done != FULL) {
+            __builtin_amdgcn_s_setprio(SPLIT_PRIO_B);
             static_for<0, Rounds<T>::num_rounds()>([&](auto qc) {
                 split_round<CT, SZ, Plan, T, P, decltype(qc)::value, 0>(lds, p4, vmask, msg, orig, reinterpret_cast<const float *>(A.llr) + fN, r0);
                 __syncthreads();  // the next round adds into the same columns
             });
+            __builtin_amdgcn_s_setprio(SPLIT_PRIO_A);
         }
         if (A.step_mode) break;
     }

@@ -187,7 +187,7 @@ def measured_traffic(args, dec, B):
     command), scaled by frames per launch; None when no profile of this configuration is committed."""
     if not (dec.path == "fused" and args.variant == "minsum" and args.dtype == "f32"):
         return None
-    tag = {"jpl.4096.4.5": "r01_split2_jpl4096_f32_minsum", "jpl.1024.4.5": "r01_split2_jpl1024_f32_minsum"}.get(args.code)
+    tag = {"jpl.4096.4.5": "r01_split3_jpl4096_f32_minsum", "jpl.1024.4.5": "r01_split3_jpl1024_f32_minsum"}.get(args.code)
     if tag is None:
         return None
     try:

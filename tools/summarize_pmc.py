@@ -26,5 +26,6 @@ json.dump(res, open(f"{out}/{tag}_pmc.json", "w"), indent=1)
 w = mean.get("SQ_WAVES", 0)
 print(json.dumps({k: res[k] for k in ("kernel", "kernel_trace_avg_ns")}), file=sys.stderr)
 if w:
-    print(f"per wave: VALU {mean['SQ_INSTS_VALU']/w:.0f}  SALU {mean['SQ_INSTS_SALU']/w:.0f}  LDS {mean['SQ_INSTS_LDS']/w:.0f}  "
-          f"occupancy {mean["SQ_WAVE_CYCLES"]*4/(mean["GRBM_GUI_ACTIVE"]/8)/256:.1f} waves/CU (GRBM_GUI_ACTIVE summed over 8 XCDs)", file=sys.stderr)
+    occ = mean["SQ_WAVE_CYCLES"] * 4 / (mean["GRBM_GUI_ACTIVE"] / 8) / 256   # GRBM_GUI_ACTIVE is summed over the 8 XCDs
+    print(f"per wave: VALU {mean['SQ_INSTS_VALU'] / w:.0f}  SALU {mean['SQ_INSTS_SALU'] / w:.0f}  LDS {mean['SQ_INSTS_LDS'] / w:.0f}  "
+          f"occupancy {occ:.1f} waves/CU", file=sys.stderr)

@@ -94,18 +94,16 @@ __device__ void cn_row_generic(const FloodDev &d, ST *__restrict__ msg, ST *__re
             if (isinf(y)) y = (prod > 0.0 ? 1.0 : -1.0) * kAtanhClamp;
             out = -2.0 * y;
         } else {
-            float pp = 1.f, cc = 0.f;
+            TanhAS acc = TanhAS::one();
             unsigned neg = 0;
             for (int j = 0; j < deg; j++) {
                 if (j == k) continue;
                 int col = d.col_idx[ebeg + j];
                 float tj = Store<ST>::ld(lam + (size_t)col * d.Bp + b) - Store<ST>::ld(msg + (size_t)(ebeg + j) * d.Bp + b);
-                const float q = TanhPC::q_of(fabsf(tj));
-                pp *= 1.0f - q;
-                cc = TanhPC::join(cc, q);
+                acc = acc.times(TanhAS::e_of(fabsf(tj)));
                 neg ^= (tj > 0.f) ? 1u : 0u;
             }
-            float mag = TanhPC::mag(pp, cc);
+            float mag = acc.mag();
             out = neg ? mag : -mag;
         }
         Store<ST>::st(scratch + (size_t)(ebeg + k) * d.Bp + b, out);

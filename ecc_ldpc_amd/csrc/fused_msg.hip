@@ -238,7 +238,7 @@ static int launch_msg(hipStream_t st, FusedArgs &a, KernelTimer *timer) {
 bool fused_msg_has(int variant, int dtype, int sz) {
     if (!(sz == 32 || sz == 64 || sz == 128)) return false;
     if (variant == LDPC_MINSUM) return dtype == LDPC_F32 || dtype == LDPC_F64;
-    return dtype == LDPC_F32;  // tanh: f32 (product/complement form); f64 tanh stays on the flood path
+    return dtype == LDPC_F32;  // tanh: f32 (ldpc_math.h cn_tanh_f32); f64 tanh stays on the flood path
 }
 
 // which compiled-in table (if any) equals this code's rotation table: 0 = none, 1 = jpl.1024, 2 = jpl.4096

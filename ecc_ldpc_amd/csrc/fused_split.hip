@@ -34,9 +34,9 @@
 #ifndef SPLIT_WAVES_PER_EU
 #define SPLIT_WAVES_PER_EU 4
 #endif
-// the tanh rule needs ~3 transient registers per edge of a row (q, suffix product, suffix complement): at 128
-// VGPRs it spills ~450 registers (2.44 Gbit/s on jpl.4096), at 3 waves per SIMD / 168 VGPRs 90 (4.16), at
-// 2 waves / 223 VGPRs none (4.26)
+// the tanh rule needs ~3 transient registers per edge of a row (e, suffix A, suffix S): at 128 VGPRs it spills
+// ~450 registers, at 3 waves per SIMD / 168 VGPRs ~90, at 2 waves / 207 VGPRs none (measured with the
+// product/complement form: 2.44 / 4.16 / 4.26 Gbit/s on jpl.4096)
 #ifndef SPLIT_TANH_WAVES_PER_EU
 #define SPLIT_TANH_WAVES_PER_EU 2
 #endif

@@ -12,8 +12,8 @@
 // Two numerics families:
 //   * double: the reference's own formulas, same operation order (parity mode; min-sum is
 //     bit-exact with the CPU reference, tanh differs only by the device libm's last ulp).
-//   * float : min-sum uses the same formulas; the tanh rule is evaluated in a product/complement
-//     form (cn_tanh_f32 below): the same real-valued function as the tanh product, but it does not
+//   * float : min-sum uses the same formulas; the tanh rule is evaluated by a hyperbolic recurrence
+//     (cn_tanh_f32 below): the same real-valued function as the tanh product, but it does not
 //     saturate where an fp32 tanh rounds to 1.  The +-37.43 clamp is
 //     applied where the double reference applies it (its product rounds to exactly +-1 <=> every factor
 //     has |t_j|/2 >= 19.0615, i.e. the true value is >= 37.43 anyway).
@@ -129,31 +129,33 @@ __device__ __forceinline__ void cn_tanh_f64(double (&t)[DEG]) {
     }
 }
 
-// tanh rule, float: "product / complement" form.  With a_j = |t_j|, e_j = e^-a_j:
-//     h_j = tanh(a_j / 2) = (1 - e_j) / (1 + e_j),     q_j = 1 - h_j = 2 e_j / (1 + e_j)
-//     p   = prod_{j /= k} h_j                           (relatively accurate while it is small)
-//     c   = 1 - prod_{j /= k} (1 - q_j)                 (relatively accurate while IT is small: built with
-//                                                        c (+) q = c + q (1 - c), a sum of positive terms)
-//     |ne'_k| = 2 atanh p = ln((1 + p) / (1 - p)) = ln(1 + 2 p / c)
-// This is the same real function as Orig.hs:86-91 but never forms 1 - p by subtraction, so it does not saturate
-// where an fp32 tanh product rounds to 1; p and c come from prefix/suffix
-// recurrences (leave-one-out without division).  4 hardware transcendentals per edge (v_exp, 2 v_rcp, v_log);
-// the phi-domain form this replaces needed 8.  A zero t_j gives e = 1, q = 1, h = 0 EXACTLY, hence p = 0 and
-// ne' = 0 exactly for the other edges of the row, as in the reference (a zero factor zeroes its product).
-// c = 0 (every other |t| enormous) gives ln(inf) -> the +-37.43 clamp, which is where the double reference
-// clamps as well (its product rounds to exactly +-1).  Emulated in float32 with +-1 ulp transcendentals against
-// the exact value: error <= 1e-6 * max(1, |ne'|) for row weights 3..18 and |t| up to 100.
-struct TanhPC {
-    // q = 1 - tanh(a/2) for a >= 0 (a = +inf -> 0)
-    static __device__ __forceinline__ float q_of(float a) {
-        const float e = __builtin_amdgcn_exp2f(a * -1.44269504088896340736f);
-        return (e + e) * __builtin_amdgcn_rcpf(1.0f + e);
+// tanh rule, float: hyperbolic-recurrence form.  With e_j = e^-|t_j|, tanh(|t_j|/2) = (1 - e_j)/(1 + e_j), so
+//     prod_{j /= k} tanh(|t_j|/2) = N / D,    D = prod (1 + e_j),  N = prod (1 - e_j)
+//     |ne'_k| = 2 atanh(N/D) = ln((D + N) / (D - N)) = ln(A / S),     A = D + N,  S = D - N.
+// A and S obey  (A, S) (+) e  =  (A + e S,  S + e A)   starting from (2, 0): only sums of positive terms, so S
+// -- the quantity an fp32 tanh product loses when it rounds to 1 -- keeps its
+// relative accuracy, and no division is needed per factor.  Two partial results combine like cosh/sinh of a sum:
+//     (A1, S1) (+) (A2, S2) = (A1 A2 + S1 S2,  A1 S2 + S1 A2)      (a common factor 1/2 is dropped: only A/S matters)
+// which gives leave-one-out from prefix/suffix passes.  Same real function as Orig.hs:86-91; 3 hardware
+// transcendentals per edge (v_exp, v_rcp, v_log) -- the phi-domain form used first needed 8, the product/complement
+// form after it 4.  A zero t_j gives e = 1, hence A = S EXACTLY from there on (the two updates become the same
+// operation; the combine is written symmetrically, products rounded separately, for the same reason), so
+// ne' = ln(1 + (A - S)/S) = 0 exactly for the other edges of the row, as a zero factor does in the reference.
+// S = 0 (every other |t| enormous) gives ln(inf) -> the +-37.43 clamp, which is where the double reference clamps
+// as well (its product rounds to exactly +-1).  Emulated in float32 with +-1 ulp transcendentals against the exact
+// value: error <= 7e-7 * max(1, |ne'|) for row weights 2..32 and |t| up to 200.
+struct TanhAS {
+    float A, S;
+    static __device__ __forceinline__ TanhAS one() { return {2.0f, 0.0f}; }
+    static __device__ __forceinline__ float e_of(float a) { return __builtin_amdgcn_exp2f(a * -1.44269504088896340736f); }  // a >= 0
+    __device__ __forceinline__ TanhAS times(float e) const { return {fmaf(e, S, A), fmaf(e, A, S)}; }
+    __device__ __forceinline__ TanhAS times(const TanhAS &o) const {
+        return {A * o.A + S * o.S, A * o.S + S * o.A};   // not contracted (-ffp-contract=off): symmetric roundings
     }
-    static __device__ __forceinline__ float join(float c, float q) { return fmaf(q, 1.0f - c, c); }  // c (+) q
-    static __device__ __forceinline__ float mag(float p, float c) {
-        const float w = (p + p) * __builtin_amdgcn_rcpf(c);
+    __device__ __forceinline__ float mag() const {
+        const float w = (A - S) * __builtin_amdgcn_rcpf(S);
         const float m = __builtin_amdgcn_logf(1.0f + w) * 0.69314718055994530942f;
-        return fminf(m, (float)kNeClamp);  // also turns the NaN/inf of c == 0 into the clamp value
+        return fminf(m, (float)kNeClamp);  // also turns the inf of S == 0 into the clamp value
     }
 };
 
@@ -166,27 +168,22 @@ __device__ __forceinline__ void cn_tanh_f32(float (&t)[DEG]) {
         uint32_t tb = __float_as_uint(t[k]);
         X ^= tb;
         sg = __builtin_amdgcn_alignbit(sg, tb, 31);
-        t[k] = TanhPC::q_of(fabsf(t[k]));
+        t[k] = TanhAS::e_of(fabsf(t[k]));
     }
-    float psuf[DEG], csuf[DEG];
-    float pr = 1.f, cr = 0.f;
+    TanhAS suf[DEG];
+    TanhAS run = TanhAS::one();
 #pragma unroll
-    for (int k = DEG - 1; k >= 0; k--) {
-        psuf[k] = pr; csuf[k] = cr;
-        pr *= 1.0f - t[k];
-        cr = TanhPC::join(cr, t[k]);
-    }
+    for (int k = DEG - 1; k >= 0; k--) { suf[k] = run; run = run.times(t[k]); }
     // factor_j = tanh(-(t_j/2)) is negative iff t_j > 0; with zero factors the magnitude is 0 and the sign
     // is irrelevant, so "t_j > 0" may be read off the sign bit: negative factors among j != k are
     // (DEG-1) - sum_{j != k} signbit_j.  ne'_k = -sign(prod) * mag: positive iff that count is odd.
     const uint32_t base = X ^ ((DEG & 1) ? 0u : 0x80000000u);  // bit 31: parity((DEG-1) + all sign bits)
-    pr = 1.f; cr = 0.f;
+    run = TanhAS::one();
 #pragma unroll
     for (int k = 0; k < DEG; k++) {
-        const float q = t[k];
-        const float mag = TanhPC::mag(pr * psuf[k], TanhPC::join(cr, csuf[k]));
-        pr *= 1.0f - q;
-        cr = TanhPC::join(cr, q);
+        const float e = t[k];
+        const float mag = run.times(suf[k]).mag();
+        run = run.times(e);
         // count parity for edge k = base ^ signbit_k ; ne' > 0 iff odd -> sign bit of ne' = NOT that
         uint32_t sk = (sg << (31 - (DEG - 1 - k)));
         uint32_t neg = ~(base ^ sk) & 0x80000000u;
@@ -196,7 +193,7 @@ __device__ __forceinline__ void cn_tanh_f32(float (&t)[DEG]) {
 
 // ---------------------------------------------------------------- padded rows (generic on-chip kernel)
 // Rows of any degree <= DMAX: slots k >= deg hold t = +inf, which is neutral for both rules
-// (|t| = inf never wins a min; q(inf) = 0 is the neutral factor; sign bit 0) -- only the "(D odd)" term of the
+// (|t| = inf never wins a min; e^-inf = 0 is the neutral factor; sign bit 0) -- only the "(D odd)" term of the
 // sign rule needs the real degree.  Results for the real slots are bit-identical to cn_update<deg>.
 template <typename CT, int VARIANT, int DMAX>
 __device__ __forceinline__ void cn_update_padded(CT (&t)[DMAX], int deg) {
@@ -258,24 +255,19 @@ __device__ __forceinline__ void cn_update_padded(CT (&t)[DMAX], int deg) {
             uint32_t tb = __float_as_uint(t[k]);
             X ^= tb;
             sg = __builtin_amdgcn_alignbit(sg, tb, 31);
-            t[k] = TanhPC::q_of(fabsf(t[k]));   // padding: a = +inf -> e = 0 -> q = 0, h = 1: neutral
+            t[k] = TanhAS::e_of(fabsf(t[k]));   // padding: a = +inf -> e = 0: the neutral factor
         }
-        float psuf[DMAX], csuf[DMAX];
-        float pr = 1.f, cr = 0.f;
+        TanhAS suf[DMAX];
+        TanhAS run = TanhAS::one();
 #pragma unroll
-        for (int k = DMAX - 1; k >= 0; k--) {
-            psuf[k] = pr; csuf[k] = cr;
-            pr *= 1.0f - t[k];
-            cr = TanhPC::join(cr, t[k]);
-        }
+        for (int k = DMAX - 1; k >= 0; k--) { suf[k] = run; run = run.times(t[k]); }
         const uint32_t base = X ^ ((deg & 1) ? 0u : 0x80000000u);
-        pr = 1.f; cr = 0.f;
+        run = TanhAS::one();
 #pragma unroll
         for (int k = 0; k < DMAX; k++) {
-            const float q = t[k];
-            const float mag = TanhPC::mag(pr * psuf[k], TanhPC::join(cr, csuf[k]));
-            pr *= 1.0f - q;
-            cr = TanhPC::join(cr, q);
+            const float e = t[k];
+            const float mag = run.times(suf[k]).mag();
+            run = run.times(e);
             uint32_t sk = (sg << (31 - (DMAX - 1 - k)));
             uint32_t neg = ~(base ^ sk) & 0x80000000u;
             t[k] = __uint_as_float(__float_as_uint(mag) | neg);

@@ -55,9 +55,9 @@ def test_flood_f16_minsum_teacher_forced_step(hip, name, iters, dbs):
 def test_flood_f16_tanh_teacher_forced_step(hip, name, iters, dbs):
     """tanh rule: the kernel's f32 arithmetic (hardware exp/rcp/log) is not reproducible bit for bit, so each stored
     message must be an fp16 neighbour of the exactly computed value: within one fp16 ulp everywhere, identical
-    almost always (the f32 result carries ~6e-8 ABSOLUTE error from forming 1 + w, i.e. up to ~1e-5 relative on
-    the small messages of weight-18 rows, against an fp16 half-ulp of 2.4e-4: a few per cent land on the other
-    neighbour)."""
+    almost always.  The f32 rule (ldpc_math.h, hyperbolic recurrence) is accurate to ~6e-7 RELATIVE for |ne'| >= 1
+    but to ~8e-7 ABSOLUTE below that (A - S cancels when the tanh product is small), so the tiny messages of
+    weight-18 rows may land a few fp16 steps away: hence the absolute term, well inside the 1e-5 LLR bar."""
     c = load(name)
     rng = np.random.default_rng(78)
     F = 6
@@ -79,9 +79,10 @@ def test_flood_f16_tanh_teacher_forced_step(hip, name, iters, dbs):
             y = np.where(np.isinf(y), np.sign(p) * 18.714973875118524, y)   # Utils.hs:113-117
             exact[:, e0 + k] = -2 * y
     want = em.r16(exact.astype(np.float32)).astype(np.float64)
-    ulp = np.maximum(np.abs(want), 2.0 ** -14) * 2.0 ** -10
+    ulp = np.maximum(np.abs(want), 2.0 ** -14) * 2.0 ** -10 + 1e-6   # + the f32 rule's own absolute error bound
     assert (np.abs(ne2 - want) <= ulp).all()
-    assert (ne2 == want).mean() > 0.94
+    big = np.abs(want) >= 2.0 ** -6
+    assert (ne2 == want)[big].mean() > 0.97 and (ne2 == want).mean() > 0.85
     # lam' = r16(orig + sum of the kernel's OWN stored messages, descending rows, f32): exact given ne2
     acc = orig.copy()
     for m in reversed(range(g.M)):

@@ -163,7 +163,7 @@ def test_full_size_round_trip_property(hip):
 
 @pytest.mark.parametrize("name,dbs", CODES)
 def test_tanh_f32_fused(hip, name, dbs):
-    """Fused tanh rule (product/complement fp32 form): teacher-forced LLRs within the 1e-5 bar (+ the oracle's own
+    """Fused tanh rule (fp32 hyperbolic-recurrence form): teacher-forced LLRs within the 1e-5 bar (+ the oracle's own
     conditioning allowance next to the clamp), free-running bits identical to the oracle, and the
     fused and flood paths identical to each other (same arithmetic, same summation order)."""
     from tests.helpers import lam_tolerance

@@ -251,6 +251,7 @@ static int code_upload(ldpc_code *c, int device) {
 void ldpc_ctx_destroy(ldpc_ctx *ctx) {
     if (!ctx) return;
     if (ctx->stream) hipStreamSynchronize(ctx->stream);
+    ldpc::flood_graph_release(ctx->flood);
     hipFree(ctx->flood.msg); hipFree(ctx->flood.scratch); hipFree(ctx->flood.lam); hipFree(ctx->flood.orig);
     hipFree(ctx->flood.dev.unsat); hipFree(ctx->flood.dev.iters); hipFree(ctx->flood.dev.conv); hipFree(ctx->flood.dev.done);
     for (int i = 1; i < ldpc_ctx::kSlots; i++) if (ctx->pstream[i]) hipStreamSynchronize(ctx->pstream[i]);

@@ -21,6 +21,8 @@
 // Algorithmic HBM bytes per frame per turn: CN reads msg (E) + lam (N, given L2 reuse of the
 // slab), writes msg (E); VN reads msg (E) + orig (N), writes lam (N)  => (3E + 3N) * sizeof(ST),
 // the B_iter of SURVEY.md section 8d.
+#include <stdlib.h>
+#include <string.h>
 #include "ldpc_math.h"
 #include "internal.h"
 
@@ -317,7 +319,7 @@ __global__ void syndrome_flags_kernel(FloodDev d, uint8_t *out, int batch, int s
     } while (0)
 
 template <typename ST, int VARIANT>
-static int run_turns(FloodState &s, hipStream_t st, int max_iters, int batch, double *d_trace) {
+static void enqueue_turns(FloodState &s, hipStream_t st, int max_iters, int batch, double *d_trace) {
     FloodDev d = s.dev;
     ST *msg = (ST *)s.msg, *scr = (ST *)s.scratch, *lam = (ST *)s.lam, *orig = (ST *)s.orig;
     const int slabs = d.Bp / kWave;
@@ -335,6 +337,46 @@ static int run_turns(FloodState &s, hipStream_t st, int max_iters, int batch, do
     if (d_trace) hipLaunchKernelGGL((trace_store_kernel<ST>), tr_grid, dim3(256), 0, st, d, lam, d_trace, max_iters, max_iters + 1, batch);
     hipLaunchKernelGGL((flood_cn_kernel<ST, VARIANT>), cn_grid, cn_block, 0, st, d, msg, scr, lam, max_iters + 1, 1, 0);
     hipLaunchKernelGGL(flood_finalize_kernel, dim3((d.Bp + 255) / 256), dim3(256), 0, st, d, max_iters);
+}
+
+// LDPC_FLOOD_GRAPH=0 keeps plain launches (A/B measurements)
+static bool graph_wanted() {
+    static const bool on = [] { const char *e = getenv("LDPC_FLOOD_GRAPH"); return !(e && !strcmp(e, "0")); }();
+    return on;
+}
+
+template <typename ST, int VARIANT>
+static int run_turns(FloodState &s, hipStream_t st, int max_iters, int batch, double *d_trace) {
+    // Graph replay when nothing per-call is inside the loop: no trace buffer, no event timing, a capturable
+    // stream (not the legacy default stream), at least one turn.
+    const bool timing = s.timer && s.timer->enabled;
+    if (graph_wanted() && !d_trace && !timing && st != nullptr && max_iters > 0) {
+        if (!s.turn_graph || s.graph_iters != max_iters) {   // (the loop's grids cover the context's Bp frames, whatever `batch` is)
+            flood_graph_release(s);
+            hipGraph_t g = nullptr;
+            hipError_t e = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
+            if (e == hipSuccess) {
+                KernelTimer *keep = s.timer;
+                s.timer = nullptr;                 // no event records inside the captured sequence
+                enqueue_turns<ST, VARIANT>(s, st, max_iters, batch, nullptr);
+                s.timer = keep;
+                e = hipStreamEndCapture(st, &g);
+            }
+            if (e == hipSuccess && g) e = hipGraphInstantiate(&s.turn_graph, g, nullptr, nullptr, 0);
+            if (g) (void)hipGraphDestroy(g);
+            if (e != hipSuccess || !s.turn_graph) {   // capture not possible here: plain launches, as before
+                (void)hipGetLastError();
+                s.turn_graph = nullptr;
+                enqueue_turns<ST, VARIANT>(s, st, max_iters, batch, nullptr);
+                HIPCHK(hipGetLastError());
+                return LDPC_OK;
+            }
+            s.graph_iters = max_iters;
+        }
+        HIPCHK(hipGraphLaunch(s.turn_graph, st));
+        return LDPC_OK;
+    }
+    enqueue_turns<ST, VARIANT>(s, st, max_iters, batch, d_trace);
     HIPCHK(hipGetLastError());
     return LDPC_OK;
 }
@@ -395,6 +437,11 @@ int flood_decode(FloodState &s, hipStream_t st, int max_iters, int batch, const 
 int flood_step(FloodState &s, hipStream_t st, int batch, const double *d_orig, const double *d_lam,
                const double *d_ne, double *d_ne_out, double *d_lam_out, uint8_t *d_syn) {
     DISPATCH(step_impl, s, st, batch, d_orig, d_lam, d_ne, d_ne_out, d_lam_out, d_syn)
+}
+
+void flood_graph_release(FloodState &s) {
+    if (s.turn_graph) { (void)hipGraphExecDestroy(s.turn_graph); s.turn_graph = nullptr; }
+    s.graph_iters = -1;
 }
 
 size_t flood_elem_size(int dtype) { return dtype == LDPC_F64 ? 8 : (dtype == LDPC_F16 ? 2 : 4); }

@@ -67,7 +67,13 @@ struct FloodState {
     int variant, dtype;
     KernelTimer *timer = nullptr;
     void *msg = nullptr, *scratch = nullptr, *lam = nullptr, *orig = nullptr;
+    // The turn loop (2 launches per turn, no host decision inside: finished frames are frozen on the device)
+    // touches only this context's buffers, so it is captured once per max_iters into a hipGraph and
+    // replayed: one graph launch instead of 2*max_iters + 2 kernel launches.  flood_graph_release() frees it.
+    hipGraphExec_t turn_graph = nullptr;
+    int graph_iters = -1;
 };
+void flood_graph_release(FloodState &s);
 
 int flood_decode(FloodState &s, hipStream_t st, int max_iters, int batch, const void *d_llr, int llr_fmt,
                  uint8_t *d_bits, double *d_final, double *d_trace);

@@ -57,7 +57,9 @@ def main():
     # LDPC_BENCH_REHEARSE=1: run the N > 1 code path on a box with fewer GPUs than ranks (ranks share devices,
     # gloo instead of RCCL).  For checking the launch/sharding/tally logic only; its number is not a result.
     rehearse = os.environ.get("LDPC_BENCH_REHEARSE") == "1"
-    dev_index = local_rank % torch.cuda.device_count() if rehearse else local_rank
+    ndev = torch.cuda.device_count()
+    # (a launcher that gives every rank its own HIP_VISIBLE_DEVICES shows each rank ONE device: index 0)
+    dev_index = local_rank % ndev if (rehearse or (0 < ndev <= local_rank)) else local_rank
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     dist = None

@@ -184,6 +184,149 @@ __global__ __launch_bounds__(kCsrThreads) void fused_csr_kernel(CsrArgs A) {
     }
 }
 
+// Batched variant for small per-thread shares (RPT rows and CPT columns per thread, column degree <= CD): the
+// thread's graph indices, its rows' messages and its columns' channel LLRs live in REGISTERS for the whole decode,
+// and each phase issues ALL of its LDS gathers before it uses any of them.  The plain kernel above goes row by row
+// (gather -> wait -> compute -> store) and spends most of its time in LDS round trips: r01 profile on
+// codes/1920.1280.3.303 (profiles/r01_csr_*): one VALU instruction per SIMD every 7-10 clk, waves waiting 55-64 %
+// of their cycles, LDS only 22-28 % busy.  Here a turn costs three round trips (lam gather | message scatter +
+// barrier | message gather) whatever RPT and CPT are.  LDS holds lam [N] and the messages [DMAX][M] only.
+#ifndef CSR_BATCHED_WAVES
+#define CSR_BATCHED_WAVES 1
+#endif
+template <typename CT, int VARIANT, int DMAX, int RPT, int CPT, int CD>
+__global__ __launch_bounds__(kCsrThreads, CSR_BATCHED_WAVES) void fused_csr_batched_kernel(CsrArgs A) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    CT *lam = reinterpret_cast<CT *>(smem);
+    CT *msg = lam + A.N;  // [DMAX][M]
+    const int tid = threadIdx.x;
+    const int frame = blockIdx.x;
+    const int M = A.M, N = A.N;
+    const size_t fN = (size_t)frame * N, fE = (size_t)frame * A.E;
+
+    // ---- this thread's share of the graph, its channel LLRs and its messages: registers
+    int rcol[RPT][DMAX], rdeg[RPT], cslot[CPT][CD];
+    CT mreg[RPT][DMAX], oreg[CPT];
+#pragma unroll
+    for (int i = 0; i < RPT; i++) {
+        const int m = tid + i * kCsrThreads;
+        const int e0 = (m < M) ? A.row_ptr[m] : 0;
+        rdeg[i] = (m < M) ? A.row_ptr[m + 1] - e0 : 0;
+#pragma unroll
+        for (int k = 0; k < DMAX; k++) {
+            rcol[i][k] = (m < M) ? A.ell_col[k * M + m] : -1;
+            mreg[i][k] = (A.step_mode && k < rdeg[i]) ? (CT)A.st_ne_in[fE + e0 + k] : CT(0);  // Orig.hs:64-65
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < CPT; i++) {
+        const int c = tid + i * kCsrThreads;
+#pragma unroll
+        for (int j = 0; j < CD; j++) cslot[i][j] = (c < N && j < A.cdmax) ? A.csc_slot[j * N + c] : -1;
+        oreg[i] = CT(0);
+        if (c < N) {
+            oreg[i] = maybe_round_f16<CT>(load_llr<CT>(A.llr, fN + c, A.llr_fmt), A.llr_round16);
+            lam[c] = A.step_mode ? (CT)A.st_lam[fN + c] : oreg[i];
+        }
+    }
+    __syncthreads();
+
+    bool converged = false;
+    int n_done = 0;
+    const int turns = A.step_mode ? 1 : A.max_iters;
+    for (int n = 0;; n++) {
+        if (A.trace)
+            for (int c = tid; c < N; c += kCsrThreads) A.trace[((size_t)frame * (A.max_iters + 1) + n) * N + c] = (double)lam[c];
+        const bool last = n >= turns;
+        // ---- rows: every lam gather of the thread first, then syndrome + check-node updates out of registers
+        CT l[RPT][DMAX];
+#pragma unroll
+        for (int i = 0; i < RPT; i++)
+#pragma unroll
+            for (int k = 0; k < DMAX; k++) l[i][k] = lam[rcol[i][k] < 0 ? 0 : rcol[i][k]];
+        int unsat = 0;
+#pragma unroll
+        for (int i = 0; i < RPT; i++) {
+            CT t[DMAX];
+            bool par = false;
+#pragma unroll
+            for (int k = 0; k < DMAX; k++) {
+                const bool on = rcol[i][k] >= 0;
+                par ^= on && (l[i][k] > CT(0));
+                t[k] = on ? l[i][k] - mreg[i][k] : CT(INFINITY);
+            }
+            unsat |= par ? 1 : 0;
+            if (!last) {
+                cn_update_padded<CT, VARIANT, DMAX>(t, rdeg[i]);
+#pragma unroll
+                for (int k = 0; k < DMAX; k++) mreg[i][k] = (rcol[i][k] >= 0) ? t[k] : CT(0);
+            }
+        }
+        if (!last) {
+#pragma unroll
+            for (int i = 0; i < RPT; i++) {
+                const int m = tid + i * kCsrThreads;
+#pragma unroll
+                for (int k = 0; k < DMAX; k++)
+                    if (rcol[i][k] >= 0) msg[k * M + m] = mreg[i][k];
+            }
+        }
+        const int any_unsat = __syncthreads_or(unsat);  // also: every message written, every lam read
+        if (A.step_mode) {
+            if (tid == 0) A.st_syn[frame] = any_unsat ? 0 : 1;
+        } else if (!any_unsat) {  // Orig.hs:69
+            converged = true; n_done = n;
+            break;
+        }
+        if (last) { n_done = n; break; }  // Orig.hs:70
+        // ---- columns: every message gather first, then lam = foldr (+) orig (column of ne'), descending rows
+        CT v[CPT][CD];
+#pragma unroll
+        for (int i = 0; i < CPT; i++)
+#pragma unroll
+            for (int j = 0; j < CD; j++) v[i][j] = msg[cslot[i][j] < 0 ? 0 : cslot[i][j]];
+#pragma unroll
+        for (int i = 0; i < CPT; i++) {
+            const int c = tid + i * kCsrThreads;
+            CT acc = oreg[i];
+#pragma unroll
+            for (int j = 0; j < CD; j++)
+                if (cslot[i][j] >= 0) acc = v[i][j] + acc;
+            if (c < N) lam[c] = acc;
+        }
+        __syncthreads();
+        if (A.step_mode) break;
+    }
+
+    if (A.step_mode) {
+        for (int c = tid; c < N; c += kCsrThreads) A.final_lam[fN + c] = (double)lam[c];
+#pragma unroll
+        for (int i = 0; i < RPT; i++) {
+            const int m = tid + i * kCsrThreads;
+            if (m < M) {
+                const int e0 = A.row_ptr[m];
+#pragma unroll
+                for (int k = 0; k < DMAX; k++)
+                    if (k < rdeg[i]) A.st_ne_out[fE + e0 + k] = (double)mreg[i][k];
+            }
+        }
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < CPT; i++) {
+        const int c = tid + i * kCsrThreads;
+        if (c < N) {
+            CT vv = converged ? lam[c] : oreg[i];
+            A.bits[fN + c] = vv > CT(0) ? 1 : 0;
+            if (A.final_lam) A.final_lam[fN + c] = (double)vv;
+        }
+    }
+    if (tid == 0) {
+        if (A.iters) A.iters[frame] = n_done;
+        if (A.conv) A.conv[frame] = converged ? 1 : 0;
+    }
+}
+
 // ------------------------------------------------------------------ host side
 struct CsrState {
     int variant = 0, dtype = 0, M = 0, N = 0, E = 0, dmax = 0, cdmax = 0, round16 = 0;
@@ -262,8 +405,36 @@ static int launch_csr(CsrState &s, hipStream_t st, CsrArgs &a) {
     return LDPC_OK;
 }
 
+template <typename CT, int VARIANT, int DMAX, int RPT, int CPT, int CD>
+static int launch_csr_batched(CsrState &s, hipStream_t st, CsrArgs &a) {
+    auto kern = fused_csr_batched_kernel<CT, VARIANT, DMAX, RPT, CPT, CD>;
+    const size_t lds = ((size_t)s.N + (size_t)DMAX * s.M) * sizeof(CT);
+    static size_t attr_set = 0;
+    if (lds > 64 * 1024 && lds > attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return set_error(LDPC_EHIP, "hipFuncSetAttribute(%zu B LDS): %s", lds, hipGetErrorString(e));
+        attr_set = lds;
+    }
+    if (s.timer && !a.step_mode) s.timer->begin(st);
+    hipLaunchKernelGGL(kern, dim3(a.batch), dim3(kCsrThreads), lds, st, a);
+    if (s.timer && !a.step_mode) s.timer->end(st);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return set_error(LDPC_EHIP, "fused_csr (batched) launch: %s", hipGetErrorString(e));
+    return LDPC_OK;
+}
+
 template <typename CT, int VARIANT>
 static int dispatch_dmax(CsrState &s, hipStream_t st, CsrArgs &a) {
+    // small per-thread shares (f32): the batched kernel; LDPC_CSR_BATCHED=0 keeps the row-by-row kernel (A/B)
+    if constexpr (sizeof(CT) == 4) {
+        const int rpt_ = (s.M + kCsrThreads - 1) / kCsrThreads, cpt_ = (s.N + kCsrThreads - 1) / kCsrThreads;
+        const char *bz = getenv("LDPC_CSR_BATCHED");
+        if (!(bz && !strcmp(bz, "0"))) {
+            if (s.dmax == 4 && rpt_ <= 6 && cpt_ <= 8 && s.cdmax <= 4) return launch_csr_batched<CT, VARIANT, 4, 6, 8, 4>(s, st, a);
+            if (s.dmax == 8 && rpt_ <= 2 && cpt_ <= 4 && s.cdmax <= 8) return launch_csr_batched<CT, VARIANT, 8, 2, 4, 8>(s, st, a);
+            if (s.dmax == 20 && rpt_ <= 2 && cpt_ <= 6 && s.cdmax <= 8) return launch_csr_batched<CT, VARIANT, 20, 2, 6, 8>(s, st, a);
+        }
+    }
     // register-cached graph indices when the per-thread share is small (f32; DMAX 4 or 8):
     //   rows per thread <= 6 or 2, columns per thread <= 8, column degree <= 8
     const int rpt = (s.M + kCsrThreads - 1) / kCsrThreads, cpt = (s.N + kCsrThreads - 1) / kCsrThreads;

@@ -184,28 +184,35 @@ __global__ __launch_bounds__(kCsrThreads) void fused_csr_kernel(CsrArgs A) {
     }
 }
 
-// Batched variant for small per-thread shares (RPT rows and CPT columns per thread, column degree <= CD): the
-// thread's graph indices, its rows' messages and its columns' channel LLRs live in REGISTERS for the whole decode,
-// and each phase issues ALL of its LDS gathers before it uses any of them.  The plain kernel above goes row by row
-// (gather -> wait -> compute -> store) and spends most of its time in LDS round trips: r01 profile on
-// codes/1920.1280.3.303 (profiles/r01_csr_*): one VALU instruction per SIMD every 7-10 clk, waves waiting 55-64 %
-// of their cycles, LDS only 22-28 % busy.  Here a turn costs three round trips (lam gather | message scatter +
-// barrier | message gather) whatever RPT and CPT are.  LDS holds lam [N] and the messages [DMAX][M] only.
-#ifndef CSR_BATCHED_WAVES
-#define CSR_BATCHED_WAVES 1
-#endif
+// Batched variant for small per-thread shares (RPT rows and CPT columns per thread, column degree <= CD, one
+// frame's lam + messages within 64 KB): the thread's graph indices, its rows' messages and its columns' channel
+// LLRs live in REGISTERS for the whole decode, and each phase issues ALL of its LDS gathers before it uses any of
+// them.  The plain kernel above goes row by row (gather -> wait -> compute -> store) and spends most of its time
+// in LDS round trips: r01 profile on codes/1920.1280.3.303 (profiles/r01_csr_*): one VALU instruction per SIMD
+// every 7-10 clk, waves waiting 55-64 % of their cycles, LDS only 22-28 % busy.  Here a turn costs three round
+// trips (lam gather | message scatter + barrier | message gather) whatever RPT and CPT are.
+// Indices are kept as 16-bit LDS BYTE OFFSETS, two per register (that is what keeps the 1920.1280.3.303 instance
+// at 128 VGPRs = 4 waves/SIMD), and padding needs no predicate: an absent row slot points at a cell holding +inf
+// (t = inf - finite = inf, the neutral element of both rules; its "hard bit" is taken back out of the row parity
+// by the known count of padded slots), an absent column slot at a cell holding 0.
+// (row weights <= 8: 4 waves/SIMD = 128 VGPRs with a few spilled registers measured 2-4 % faster than 3 waves
+//  without; the weight-20 instance needs its 211-256 registers)
 template <typename CT, int VARIANT, int DMAX, int RPT, int CPT, int CD>
-__global__ __launch_bounds__(kCsrThreads, CSR_BATCHED_WAVES) void fused_csr_batched_kernel(CsrArgs A) {
+__global__ __launch_bounds__(kCsrThreads, (DMAX <= 8 ? 4 : 1)) void fused_csr_batched_kernel(CsrArgs A) {
+    static_assert(sizeof(CT) == 4 && DMAX % 2 == 0 && CD % 2 == 0, "pairs of 16-bit offsets");
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    CT *lam = reinterpret_cast<CT *>(smem);
-    CT *msg = lam + A.N;  // [DMAX][M]
     const int tid = threadIdx.x;
     const int frame = blockIdx.x;
     const int M = A.M, N = A.N;
     const size_t fN = (size_t)frame * N, fE = (size_t)frame * A.E;
+    CT *lam = reinterpret_cast<CT *>(smem);
+    CT *msg = lam + N;  // [DMAX][M]
+    const uint32_t off_inf = (uint32_t)(N + DMAX * M) * 4u, off_zero = off_inf + 4u, off_msg = (uint32_t)N * 4u;
+    auto lds_at = [&](uint32_t byte_off) -> CT { return *reinterpret_cast<const CT *>(smem + byte_off); };
 
     // ---- this thread's share of the graph, its channel LLRs and its messages: registers
-    int rcol[RPT][DMAX], rdeg[RPT], cslot[CPT][CD];
+    uint32_t rpack[RPT][DMAX / 2], cpack[CPT][CD / 2];
+    int rdeg[RPT];
     CT mreg[RPT][DMAX], oreg[CPT];
 #pragma unroll
     for (int i = 0; i < RPT; i++) {
@@ -214,7 +221,9 @@ __global__ __launch_bounds__(kCsrThreads, CSR_BATCHED_WAVES) void fused_csr_batc
         rdeg[i] = (m < M) ? A.row_ptr[m + 1] - e0 : 0;
 #pragma unroll
         for (int k = 0; k < DMAX; k++) {
-            rcol[i][k] = (m < M) ? A.ell_col[k * M + m] : -1;
+            const int col = (m < M) ? A.ell_col[k * M + m] : -1;
+            const uint32_t off = col < 0 ? off_inf : (uint32_t)col * 4u;
+            if (k & 1) rpack[i][k / 2] |= off << 16; else rpack[i][k / 2] = off;
             mreg[i][k] = (A.step_mode && k < rdeg[i]) ? (CT)A.st_ne_in[fE + e0 + k] : CT(0);  // Orig.hs:64-65
         }
     }
@@ -222,12 +231,20 @@ __global__ __launch_bounds__(kCsrThreads, CSR_BATCHED_WAVES) void fused_csr_batc
     for (int i = 0; i < CPT; i++) {
         const int c = tid + i * kCsrThreads;
 #pragma unroll
-        for (int j = 0; j < CD; j++) cslot[i][j] = (c < N && j < A.cdmax) ? A.csc_slot[j * N + c] : -1;
+        for (int j = 0; j < CD; j++) {
+            const int slot = (c < N && j < A.cdmax) ? A.csc_slot[j * N + c] : -1;
+            const uint32_t off = slot < 0 ? off_zero : off_msg + (uint32_t)slot * 4u;
+            if (j & 1) cpack[i][j / 2] |= off << 16; else cpack[i][j / 2] = off;
+        }
         oreg[i] = CT(0);
         if (c < N) {
             oreg[i] = maybe_round_f16<CT>(load_llr<CT>(A.llr, fN + c, A.llr_fmt), A.llr_round16);
             lam[c] = A.step_mode ? (CT)A.st_lam[fN + c] : oreg[i];
         }
+    }
+    if (tid == 0) {
+        *reinterpret_cast<CT *>(smem + off_inf) = CT(INFINITY);
+        *reinterpret_cast<CT *>(smem + off_zero) = CT(0);
     }
     __syncthreads();
 
@@ -243,32 +260,35 @@ __global__ __launch_bounds__(kCsrThreads, CSR_BATCHED_WAVES) void fused_csr_batc
 #pragma unroll
         for (int i = 0; i < RPT; i++)
 #pragma unroll
-            for (int k = 0; k < DMAX; k++) l[i][k] = lam[rcol[i][k] < 0 ? 0 : rcol[i][k]];
+            for (int k = 0; k < DMAX; k += 2) {
+                l[i][k] = lds_at(rpack[i][k / 2] & 0xffffu);
+                l[i][k + 1] = lds_at(rpack[i][k / 2] >> 16);
+            }
         int unsat = 0;
 #pragma unroll
         for (int i = 0; i < RPT; i++) {
             CT t[DMAX];
-            bool par = false;
+            uint32_t par = (uint32_t)(DMAX - rdeg[i]);   // each padded slot reads +inf: its "hard bit" 1 is taken back out
 #pragma unroll
             for (int k = 0; k < DMAX; k++) {
-                const bool on = rcol[i][k] >= 0;
-                par ^= on && (l[i][k] > CT(0));
-                t[k] = on ? l[i][k] - mreg[i][k] : CT(INFINITY);
+                par ^= (l[i][k] > CT(0)) ? 1u : 0u;
+                t[k] = l[i][k] - mreg[i][k];             // padded slot: inf - finite = inf
             }
-            unsat |= par ? 1 : 0;
+            unsat |= (tid + i * kCsrThreads < M) ? (int)(par & 1u) : 0;
             if (!last) {
                 cn_update_padded<CT, VARIANT, DMAX>(t, rdeg[i]);
 #pragma unroll
-                for (int k = 0; k < DMAX; k++) mreg[i][k] = (rcol[i][k] >= 0) ? t[k] : CT(0);
+                for (int k = 0; k < DMAX; k++) mreg[i][k] = t[k];   // padded slots: finite, never read by a column
             }
         }
         if (!last) {
 #pragma unroll
             for (int i = 0; i < RPT; i++) {
                 const int m = tid + i * kCsrThreads;
+                if (m < M) {
 #pragma unroll
-                for (int k = 0; k < DMAX; k++)
-                    if (rcol[i][k] >= 0) msg[k * M + m] = mreg[i][k];
+                    for (int k = 0; k < DMAX; k++) msg[k * M + m] = mreg[i][k];
+                }
             }
         }
         const int any_unsat = __syncthreads_or(unsat);  // also: every message written, every lam read
@@ -284,14 +304,16 @@ __global__ __launch_bounds__(kCsrThreads, CSR_BATCHED_WAVES) void fused_csr_batc
 #pragma unroll
         for (int i = 0; i < CPT; i++)
 #pragma unroll
-            for (int j = 0; j < CD; j++) v[i][j] = msg[cslot[i][j] < 0 ? 0 : cslot[i][j]];
+            for (int j = 0; j < CD; j += 2) {
+                v[i][j] = lds_at(cpack[i][j / 2] & 0xffffu);
+                v[i][j + 1] = lds_at(cpack[i][j / 2] >> 16);
+            }
 #pragma unroll
         for (int i = 0; i < CPT; i++) {
             const int c = tid + i * kCsrThreads;
             CT acc = oreg[i];
 #pragma unroll
-            for (int j = 0; j < CD; j++)
-                if (cslot[i][j] >= 0) acc = v[i][j] + acc;
+            for (int j = 0; j < CD; j++) acc = v[i][j] + acc;   // absent slots add 0 (they follow the present ones)
             if (c < N) lam[c] = acc;
         }
         __syncthreads();
@@ -408,13 +430,7 @@ static int launch_csr(CsrState &s, hipStream_t st, CsrArgs &a) {
 template <typename CT, int VARIANT, int DMAX, int RPT, int CPT, int CD>
 static int launch_csr_batched(CsrState &s, hipStream_t st, CsrArgs &a) {
     auto kern = fused_csr_batched_kernel<CT, VARIANT, DMAX, RPT, CPT, CD>;
-    const size_t lds = ((size_t)s.N + (size_t)DMAX * s.M) * sizeof(CT);
-    static size_t attr_set = 0;
-    if (lds > 64 * 1024 && lds > attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return set_error(LDPC_EHIP, "hipFuncSetAttribute(%zu B LDS): %s", lds, hipGetErrorString(e));
-        attr_set = lds;
-    }
+    const size_t lds = ((size_t)s.N + (size_t)DMAX * s.M + 2) * sizeof(CT);   // lam, messages, the +inf and 0 cells; <= 64 KB
     if (s.timer && !a.step_mode) s.timer->begin(st);
     hipLaunchKernelGGL(kern, dim3(a.batch), dim3(kCsrThreads), lds, st, a);
     if (s.timer && !a.step_mode) s.timer->end(st);
@@ -429,7 +445,8 @@ static int dispatch_dmax(CsrState &s, hipStream_t st, CsrArgs &a) {
     if constexpr (sizeof(CT) == 4) {
         const int rpt_ = (s.M + kCsrThreads - 1) / kCsrThreads, cpt_ = (s.N + kCsrThreads - 1) / kCsrThreads;
         const char *bz = getenv("LDPC_CSR_BATCHED");
-        if (!(bz && !strcmp(bz, "0"))) {
+        const bool fits16 = ((size_t)s.N + (size_t)s.dmax * s.M + 2) * 4 <= 65536;   // 16-bit LDS byte offsets
+        if (fits16 && !(bz && !strcmp(bz, "0"))) {
             if (s.dmax == 4 && rpt_ <= 6 && cpt_ <= 8 && s.cdmax <= 4) return launch_csr_batched<CT, VARIANT, 4, 6, 8, 4>(s, st, a);
             if (s.dmax == 8 && rpt_ <= 2 && cpt_ <= 4 && s.cdmax <= 8) return launch_csr_batched<CT, VARIANT, 8, 2, 4, 8>(s, st, a);
             if (s.dmax == 20 && rpt_ <= 2 && cpt_ <= 6 && s.cdmax <= 8) return launch_csr_batched<CT, VARIANT, 20, 2, 6, 8>(s, st, a);

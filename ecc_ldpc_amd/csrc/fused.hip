@@ -495,7 +495,8 @@ int fused_decode(FusedState &s, hipStream_t st, int max_iters, int batch, const 
     FusedArgs a{};
     a.tab = s.d_tab; a.llr = d_llr; a.llr_fmt = llr_fmt; a.llr_round16 = s.round16; a.bits = d_bits; a.iters = d_iters; a.conv = d_conv;
     a.final_lam = d_final; a.trace = d_trace; a.batch = batch; a.max_iters = max_iters; a.step_mode = 0;
-    if (s.use_split) return fused_split_launch(s.variant, s.sz, st, a, s.timer);
+    // (the split kernel packs a frame's result into one register: 9 bits for the turn it converged at)
+    if (s.use_split && max_iters <= kSplitMaxIters) return fused_split_launch(s.variant, s.sz, st, a, s.timer);
     if (s.use_msg) return fused_msg_launch(s.variant, s.dtype, s.sz, s.static_id, st, a, s.timer);
     return dispatch(s, st, a);
 }

@@ -109,5 +109,6 @@ int fused_msg_launch(int variant, int dtype, int sz, int static_id, hipStream_t 
 // four-wave variant with the block rows split between two wave pairs (fused_split.hip)
 bool fused_split_has(int variant, int dtype, int sz, int static_id);
 int fused_split_launch(int variant, int sz, hipStream_t st, FusedArgs &a, KernelTimer *timer);
+constexpr int kSplitMaxIters = 511;  // fused_split.hip result word: bits 23..31 hold the turn a frame converged at
 
 }  // namespace ldpc

@@ -218,7 +218,7 @@ __device__ __forceinline__ void split_body(const FusedArgs &A, char *lds, const 
 #pragma unroll
     for (int s2 = 0; s2 < CPW; s2++) done |= ((long long)blockIdx.x * CPW + s2 < A.batch) ? 0u : (1u << s2);
     // bits 0..21: hard(lam) of this lane's columns at the moment its frame converged; bit 22: converged;
-    // bits 23..: the iteration it converged at
+    // bits 23..31: the iteration it converged at (max_iters <= kSplitMaxIters: fused.hip falls back to fused_msg above)
     static_assert(Plan::NBC <= 44, "result word layout");
     uint32_t res = 0;
     const int turns = A.step_mode ? 1 : A.max_iters;

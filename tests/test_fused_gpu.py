@@ -254,3 +254,16 @@ def test_split_kernel_matches_two_wave_kernel(hip, monkeypatch, name, variant):
     monkeypatch.delenv("LDPC_FUSED_KERNEL")
     a2 = hip.Decoder(code, variant, "f32", B, path="fused").decode_batch(llr, 50)   # and is repeatable
     assert all(np.array_equal(x, y) for x, y in zip(a, a2))
+
+
+def test_many_iterations_leave_the_split_kernel(hip):
+    """The split kernel reports the turn a frame converged at in 9 bits; beyond 511 turns the two-wave kernel runs.
+    A frame far below the waterfall must come back with iters == max_iters either way, identical to the flood path."""
+    c = load("jpl.1024.4.5")
+    _, llr = c.frames(16, 1.0, seed=77)
+    llr = llr.astype(np.float32)
+    code = c.hip_code(hip)
+    for iters in (511, 600):
+        a = hip.Decoder(code, "min", "f32", len(llr), path="fused").decode_batch(llr, iters)
+        b = hip.Decoder(code, "min", "f32", len(llr), path="flood").decode_batch(llr, iters)
+        assert all(np.array_equal(x, y) for x, y in zip(a, b)) and int(a[1].max()) == iters

@@ -604,9 +604,16 @@ ldpc_sim *ldpc_sim_create(const ldpc_code *code, int k, int n_tx, int p, const u
         for (int r = 0; r < k; r++)
             for (int j = 0; j < p; j++)
                 if (G[(size_t)r * p + j]) s->gt_host[(size_t)j * s->dev.kwords + (r >> 5)] |= 1u << (r & 31);
-        e = hipMalloc((void **)&s->d_gt, s->gt_host.size() * 4);
-        if (e == hipSuccess) e = hipMemcpy(s->d_gt, s->gt_host.data(), s->gt_host.size() * 4, hipMemcpyHostToDevice);
+        // device copy transposed and padded: [kwords][pp], parity position fastest, so that the lanes of a wave
+        // (consecutive parity positions, four per lane) read consecutive words
+        const int pp = (p + 3) / 4 * 4;
+        std::vector<uint32_t> gtt((size_t)s->dev.kwords * pp, 0u);
+        for (int j = 0; j < p; j++)
+            for (int w = 0; w < s->dev.kwords; w++) gtt[(size_t)w * pp + j] = s->gt_host[(size_t)j * s->dev.kwords + w];
+        e = hipMalloc((void **)&s->d_gt, gtt.size() * 4);
+        if (e == hipSuccess) e = hipMemcpy(s->d_gt, gtt.data(), gtt.size() * 4, hipMemcpyHostToDevice);
         s->dev.gt = s->d_gt;
+        s->dev.pp = pp;
     }
     if (e == hipSuccess) e = hipMalloc((void **)&s->d_msgw, (size_t)max_batch * s->dev.kwords * 4);
     if (e != hipSuccess) { set_error(LDPC_EHIP, "ldpc_sim_create: %s", hipGetErrorString(e)); ldpc_sim_destroy(s); return nullptr; }

@@ -8,7 +8,7 @@
 //   BPSK bit b -> 2b-1 (LLR > 0 <=> bit 1, `hard x = x > 0`); noise N(0, sigma^2),
 //   sigma^2 = 1/(2 R 10^(EbN0/10)), R = k/n_tx; LLR = 2y/sigma^2; punctured tail LLR = 0
 //   (Utils.hs:55 `unpuncture`).
-// Randomness: Philox4x32-10 keyed by the 64-bit seed, counter = (global frame id, index, stream),
+// Randomness: Philox4x32-10 keyed by the 64-bit seed, counter = (global frame id, index / 4, stream),
 // so a frame's content depends only on (seed, frame id): ranks generate disjoint frame ranges
 // with no scatter.
 #include "internal.h"
@@ -51,42 +51,92 @@ __global__ void sim_msg_kernel(uint32_t *msgw, int kwords, int k, uint64_t seed,
     msgw[i] = v;
 }
 
-// one thread per (frame, transmitted or punctured position n)
-template <typename OT>
+// one thread per (frame, group of four consecutive positions n = 4g .. 4g+3): ONE Philox call feeds both
+// Box-Muller pairs (r0,r1 -> cos and sin branch, r2,r3 likewise), i.e. four normals -- the generator is bound by
+// Philox's quarter-rate 32x32 multiplies, and the first version spent a whole call per sample.
+template <typename OT, bool VEC>
 __global__ __launch_bounds__(256) void sim_frame_kernel(SimDev s, const uint32_t *__restrict__ msgw, OT *__restrict__ llr,
                                                         uint8_t *__restrict__ msg_bytes, uint64_t seed, uint64_t first_frame,
                                                         int batch, float sigma, float llr_scale) {
-    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
     const int f = blockIdx.y;
-    if (n >= s.N || f >= batch) return;
-    float out = 0.f;
-    if (n < s.n_tx) {
-        const uint32_t *mw = msgw + (size_t)f * s.kwords;
-        uint32_t bit;
-        if (n < s.k) {
-            bit = (mw[n >> 5] >> (n & 31)) & 1u;
-            if (msg_bytes) msg_bytes[(size_t)f * s.k + n] = (uint8_t)bit;
-        } else if (s.gt) { // parity bit j = <msg, column j of G> over GF(2)
-            const uint32_t *col = s.gt + (size_t)(n - s.k) * s.kwords;
-            uint32_t acc = 0;
-            for (int w = 0; w < s.kwords; w++) acc ^= mw[w] & col[w];
-            bit = __popc(acc) & 1u;
-        } else {
-            bit = 0u; // no generator: all-zero codeword
-        }
+    const int n0 = 4 * g;
+    if (n0 >= s.N || f >= batch) return;
+    const uint32_t *mw = msgw + (size_t)f * s.kwords;
+    float z[4] = {0.f, 0.f, 0.f, 0.f};
+    if (n0 < s.n_tx) {
         uint32_t r[4];
-        Philox::gen(seed, first_frame + f, (uint32_t)n, 1u, r);
-        // Box-Muller on two 32-bit uniforms (u1 in (0,1])
-        float u1 = ((float)r[0] + 1.0f) * 2.3283064365386963e-10f;
-        float u2 = (float)r[1] * 2.3283064365386963e-10f;
-        float z = sqrtf(-2.0f * logf(u1)) * cospif(2.0f * u2);
-        float y = (bit ? 1.0f : -1.0f) + sigma * z;
-        out = llr_scale * y;
-    } else if (n < s.k && msg_bytes) {
-        msg_bytes[(size_t)f * s.k + n] = (uint8_t)((msgw[(size_t)f * s.kwords + (n >> 5)] >> (n & 31)) & 1u);
+        Philox::gen(seed, first_frame + f, (uint32_t)g, 1u, r);
+        // Box-Muller on two 32-bit uniforms (u1 in (0,1]); both branches of each pair are used
+        const float ua = ((float)r[0] + 1.0f) * 2.3283064365386963e-10f, ub = (float)r[1] * 2.3283064365386963e-10f;
+        const float uc = ((float)r[2] + 1.0f) * 2.3283064365386963e-10f, ud = (float)r[3] * 2.3283064365386963e-10f;
+        const float ra = sqrtf(-2.0f * logf(ua)), rc = sqrtf(-2.0f * logf(uc));
+        float sa, ca, sc, cc;
+        sincospif(2.0f * ub, &sa, &ca);
+        sincospif(2.0f * ud, &sc, &cc);
+        z[0] = ra * ca; z[1] = ra * sa; z[2] = rc * cc; z[3] = rc * sc;
     }
-    if constexpr (sizeof(OT) == 2) llr[(size_t)f * s.N + n] = __float2half_rn(fminf(fmaxf(out, -65504.f), 65504.f));  // = round_f16
-    else llr[(size_t)f * s.N + n] = out;
+    // parity bits of the group: bit j = <msg, column j of G> over GF(2); a group that lies inside the parity part
+    // on a 4-aligned column reads its four columns with one 16-byte load per message word
+    uint32_t pacc[4] = {0u, 0u, 0u, 0u};
+    if (s.gt && n0 + 3 >= s.k && n0 < s.n_tx) {
+        const int j0 = n0 - s.k;
+        if (j0 >= 0 && (j0 & 3) == 0) {
+            const uint4 *col = reinterpret_cast<const uint4 *>(s.gt + j0);
+            const size_t stride = (size_t)s.pp / 4;
+            for (int w = 0; w < s.kwords; w++) {
+                const uint32_t m = mw[w];
+                const uint4 c = col[(size_t)w * stride];
+                pacc[0] ^= m & c.x; pacc[1] ^= m & c.y; pacc[2] ^= m & c.z; pacc[3] ^= m & c.w;
+            }
+        } else {
+            for (int w = 0; w < s.kwords; w++) {
+                const uint32_t m = mw[w];
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const int j = j0 + i;
+                    if (j >= 0 && j < s.pp) pacc[i] ^= m & s.gt[(size_t)w * s.pp + j];
+                }
+            }
+        }
+    }
+    float out[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int n = n0 + i;
+        out[i] = 0.f;
+        if (n < s.n_tx) {
+            uint32_t bit;
+            if (n < s.k) {
+                bit = (mw[n >> 5] >> (n & 31)) & 1u;
+                if (msg_bytes) msg_bytes[(size_t)f * s.k + n] = (uint8_t)bit;
+            } else {
+                bit = __popc(pacc[i]) & 1u;   // (no generator: pacc = 0, the all-zero codeword)
+            }
+            out[i] = llr_scale * ((bit ? 1.0f : -1.0f) + sigma * z[i]);
+        } else if (n < s.k && msg_bytes) {
+            msg_bytes[(size_t)f * s.k + n] = (uint8_t)((mw[n >> 5] >> (n & 31)) & 1u);
+        }
+    }
+    OT *dst = llr + (size_t)f * s.N + n0;
+    if constexpr (sizeof(OT) == 2) {
+        __half h[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) h[i] = __float2half_rn(fminf(fmaxf(out[i], -65504.f), 65504.f));  // = round_f16
+        if constexpr (VEC) {
+            *reinterpret_cast<uint2 *>(dst) = *reinterpret_cast<const uint2 *>(h);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; i++) if (n0 + i < s.N) dst[i] = h[i];
+        }
+    } else {
+        if constexpr (VEC) {
+            *reinterpret_cast<float4 *>(dst) = make_float4(out[0], out[1], out[2], out[3]);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; i++) if (n0 + i < s.N) dst[i] = out[i];
+        }
+    }
 }
 
 // tally[0..3] += {frames, frame errors, message-bit errors, sum of iterations}; one wave per frame
@@ -115,13 +165,18 @@ int sim_generate(const SimDev &s, uint32_t *msgw, hipStream_t st, uint64_t seed,
     const double sigma2 = 1.0 / (2.0 * R * pow(10.0, ebn0_db / 10.0));
     size_t nw = (size_t)batch * s.kwords;
     hipLaunchKernelGGL(sim_msg_kernel, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, st, msgw, s.kwords, s.k, seed, first_frame, batch, s.gt ? 0 : 1);
-    const dim3 grid((s.N + 255) / 256, batch);
-    if (llr_f16)
-        hipLaunchKernelGGL(sim_frame_kernel<__half>, grid, dim3(256), 0, st, s, msgw, (__half *)d_llr, d_msg, seed, first_frame, batch,
-                           (float)sqrt(sigma2), (float)(2.0 / sigma2));
-    else
-        hipLaunchKernelGGL(sim_frame_kernel<float>, grid, dim3(256), 0, st, s, msgw, (float *)d_llr, d_msg, seed, first_frame, batch,
-                           (float)sqrt(sigma2), (float)(2.0 / sigma2));
+    const int groups = (s.N + 3) / 4;
+    const dim3 grid((groups + 255) / 256, batch);
+    const float sg = (float)sqrt(sigma2), sc = (float)(2.0 / sigma2);
+    // 16-byte (f32) / 8-byte (fp16) vector stores when every row starts aligned
+    const bool vec = (s.N % 4 == 0) && ((uintptr_t)d_llr % 16 == 0);
+    if (llr_f16) {
+        if (vec) hipLaunchKernelGGL((sim_frame_kernel<__half, true>), grid, dim3(256), 0, st, s, msgw, (__half *)d_llr, d_msg, seed, first_frame, batch, sg, sc);
+        else hipLaunchKernelGGL((sim_frame_kernel<__half, false>), grid, dim3(256), 0, st, s, msgw, (__half *)d_llr, d_msg, seed, first_frame, batch, sg, sc);
+    } else {
+        if (vec) hipLaunchKernelGGL((sim_frame_kernel<float, true>), grid, dim3(256), 0, st, s, msgw, (float *)d_llr, d_msg, seed, first_frame, batch, sg, sc);
+        else hipLaunchKernelGGL((sim_frame_kernel<float, false>), grid, dim3(256), 0, st, s, msgw, (float *)d_llr, d_msg, seed, first_frame, batch, sg, sc);
+    }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return set_error(LDPC_EHIP, "sim_generate: %s", hipGetErrorString(e));
     return LDPC_OK;

@@ -116,3 +116,20 @@ def test_batched_kernel_equals_row_by_row_kernel(hip, monkeypatch, name, iters, 
     rb = hip.Decoder(code, variant, "f32", len(llr), path="fused").decode_batch(llr.astype(np.float64), iters, want_lam=True)
     assert len(set(ra[1].tolist())) > 2
     assert all(np.array_equal(x, y) for x, y in zip(ra, rb))
+
+
+def test_placement_changes_nothing_but_speed(hip, monkeypatch):
+    """The batched kernel stores rows and columns at conflict-aware LDS positions (LDPC_CSR_PLACE=0: file order);
+    positions never enter the arithmetic, so every output is identical, traces and teacher-forced steps included."""
+    c = load("1920.1280.3.303")
+    llr = _frames(c, 12, (1.0, 2.0), 2100)
+    code = _code(hip, c)
+    rng = np.random.default_rng(9)
+    orig = rng.normal(0, 4, (4, c.N)); lam = orig + rng.normal(0, 2, (4, c.N)); ne = rng.normal(0, 1, (4, c.E))
+    outs = []
+    for place in ("1", "0"):
+        monkeypatch.setenv("LDPC_CSR_PLACE", place)
+        d = hip.Decoder(code, "tanh", "f32", len(llr), path="fused")
+        outs.append((d.decode_batch(llr, 50, want_lam=True), d.decode_trace(llr[:6], 50), d.debug_step(orig, lam, ne)))
+    for x, y in zip(outs[0], outs[1]):
+        assert all(np.array_equal(p, q) for p, q in zip(x, y))

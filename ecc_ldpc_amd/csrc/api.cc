@@ -63,6 +63,12 @@ struct ldpc_ctx {
     int32_t *d_iters[kSlots] = {};
     uint8_t *d_conv[kSlots] = {};
     double *d_final[kSlots] = {};       // [chunk][N], only when final LLRs are requested
+    // latency path of the host-pointer entry points (<= kSmallFrames frames, e.g. ldpc_decode_one): page-locked
+    // bounce buffers and ONE device block for bits|iters|converged, so a call costs one H2D copy, one launch and
+    // one D2H copy instead of four pageable copies
+    static constexpr int kSmallFrames = 16;
+    void *h_small_in = nullptr;
+    uint8_t *h_small_out = nullptr, *d_small_out = nullptr;
     ldpc::KernelTimer timer;
 };
 
@@ -257,6 +263,9 @@ void ldpc_ctx_destroy(ldpc_ctx *ctx) {
     for (int i = 1; i < ldpc_ctx::kSlots; i++) if (ctx->pstream[i]) hipStreamSynchronize(ctx->pstream[i]);
     for (int i = 0; i < ldpc_ctx::kSlots; i++) { hipFree(ctx->d_in[i]); hipFree(ctx->d_bits[i]); hipFree(ctx->d_iters[i]); hipFree(ctx->d_conv[i]); hipFree(ctx->d_final[i]); }
     for (int i = 1; i < ldpc_ctx::kSlots; i++) if (ctx->pstream[i]) hipStreamDestroy(ctx->pstream[i]);
+    if (ctx->h_small_in) (void)hipHostFree(ctx->h_small_in);
+    if (ctx->h_small_out) (void)hipHostFree(ctx->h_small_out);
+    (void)hipFree(ctx->d_small_out);
     if (ctx->fused) ldpc::fused_destroy(ctx->fused);
     ctx->timer.destroy();
     if (ctx->stream) hipStreamDestroy(ctx->stream);
@@ -426,6 +435,40 @@ static int decode_host(ldpc_ctx *ctx, int max_iters, int batch, const void *llr,
     if (!llr || !bits) return set_error(LDPC_EINVAL, "null llr/bits");
     if ((rc = ensure_staging(ctx, final_lam != nullptr)) != LDPC_OK) return rc;
     const size_t N = (size_t)ctx->code->N, es = fmt == ldpc::LLR_F64 ? 8 : (fmt == ldpc::LLR_F16 ? 2 : 4);
+    if (batch <= ldpc_ctx::kSmallFrames && !final_lam && !trace_lam) {   // latency path
+        const size_t cap = (size_t)ldpc_ctx::kSmallFrames;
+        const size_t out_cap = cap * N + cap * sizeof(int32_t) + cap + 16;
+        if (!ctx->h_small_in) {
+            hipError_t e = hipHostMalloc(&ctx->h_small_in, cap * N * sizeof(double), hipHostMallocDefault);
+            if (e == hipSuccess) e = hipHostMalloc((void **)&ctx->h_small_out, out_cap, hipHostMallocDefault);
+            if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_small_out, out_cap);
+            if (e != hipSuccess) {
+                if (ctx->h_small_in) (void)hipHostFree(ctx->h_small_in);
+                if (ctx->h_small_out) (void)hipHostFree(ctx->h_small_out);
+                (void)hipFree(ctx->d_small_out);
+                ctx->h_small_in = nullptr; ctx->h_small_out = nullptr; ctx->d_small_out = nullptr;
+                return set_error(LDPC_ENOMEM, "latency-path buffers: %s", hipGetErrorString(e));
+            }
+        }
+        const size_t nb = (size_t)batch, in_bytes = nb * N * es;
+        const size_t off_it = (nb * N + 3) / 4 * 4, off_cv = off_it + nb * sizeof(int32_t), out_bytes = off_cv + nb;
+        memcpy(ctx->h_small_in, llr, in_bytes);
+        hipStream_t st = ctx->stream;
+        hipError_t e = hipMemcpyAsync(ctx->d_in[0], ctx->h_small_in, in_bytes, hipMemcpyHostToDevice, st);
+        if (e == hipSuccess) {
+            rc = decode_dev(ctx, st, max_iters, batch, ctx->d_in[0], fmt, ctx->d_small_out, (int32_t *)(ctx->d_small_out + off_it),
+                            ctx->d_small_out + off_cv, nullptr, nullptr);
+            if (rc == LDPC_OK) e = hipMemcpyAsync(ctx->h_small_out, ctx->d_small_out, out_bytes, hipMemcpyDeviceToHost, st);
+        }
+        hipError_t es2 = hipStreamSynchronize(st);   // also after an error: nothing may still be in flight
+        if (e == hipSuccess) e = es2;
+        if (rc == LDPC_OK && e != hipSuccess) rc = set_error(LDPC_EHIP, "decode: %s", hipGetErrorString(e));
+        if (rc != LDPC_OK) return rc;
+        memcpy(bits, ctx->h_small_out, nb * N);
+        if (iters) memcpy(iters, ctx->h_small_out + off_it, nb * sizeof(int32_t));
+        if (converged) memcpy(converged, ctx->h_small_out + off_cv, nb);
+        return LDPC_OK;
+    }
     double *d_trace = nullptr;
     const size_t turns = (size_t)max_iters + 1;
     if (trace_lam) {  // verification path: one device buffer for the whole batch

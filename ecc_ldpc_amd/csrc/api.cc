@@ -69,6 +69,9 @@ struct ldpc_ctx {
     static constexpr int kSmallFrames = 16;
     void *h_small_in = nullptr;
     uint8_t *h_small_out = nullptr, *d_small_out = nullptr;
+    // zero-copy path: outputs the caller gave as pageable memory while llr/bits are page-locked
+    int32_t *d_zc_iters = nullptr;
+    uint8_t *d_zc_conv = nullptr;
     ldpc::KernelTimer timer;
 };
 
@@ -266,6 +269,7 @@ void ldpc_ctx_destroy(ldpc_ctx *ctx) {
     if (ctx->h_small_in) (void)hipHostFree(ctx->h_small_in);
     if (ctx->h_small_out) (void)hipHostFree(ctx->h_small_out);
     (void)hipFree(ctx->d_small_out);
+    (void)hipFree(ctx->d_zc_iters); (void)hipFree(ctx->d_zc_conv);
     if (ctx->fused) ldpc::fused_destroy(ctx->fused);
     ctx->timer.destroy();
     if (ctx->stream) hipStreamDestroy(ctx->stream);
@@ -427,12 +431,51 @@ static int ensure_staging(ldpc_ctx *ctx, bool want_final) {
     return LDPC_OK;
 }
 
+// device-visible address of page-locked host memory (hipHostMalloc / hipHostRegister), or nullptr for pageable memory
+static void *pinned_device_ptr(const void *p) {
+    if (!p) return nullptr;
+    hipPointerAttribute_t at;
+    if (hipPointerGetAttributes(&at, p) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    if (at.type != hipMemoryTypeHost || !at.devicePointer) return nullptr;
+    return at.devicePointer;
+}
+
 static int decode_host(ldpc_ctx *ctx, int max_iters, int batch, const void *llr, int fmt, uint8_t *bits,
                        int32_t *iters, uint8_t *converged, double *final_lam, double *trace_lam) {
     int rc = check_call(ctx, max_iters, batch);
     if (rc != LDPC_OK) return rc;
     if (batch == 0) return LDPC_OK;
     if (!llr || !bits) return set_error(LDPC_EINVAL, "null llr/bits");
+    // Zero-copy: with page-locked llr and bits (ldpc_host_alloc) and a kernel that reads every LLR once, the decode
+    // kernel itself reads the LLRs and writes the bits over PCIe -- no staging copies, the transfer hides under the
+    // compute of the other workgroups.  Measured (65 536 jpl.4096 frames, min-sum): f32 26.9 ms vs 57.9 ms through
+    // the chunked copy pipeline, fp16 LLRs 24.6 vs 44.7 ms (copies issued next to the decode kernel did not overlap
+    // with it on this platform: pipeline time = copy time + kernel time).
+    if (!final_lam && !trace_lam && batch > ldpc_ctx::kSmallFrames &&
+        (ctx->path == LDPC_PATH_FLOOD || ldpc::fused_reads_llr_once(*ctx->fused, max_iters))) {
+        void *z_llr = pinned_device_ptr(llr), *z_bits = pinned_device_ptr(bits);
+        if (z_llr && z_bits) {
+            int32_t *z_it = (int32_t *)pinned_device_ptr(iters);
+            uint8_t *z_cv = (uint8_t *)pinned_device_ptr(converged);
+            if (iters && !z_it) {
+                if (!ctx->d_zc_iters) HIPCHK(hipMalloc((void **)&ctx->d_zc_iters, sizeof(int32_t) * (size_t)ctx->max_batch));
+                z_it = ctx->d_zc_iters;
+            }
+            if (converged && !z_cv) {
+                if (!ctx->d_zc_conv) HIPCHK(hipMalloc((void **)&ctx->d_zc_conv, (size_t)ctx->max_batch));
+                z_cv = ctx->d_zc_conv;
+            }
+            hipStream_t st = ctx->stream;
+            rc = decode_dev(ctx, st, max_iters, batch, z_llr, fmt, (uint8_t *)z_bits, z_it, z_cv, nullptr, nullptr);
+            hipError_t e = hipSuccess;
+            if (rc == LDPC_OK && iters && z_it == ctx->d_zc_iters) e = hipMemcpyAsync(iters, z_it, sizeof(int32_t) * (size_t)batch, hipMemcpyDeviceToHost, st);
+            if (rc == LDPC_OK && e == hipSuccess && converged && z_cv == ctx->d_zc_conv) e = hipMemcpyAsync(converged, z_cv, (size_t)batch, hipMemcpyDeviceToHost, st);
+            hipError_t es2 = hipStreamSynchronize(st);
+            if (e == hipSuccess) e = es2;
+            if (rc == LDPC_OK && e != hipSuccess) rc = set_error(LDPC_EHIP, "decode (zero-copy): %s", hipGetErrorString(e));
+            return rc;
+        }
+    }
     if ((rc = ensure_staging(ctx, final_lam != nullptr)) != LDPC_OK) return rc;
     const size_t N = (size_t)ctx->code->N, es = fmt == ldpc::LLR_F64 ? 8 : (fmt == ldpc::LLR_F16 ? 2 : 4);
     if (batch <= ldpc_ctx::kSmallFrames && !final_lam && !trace_lam) {   // latency path

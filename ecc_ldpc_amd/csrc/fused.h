@@ -20,6 +20,9 @@ int fused_step(FusedState &s, hipStream_t st, int batch, const double *d_orig, c
 
 // name of the kernel fused_decode launches for this state (as rocprofv3 lists it, without template arguments)
 const char *fused_kernel_name(const FusedState &s);
+// whether the kernel fused_decode launches reads every channel LLR from memory exactly once (then the LLRs may sit in
+// page-locked HOST memory and be read over PCIe by the kernel itself: api.cc zero-copy path)
+bool fused_reads_llr_once(const FusedState &s, int max_iters);
 
 // generic on-chip kernel for any H that fits in LDS (fused_csr.hip); reached through the functions above
 struct CsrState;

@@ -482,6 +482,10 @@ void fused_destroy(FusedState *s) {
 
 void fused_set_timer(FusedState *s, KernelTimer *t) { if (s) { s->timer = t; fused_csr_set_timer(s->csr, t); } }
 
+bool fused_reads_llr_once(const FusedState &s, int max_iters) {
+    return s.csr != nullptr || (s.use_split && max_iters <= kSplitMaxIters);
+}
+
 const char *fused_kernel_name(const FusedState &s) {
     if (s.csr) return "fused_csr_kernel";
     if (s.use_split) return "fused_split_kernel";

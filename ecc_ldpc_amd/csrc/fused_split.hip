@@ -174,24 +174,31 @@ __device__ __forceinline__ void split_body(const FusedArgs &A, char *lds, const 
     for (int i = 0; i < (SPLIT_ORIG_REGS ? S::NORIG : 1); i++) orig[i] = CT(0);
     // ---- lam <- LLRs (or the given lam): pair P fills the block columns bc with bc % 2 == P.  One dispatch on the
     // LLR element type around ALL of the thread's loads (46 of them): they issue back to back.
+    // Every channel LLR is read from global memory ONCE (the input may be page-locked HOST memory read over PCIe,
+    // api.cc zero-copy path): the hard decisions of the thread's own columns are kept in `obits` -- the answer of a
+    // frame that runs out of turns (Orig.hs:70) -- and the rotated copies phase B wants come out of LDS below.
+    uint32_t obits = 0;
     with_llr_format(A.llr_fmt, [&](auto fc) {
         constexpr int FMT = decltype(fc)::value;
         static_for<0, Plan::NBC>([&](auto bcc) {
             constexpr int bc = decltype(bcc)::value;
             if constexpr ((bc & 1) == P) {
                 CT v = maybe_round_f16<CT>(load_llr_as<CT, FMT>(A.llr, fN + bc * SZ + r0), A.llr_round16);
+                obits |= (v > CT(0) ? 1u : 0u) << (bc >> 1);
                 if (A.step_mode) v = (CT)A.st_lam[fN + bc * SZ + r0];
                 lds_st<CT>(lds, p4 | (bc * V * ES), v);
             }
         });
-        static_for<0, Plan::NBC>([&](auto bcc) {
-            constexpr int bc = decltype(bcc)::value;
-            if constexpr (SPLIT_ORIG_REGS && S::oowner(bc) == P) {
-                constexpr int e0 = Rounds<T>::round0_edge(bc);
-                constexpr int os = S::oslot(bc);
-                orig[os] = maybe_round_f16<CT>(load_llr_as<CT, FMT>(A.llr, fN + bc * SZ + ((r0 + T::rot[e0]) & (SZ - 1))), A.llr_round16);
-            }
-        });
+        if (A.step_mode) {   // teacher-forced step: LDS holds the given lam, the channel LLRs come from memory
+            static_for<0, Plan::NBC>([&](auto bcc) {
+                constexpr int bc = decltype(bcc)::value;
+                if constexpr (SPLIT_ORIG_REGS && S::oowner(bc) == P) {
+                    constexpr int e0 = Rounds<T>::round0_edge(bc);
+                    constexpr int os = S::oslot(bc);
+                    orig[os] = maybe_round_f16<CT>(load_llr_as<CT, FMT>(A.llr, fN + bc * SZ + ((r0 + T::rot[e0]) & (SZ - 1))), A.llr_round16);
+                }
+            });
+        }
     });
     if (A.step_mode) {
         static_for<0, Plan::NBR>([&](auto brc) {
@@ -207,6 +214,16 @@ __device__ __forceinline__ void split_body(const FusedArgs &A, char *lds, const 
         });
     }
     __syncthreads();
+    if (!A.step_mode) {   // lam == channel LLRs right now: the round-0 (rotated) copies are an LDS gather away
+        static_for<0, Plan::NBC>([&](auto bcc) {
+            constexpr int bc = decltype(bcc)::value;
+            if constexpr (SPLIT_ORIG_REGS && S::oowner(bc) == P) {
+                constexpr int e0 = Rounds<T>::round0_edge(bc);
+                constexpr int os = S::oslot(bc);
+                orig[os] = lds_ld<CT>(lds + bc * V * ES, (p4 + T::rot[e0] * CPW * ES) & vmask);
+            }
+        });
+    }
 
     volatile uint32_t *flags = reinterpret_cast<volatile uint32_t *>(lds + LAM_BYTES);
     // done: bit s = frame s of this workgroup has finished.  Workgroup-uniform (derived from the shared flags), so
@@ -220,7 +237,7 @@ __device__ __forceinline__ void split_body(const FusedArgs &A, char *lds, const 
     // bits 0..21: hard(lam) of this lane's columns at the moment its frame converged; bit 22: converged;
     // bits 23..31: the iteration it converged at (max_iters <= kSplitMaxIters: fused.hip falls back to fused_msg above)
     static_assert(Plan::NBC <= 44, "result word layout");
-    uint32_t res = 0;
+    uint32_t res = obits;   // until the frame converges: the hard decisions of its channel LLRs (bit 22 clear)
     const int turns = A.step_mode ? 1 : A.max_iters;
 
     for (int n = 0;; n++) {
@@ -326,18 +343,22 @@ __device__ __forceinline__ void split_body(const FusedArgs &A, char *lds, const 
             if constexpr ((bc & 1) == P) A.bits[w.fN + bc * SZ + w.r0] = (res >> (bc >> 1)) & 1u;
         });
     } else {
-        with_llr_format(A.llr_fmt, [&](auto fc) {
-            constexpr int FMT = decltype(fc)::value;
-            static_for<0, Plan::NBC>([&](auto bcc) {
-                constexpr int bc = decltype(bcc)::value;
-                if constexpr ((bc & 1) == P) {
-                    const size_t gi = w.fN + bc * SZ + w.r0;
-                    const CT v = maybe_round_f16<CT>(load_llr_as<CT, FMT>(A.llr, gi), A.llr_round16);
-                    A.bits[gi] = v > CT(0) ? 1 : 0;
-                    if (A.final_lam) A.final_lam[gi] = (double)v;
-                }
-            });
+        static_for<0, Plan::NBC>([&](auto bcc) {
+            constexpr int bc = decltype(bcc)::value;
+            if constexpr ((bc & 1) == P) A.bits[w.fN + bc * SZ + w.r0] = (res >> (bc >> 1)) & 1u;   // hard(channel LLR)
         });
+        if (A.final_lam) {
+            with_llr_format(A.llr_fmt, [&](auto fc) {
+                constexpr int FMT = decltype(fc)::value;
+                static_for<0, Plan::NBC>([&](auto bcc) {
+                    constexpr int bc = decltype(bcc)::value;
+                    if constexpr ((bc & 1) == P) {
+                        const size_t gi = w.fN + bc * SZ + w.r0;
+                        A.final_lam[gi] = (double)maybe_round_f16<CT>(load_llr_as<CT, FMT>(A.llr, gi), A.llr_round16);
+                    }
+                });
+            });
+        }
     }
     if (w.r0 == 0 && P == 0) {
         if (A.iters) A.iters[w.frame] = converged ? (int)(res >> 23) : turns;

@@ -267,3 +267,22 @@ def test_many_iterations_leave_the_split_kernel(hip):
         a = hip.Decoder(code, "min", "f32", len(llr), path="fused").decode_batch(llr, iters)
         b = hip.Decoder(code, "min", "f32", len(llr), path="flood").decode_batch(llr, iters)
         assert all(np.array_equal(x, y) for x, y in zip(a, b)) and int(a[1].max()) == iters
+
+
+@pytest.mark.parametrize("name,qc,path", [("jpl.1024.4.5", True, "fused"), ("1920.1280.3.303", False, "fused"), ("jpl.1024.4.5", True, "flood")])
+def test_zero_copy_host_path_equals_staged_path(hip, name, qc, path):
+    """With page-locked llr and bits buffers (ldpc_host_alloc) the decode kernel reads the LLRs and writes the bits
+    over PCIe itself; pageable buffers go through the chunked copy pipeline.  Same answers either way, for f32 and
+    fp16 LLR buffers, with the iteration counts returned into pageable or page-locked memory."""
+    c = load(name)
+    B = 600
+    _, llr = c.frames(B, 3.0 if qc else 1.5, seed=606)
+    dec = hip.Decoder(c.hip_code(hip, prefer_qc=qc), "min", "f32", B, path=path)
+    for dt in (np.float32, np.float16):
+        src = np.clip(llr, -6e4, 6e4).astype(dt)
+        want = dec.decode_batch(src, 50)                       # pageable -> staged copies
+        pin_in = hip.PinnedArray((B, c.N), dt); pin_in.array[:] = src
+        pin_out = hip.PinnedArray((B, c.N), np.uint8); pin_out.array[:] = 7
+        got = dec.decode_batch(pin_in.array, 50, out_bits=pin_out.array)   # page-locked -> zero-copy
+        assert got[0] is pin_out.array and all(np.array_equal(x, y) for x, y in zip(got, want))
+        assert 0 < int(want[2].sum()) < B                      # a mixed batch

@@ -6,6 +6,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import ecc_ldpc_amd as E
 E.init(0)
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
+ITERS = int(sys.argv[2]) if len(sys.argv) > 2 else 50
 ecc = E.ECC("codes", "ldpc/hip-minsum/jpl.4096.4.5/50/4/5", max_batch=B)
 N, k, n_tx = ecc.code.N, ecc.message_length, ecc.codeword_length
 rng = np.random.default_rng(1)
@@ -22,9 +23,9 @@ for dt_np, label in ((np.float32, "f32 LLRs"), (np.float16, "fp16 LLRs")):
         pinned = rep >= 3
         t0 = time.perf_counter()
         if pinned:
-            bits, its, conv = ecc.decoder.decode_batch(pin_in.array, 50, out_bits=pin_out.array)
+            bits, its, conv = ecc.decoder.decode_batch(pin_in.array, ITERS, out_bits=pin_out.array)
         else:
-            bits, its, conv = ecc.decoder.decode_batch(src, 50)
+            bits, its, conv = ecc.decoder.decode_batch(src, ITERS)
         dt = time.perf_counter() - t0
         print(f"ldpc_decode_batch host->host {label} ({'pinned  ' if pinned else 'pageable'}): {B} frames in {dt * 1e3:7.1f} ms = {B * k / dt / 1e6:8.1f} Mbit/s  "
               f"(H2D {src.nbytes / 1e6:.0f} MB, D2H {bits.nbytes / 1e6:.0f} MB; mean iters {its.mean():.1f})", flush=True)

@@ -34,11 +34,11 @@
 #ifndef SPLIT_WAVES_PER_EU
 #define SPLIT_WAVES_PER_EU 4
 #endif
-// the tanh rule needs ~3 transient registers per edge of a row (e, suffix A, suffix S): at 128 VGPRs it spills
-// ~450 registers, at 3 waves per SIMD / 168 VGPRs ~90, at 2 waves / 207 VGPRs none (measured with the
-// product/complement form: 2.44 / 4.16 / 4.26 Gbit/s on jpl.4096)
+// the tanh rule needs ~3 transient registers per edge of a row (e, suffix A, suffix S).  Measured on jpl.4096,
+// 16 384 frames, hyperbolic-recurrence rule: 2 waves per SIMD (209 VGPRs, no spills) 4.92 Gbit/s, 3 waves
+// (168 VGPRs, 37 spilled) 5.80; 4 waves (128 VGPRs) spills several hundred registers.
 #ifndef SPLIT_TANH_WAVES_PER_EU
-#define SPLIT_TANH_WAVES_PER_EU 2
+#define SPLIT_TANH_WAVES_PER_EU 3
 #endif
 
 namespace ldpc {

@@ -189,13 +189,14 @@ def measured_traffic(args, dec, B):
     command), scaled by frames per launch; None when no profile of this configuration is committed."""
     if not (dec.path == "fused" and args.variant == "minsum" and args.dtype == "f32"):
         return None
-    tag = {"jpl.4096.4.5": "r01_split3_jpl4096_f32_minsum", "jpl.1024.4.5": "r01_split3_jpl1024_f32_minsum"}.get(args.code)
+    tag = {"jpl.4096.4.5": "r01_final_jpl4096_f32_minsum", "jpl.1024.4.5": "r01_final_jpl1024_f32_minsum"}.get(args.code)
     if tag is None:
         return None
     try:
         prof = json.load(open(os.path.join(ROOT, "profiles", tag + "_pmc.json")))
         h = prof["hbm_bytes_per_launch"]   # collected at 65536 frames per launch (tools/profile.sh)
-        return int((h["FETCH_SIZE_raw_bytes"] + h["WRITE_SIZE_bytes"]) * B / 65536)
+        fetch = h.get("FETCH_SIZE_corrected_bytes", 2 * h["FETCH_SIZE_raw_bytes"])   # gfx950: raw FETCH_SIZE is 1/2 of the bytes
+        return int((fetch + h["WRITE_SIZE_bytes"]) * B / 65536)
     except Exception:
         return None
 

@@ -188,9 +188,26 @@ __global__ __launch_bounds__(256) void flood_vn_kernel(FloodDev d, const ST *__r
     }
     CT acc = Store<ST>::ld(orig + (size_t)col * d.Bp + b);
     const int qb = d.col_ptr[col], qe = d.col_ptr[col + 1];
-    for (int q = qe - 1; q >= qb; q--) { // Orig.hs:96: foldr => last row first
-        int e = d.csc_edge[q];
-        acc = Store<ST>::ld(msg + (size_t)e * d.Bp + b) + acc;
+    // Orig.hs:96: foldr => last row first.  Columns of weight <= 8: every edge index (scalar loads), then every
+    // message load, are issued before the first sum -- with a dynamic loop the wave pays one memory round trip per
+    // edge (measured on jpl.4096, 16 384 frames: 699 -> 596 us per launch).
+    constexpr int U = 8;
+    if (qe - qb <= U) {
+        const int deg = qe - qb;   // wave-uniform
+        int e[U];
+        CT v[U];
+#pragma unroll
+        for (int j = 0; j < U; j++) e[j] = (j < deg) ? d.csc_edge[qe - 1 - j] : 0;
+#pragma unroll
+        for (int j = 0; j < U; j++) v[j] = (j < deg) ? Store<ST>::ld(msg + (size_t)e[j] * d.Bp + b) : CT(0);
+#pragma unroll
+        for (int j = 0; j < U; j++)
+            if (j < deg) acc = v[j] + acc;
+    } else {
+        for (int q = qe - 1; q >= qb; q--) {
+            int e = d.csc_edge[q];
+            acc = Store<ST>::ld(msg + (size_t)e * d.Bp + b) + acc;
+        }
     }
     Store<ST>::st(lam + (size_t)col * d.Bp + b, acc);
 }

@@ -153,6 +153,10 @@ def main():
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": measured_traffic(args, dec, B),
                 "kernel": dec.kernel_name, "launches": launches, "avg_launch_ms": round(avg_ms, 4),
                 "algorithmic_bytes_per_launch": bytes_per_launch, "bytes_model": bytes_note}
+    if dec.path == "fused":
+        # the fused kernels keep the BP state on-chip, so `frac` (the contract's HBM byte model) exceeds 1; what binds
+        # them is VALU issue -- figures from the committed PMC passes of this workload, when there are any
+        roofline["binding_resource"] = onchip_note(args)
 
     out = None
     if rank == 0:
@@ -199,6 +203,23 @@ def measured_traffic(args, dec, B):
         return int((fetch + h["WRITE_SIZE_bytes"]) * B / 65536)
     except Exception:
         return None
+
+
+def onchip_note(args):
+    tag = {("jpl.4096.4.5", "minsum"): "r01_final_jpl4096_f32_minsum", ("jpl.1024.4.5", "minsum"): "r01_final_jpl1024_f32_minsum",
+           ("jpl.4096.4.5", "tanh"): "r01_final_jpl4096_f32_tanh", ("1920.1280.3.303", "tanh"): "r01_final_mackay_f32_tanh"}.get((args.code, args.variant))
+    note = {"bound": "valu issue + LDS round trips (state on-chip; HBM carries the LLRs in and the bits out only)"}
+    try:
+        m = json.load(open(os.path.join(ROOT, "profiles", tag + "_pmc.json")))["per_dispatch_mean"]
+        gui = m["GRBM_GUI_ACTIVE"] / 8          # summed over the 8 XCDs
+        note.update({"source": f"profiles/{tag}_pmc.json",
+                     "valu_issue_interval_clk_per_simd": round(gui * 1024 / m["SQ_INSTS_VALU"], 2),
+                     "waves_per_cu": round(m["SQ_WAVE_CYCLES"] * 4 / gui / 256, 1),
+                     "lds_busy": round(m["SQ_LDS_IDX_ACTIVE"] / (gui * 256), 2),
+                     "lds_bank_conflict_share": round(m["SQ_LDS_BANK_CONFLICT"] / max(m["SQ_LDS_IDX_ACTIVE"], 1), 2)})
+    except Exception:
+        pass
+    return note
 
 
 def host_cores():

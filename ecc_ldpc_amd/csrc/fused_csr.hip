@@ -358,6 +358,7 @@ __global__ __launch_bounds__(kCsrThreads, (DMAX <= 8 ? 4 : 1)) void fused_csr_ba
 // ------------------------------------------------------------------ host side
 struct CsrState {
     int variant = 0, dtype = 0, M = 0, N = 0, E = 0, dmax = 0, cdmax = 0, round16 = 0;
+    bool want_batched = true, want_cache = true;   // A/B switches, read from the environment once, at creation
     int32_t *d_ell = nullptr, *d_csc = nullptr, *d_row_ptr = nullptr;
     // batched kernel: the same tables in POSITION space (conflict-aware placement of rows and columns in LDS)
     int32_t *d_ell_b = nullptr, *d_csc_b = nullptr, *d_row_of_pos = nullptr, *d_col_of_pos = nullptr;
@@ -523,6 +524,11 @@ CsrState *fused_csr_create(const ldpc_code &c, int variant, int dtype) {
     if (!s) { set_error(LDPC_ENOMEM, "out of host memory"); return nullptr; }
     s->variant = variant; s->dtype = dtype; s->M = c.M; s->N = c.N; s->E = c.E;
     s->dmax = pick_dmax(c.max_row_deg); s->cdmax = c.max_col_deg;
+    {   // LDPC_CSR_BATCHED=0: row-by-row kernel; LDPC_CSR_NOCACHE: its indices re-read from memory every turn
+        const char *bz = getenv("LDPC_CSR_BATCHED");
+        s->want_batched = !(bz && !strcmp(bz, "0"));
+        s->want_cache = getenv("LDPC_CSR_NOCACHE") == nullptr;
+    }
     std::vector<int32_t> ell((size_t)s->dmax * c.M, -1), csc((size_t)std::max(s->cdmax, 1) * c.N, -1), slot_of_edge((size_t)c.E);
     for (int m = 0; m < c.M; m++)
         for (int e = c.row_ptr[m]; e < c.row_ptr[m + 1]; e++) {
@@ -607,8 +613,7 @@ template <typename CT, int VARIANT>
 static int dispatch_dmax(CsrState &s, hipStream_t st, CsrArgs &a) {
     // small per-thread shares (f32): the batched kernel; LDPC_CSR_BATCHED=0 keeps the row-by-row kernel (A/B)
     if constexpr (sizeof(CT) == 4) {
-        const char *bz = getenv("LDPC_CSR_BATCHED");
-        const int shape = (s.d_ell_b && !(bz && !strcmp(bz, "0"))) ? batched_shape(s) : 0;
+        const int shape = (s.d_ell_b && s.want_batched) ? batched_shape(s) : 0;
         if (shape) {
             a.ell_col = s.d_ell_b; a.csc_slot = s.d_csc_b; a.row_of_pos = s.d_row_of_pos; a.col_of_pos = s.d_col_of_pos;
             if (shape == 1) return launch_csr_batched<CT, VARIANT, 4, 6, 8, 4>(s, st, a);
@@ -621,7 +626,7 @@ static int dispatch_dmax(CsrState &s, hipStream_t st, CsrArgs &a) {
     const int rpt = (s.M + kCsrThreads - 1) / kCsrThreads, cpt = (s.N + kCsrThreads - 1) / kCsrThreads;
     // measured on codes/1920.1280.3.303, 1 dB: min-sum 1 878 vs 1 586 Mbit/s with cached indices, but tanh
     // 1 209 vs 1 665 (its check node needs the registers: 154 VGPRs -> 3 waves/SIMD), so min-sum only
-    const bool cache_ok = VARIANT == LDPC_V_MINSUM && sizeof(CT) == 4 && cpt <= 8 && s.cdmax <= kCdMax && !getenv("LDPC_CSR_NOCACHE");
+    const bool cache_ok = VARIANT == LDPC_V_MINSUM && sizeof(CT) == 4 && cpt <= 8 && s.cdmax <= kCdMax && s.want_cache;
     switch (s.dmax) {
         case 4:
             if (cache_ok && rpt <= 6) return launch_csr<CT, VARIANT, 4, 6, 8>(s, st, a);

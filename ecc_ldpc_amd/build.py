@@ -9,6 +9,8 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libldpc_hip.so")
+CLI = os.path.join(HERE, "ecc-ldpc-hip")
+# (cli_main.cc is the stand-alone executable, built separately below)
 SOURCES = ["api.cc", "host.cc", "flood.hip", "fused.hip", "fused_msg.hip", "fused_split.hip", "fused_csr.hip", "sim.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-Wall", "-Wno-unused-function", "-Wno-unused-value",
@@ -48,6 +50,13 @@ def build(force: bool = False, verbose: bool = True) -> str:
             raise RuntimeError(f"hipcc failed on {s}")
     if force or procs or _stale(OUT, objs):
         cmd = [HIPCC, "-shared", "-fPIC", "--offload-arch=gfx950", "-o", OUT] + objs
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    # the native command-line driver (host code only; binds the C ABI like any other C/C++ host would)
+    cli_src = os.path.join(CSRC, "cli_main.cc")
+    if force or _stale(CLI, [cli_src, OUT] + hdrs):
+        cmd = [HIPCC, "-O2", "-std=c++17", "-Wall", "-x", "hip", cli_src, "-o", CLI, "-L" + HERE, "-lldpc_hip", "-Wl,-rpath,$ORIGIN"]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)

@@ -153,3 +153,22 @@ def test_cli_rows(hip, capsys):
     assert rc == 0 and len(rows) == 2 and "no such code" in out.err
     assert rows[0][1] == "ldpc/hip-minsum/jpl.1024.4.5/50/4/5" and int(rows[0][3]) == 2048
     assert float(rows[0][5]) > float(rows[1][5]) and float(rows[1][5]) == 0.0  # BER falls with Eb/N0; 4.5 dB is clean
+
+
+@pytest.mark.gpu
+def test_native_cli_matches_python_cli(hip, capsys):
+    """ecc-ldpc-hip (C++ over the C ABI, csrc/cli_main.cc) and the Python command line drive the same library with
+    the same frame source: identical frame / bit-error counts, row for row."""
+    import subprocess
+    from ecc_ldpc_amd import cli
+    from ecc_ldpc_amd.build import CLI
+    args = ["3", "3.5", "ldpc/hip-minsum/jpl.1024.4.5/50/4/5", "ldpc/hip-tanh/1920.1280.3.303/50", "ldpc/nonsense/jpl.1024.4.5/50", "-m8192", "-b4096"]
+    p = subprocess.run([CLI] + args + ["-c" + CODES], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr
+    assert "nonsense" in p.stderr                      # unknown decoder: skipped with a note, as the Python CLI does
+    native = [l.split() for l in p.stdout.splitlines() if l.strip()]
+    assert cli.main(args) == 0
+    py = [l.split() for l in capsys.readouterr().out.splitlines() if l.strip()]
+    assert len(native) == len(py) == 4
+    for a, b in zip(native, py):
+        assert a[1:6] == b[1:6] and a[-1] == b[-1]     # name, Eb/N0, frames, bit errors, BER ... [path]

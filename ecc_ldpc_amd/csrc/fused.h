@@ -30,6 +30,7 @@ const char *fused_csr_why_not(const ldpc_code &code, int variant, int dtype);
 CsrState *fused_csr_create(const ldpc_code &code, int variant, int dtype);
 void fused_csr_destroy(CsrState *s);
 void fused_csr_set_timer(CsrState *s, KernelTimer *t);
+const char *fused_csr_kernel_name(const CsrState &s);
 void fused_csr_set_round16(CsrState *s, int on);  // LDPC_F16 context: LLRs count as stored in fp16
 int fused_csr_decode(CsrState &s, hipStream_t st, int max_iters, int batch, const void *d_llr, int llr_fmt, uint8_t *d_bits,
                      int32_t *d_iters, uint8_t *d_conv, double *d_final, double *d_trace);

@@ -487,7 +487,7 @@ bool fused_reads_llr_once(const FusedState &s, int max_iters) {
 }
 
 const char *fused_kernel_name(const FusedState &s) {
-    if (s.csr) return "fused_csr_kernel";
+    if (s.csr) return fused_csr_kernel_name(*s.csr);
     if (s.use_split) return "fused_split_kernel";
     if (s.use_msg) return "fused_msg_kernel";
     return "fused_decode_kernel";

@@ -577,6 +577,9 @@ CsrState *fused_csr_create(const ldpc_code &c, int variant, int dtype) {
 }
 
 void fused_csr_set_timer(CsrState *s, KernelTimer *t) { if (s) s->timer = t; }
+const char *fused_csr_kernel_name(const CsrState &s) {
+    return (s.dtype == LDPC_F32 && s.d_ell_b && s.want_batched && batched_shape(s)) ? "fused_csr_batched_kernel" : "fused_csr_kernel";
+}
 void fused_csr_set_round16(CsrState *s, int on) { if (s) s->round16 = on; }
 
 template <typename CT, int VARIANT, int DMAX, int RPT, int CPT>

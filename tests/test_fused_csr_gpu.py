@@ -110,10 +110,12 @@ def test_batched_kernel_equals_row_by_row_kernel(hip, monkeypatch, name, iters, 
     llr = _frames(c, 40, dbs, 1900).astype(np.float32)
     code = _code(hip, c)
     a = hip.Decoder(code, variant, "f32", len(llr), path="fused")
-    assert a.kernel_name == "fused_csr_kernel"
+    assert a.kernel_name == "fused_csr_batched_kernel"
     ra = a.decode_batch(llr.astype(np.float64), iters, want_lam=True)
     monkeypatch.setenv("LDPC_CSR_BATCHED", "0")
-    rb = hip.Decoder(code, variant, "f32", len(llr), path="fused").decode_batch(llr.astype(np.float64), iters, want_lam=True)
+    b = hip.Decoder(code, variant, "f32", len(llr), path="fused")
+    assert b.kernel_name == "fused_csr_kernel"
+    rb = b.decode_batch(llr.astype(np.float64), iters, want_lam=True)
     assert len(set(ra[1].tolist())) > 2
     assert all(np.array_equal(x, y) for x, y in zip(ra, rb))
 

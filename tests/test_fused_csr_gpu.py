@@ -110,7 +110,8 @@ def test_batched_kernel_equals_row_by_row_kernel(hip, monkeypatch, name, iters, 
     llr = _frames(c, 40, dbs, 1900).astype(np.float32)
     code = _code(hip, c)
     a = hip.Decoder(code, variant, "f32", len(llr), path="fused")
-    assert a.kernel_name == "fused_csr_batched_kernel"
+    # (moon.7.13 has columns of weight > 8: no batched instance, both runs use the row-by-row kernel)
+    assert a.kernel_name == ("fused_csr_kernel" if name == "moon.7.13" else "fused_csr_batched_kernel")
     ra = a.decode_batch(llr.astype(np.float64), iters, want_lam=True)
     monkeypatch.setenv("LDPC_CSR_BATCHED", "0")
     b = hip.Decoder(code, variant, "f32", len(llr), path="fused")

@@ -34,6 +34,11 @@
 #ifndef SPLIT_WAVES_PER_EU
 #define SPLIT_WAVES_PER_EU 4
 #endif
+// edges per read-add-write batch inside a column round (2 registers per edge in flight).  Measured on jpl.4096,
+// 65 536 frames: 4: 20.66 ms, 6: 20.15, 8: 20.01, 10: 19.50, 11: 19.36, 12: 19.29, 14: 19.42, 16: 19.57, 24: 19.47.
+#ifndef SPLIT_CH
+#define SPLIT_CH 12
+#endif
 // the tanh rule needs ~3 transient registers per edge of a row (e, suffix A, suffix S).  Measured on jpl.4096,
 // 16 384 frames, hyperbolic-recurrence rule: 2 waves per SIMD (209 VGPRs, no spills) 4.92 Gbit/s, 3 waves
 // (168 VGPRs, 37 spilled) 5.80; 4 waves (128 VGPRs) spills several hundred registers.
@@ -126,7 +131,7 @@ __device__ __forceinline__ void split_round_chunk(char *lds, uint32_t p4, uint32
 }
 template <typename CT, int SZ, class Plan, class T, int P, int Q, int I0>
 __device__ __forceinline__ void split_round(char *lds, uint32_t p4, uint32_t vmask, const CT *msg, const CT *orig_rot, const float *gllr, uint32_t r0) {
-    constexpr int CNT = Split<Plan, T>::count(Q, P), CH = 8;
+    constexpr int CNT = Split<Plan, T>::count(Q, P), CH = SPLIT_CH;
     if constexpr (I0 < CNT) {
         split_round_chunk<CT, SZ, Plan, T, P, Q, I0, (I0 + CH < CNT ? I0 + CH : CNT)>(lds, p4, vmask, msg, orig_rot, gllr, r0);
         split_round<CT, SZ, Plan, T, P, Q, I0 + CH>(lds, p4, vmask, msg, orig_rot, gllr, r0);

@@ -39,6 +39,10 @@
 #ifndef SPLIT_CH
 #define SPLIT_CH 12
 #endif
+// sz = 32 (two frames per workgroup, one wave per pair): jpl.1024 4.80 ms at 12, 4.76 at 16, 4.68 at 24
+#ifndef SPLIT_CH_SMALL
+#define SPLIT_CH_SMALL 24
+#endif
 // the tanh rule needs ~3 transient registers per edge of a row (e, suffix A, suffix S).  Measured on jpl.4096,
 // 16 384 frames, hyperbolic-recurrence rule: 2 waves per SIMD (209 VGPRs, no spills) 4.92 Gbit/s, 3 waves
 // (168 VGPRs, 37 spilled) 5.80; 4 waves (128 VGPRs) spills several hundred registers.
@@ -131,7 +135,7 @@ __device__ __forceinline__ void split_round_chunk(char *lds, uint32_t p4, uint32
 }
 template <typename CT, int SZ, class Plan, class T, int P, int Q, int I0>
 __device__ __forceinline__ void split_round(char *lds, uint32_t p4, uint32_t vmask, const CT *msg, const CT *orig_rot, const float *gllr, uint32_t r0) {
-    constexpr int CNT = Split<Plan, T>::count(Q, P), CH = SPLIT_CH;
+    constexpr int CNT = Split<Plan, T>::count(Q, P), CH = SZ < 64 ? SPLIT_CH_SMALL : SPLIT_CH;
     if constexpr (I0 < CNT) {
         split_round_chunk<CT, SZ, Plan, T, P, Q, I0, (I0 + CH < CNT ? I0 + CH : CNT)>(lds, p4, vmask, msg, orig_rot, gllr, r0);
         split_round<CT, SZ, Plan, T, P, Q, I0 + CH>(lds, p4, vmask, msg, orig_rot, gllr, r0);

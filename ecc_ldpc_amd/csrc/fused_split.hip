@@ -36,6 +36,11 @@
 #endif
 // edges per read-add-write batch inside a column round (2 registers per edge in flight).  Measured on jpl.4096,
 // 65 536 frames: 4: 20.66 ms, 6: 20.15, 8: 20.01, 10: 19.50, 11: 19.36, 12: 19.29, 14: 19.42, 16: 19.57, 24: 19.47.
+// number of wave groups a frame's block rows are dealt to (block row br -> group br % SPLIT_NP).  2 = the wave
+// PAIRS described above.
+#ifndef SPLIT_NP
+#define SPLIT_NP 2
+#endif
 #ifndef SPLIT_CH
 #define SPLIT_CH 12
 #endif
@@ -60,7 +65,7 @@ struct Split {
         for (int b = 0; b < Plan::NBR; b++) if (Plan::ebeg(b) <= e) br = b;
         return br;
     }
-    static constexpr int owner_br(int br) { return br & 1; }
+    static constexpr int owner_br(int br) { return br % SPLIT_NP; }
     static constexpr int owner(int e) { return owner_br(br_of(e)); }
     static constexpr int slot(int e) {  // index of e among its owner's edges, plan order
         int c = 0;
@@ -72,7 +77,8 @@ struct Split {
         for (int e = 0; e < T::NEDGE; e++) c += owner(e) == p ? 1 : 0;
         return c;
     }
-    static constexpr int NMSG = nmsg(0) > nmsg(1) ? nmsg(0) : nmsg(1);
+    static constexpr int max_over_groups(int (*f)(int)) { int m = 0; for (int g = 0; g < SPLIT_NP; g++) m = f(g) > m ? f(g) : m; return m; }
+    static constexpr int NMSG = max_over_groups(nmsg);
     // channel LLR of the column a thread writes in round 0 of block column bc: held by the owner of that edge
     static constexpr int oowner(int bc) { return owner(Rounds<T>::round0_edge(bc)); }
     static constexpr int oslot(int bc) {
@@ -85,7 +91,7 @@ struct Split {
         for (int bc = 0; bc < T::NBC; bc++) c += oowner(bc) == p ? 1 : 0;
         return c;
     }
-    static constexpr int NORIG = norig(0) > norig(1) ? norig(0) : norig(1);
+    static constexpr int NORIG = max_over_groups(norig);
     // edges of round q owned by pair p, highest edge index first
     static constexpr int count(int q, int p) {
         int c = 0;
@@ -151,7 +157,7 @@ template <typename CT, int VARIANT, class Plan, int SZ, class T, int P>
 __device__ __forceinline__ void split_body(const FusedArgs &A, char *lds, const uint32_t tid) {
     using S = Split<Plan, T>;
     constexpr int CPW = SZ >= 64 ? 1 : 64 / SZ, V = SZ * CPW;  // frames per workgroup, threads per pair
-    constexpr int N = Plan::NBC * SZ, THREADS = 2 * V, NW = THREADS / 64;
+    constexpr int N = Plan::NBC * SZ, THREADS = SPLIT_NP * V, NW = THREADS / 64;
     constexpr uint32_t ES = sizeof(CT), vmask = V * ES - 1;
     constexpr int LAM_BYTES = Plan::NBC * V * (int)ES;
     // Only p4 (the lane's LDS byte offset inside a block column) lives across the iteration loop; everything else
@@ -191,9 +197,9 @@ __device__ __forceinline__ void split_body(const FusedArgs &A, char *lds, const 
         constexpr int FMT = decltype(fc)::value;
         static_for<0, Plan::NBC>([&](auto bcc) {
             constexpr int bc = decltype(bcc)::value;
-            if constexpr ((bc & 1) == P) {
+            if constexpr ((bc % SPLIT_NP) == P) {
                 CT v = maybe_round_f16<CT>(load_llr_as<CT, FMT>(A.llr, fN + bc * SZ + r0), A.llr_round16);
-                obits |= (v > CT(0) ? 1u : 0u) << (bc >> 1);
+                obits |= (v > CT(0) ? 1u : 0u) << (bc / SPLIT_NP);
                 if (A.step_mode) v = (CT)A.st_lam[fN + bc * SZ + r0];
                 lds_st<CT>(lds, p4 | (bc * V * ES), v);
             }
@@ -255,7 +261,7 @@ __device__ __forceinline__ void split_body(const FusedArgs &A, char *lds, const 
             const Where w(p4, A.batch);
             static_for<0, Plan::NBC>([&](auto bcc) {
                 constexpr int bc = decltype(bcc)::value;
-                if constexpr ((bc & 1) == P)
+                if constexpr ((bc % SPLIT_NP) == P)
                     A.trace[((size_t)w.frame * (A.max_iters + 1) + n) * N + bc * SZ + w.r0] = (double)lds_ld<CT>(lds, p4 | (bc * V * ES));
             });
         }
@@ -295,16 +301,16 @@ __device__ __forceinline__ void split_body(const FusedArgs &A, char *lds, const 
                 res = (1u << 22) | ((uint32_t)n << 23);
                 static_for<0, Plan::NBC>([&](auto bcc) {
                     constexpr int bc = decltype(bcc)::value;
-                    if constexpr ((bc & 1) == P) {
+                    if constexpr ((bc % SPLIT_NP) == P) {
                         CT v = lds_ld<CT>(lds, p4 | (bc * V * ES));
-                        res |= (v > CT(0) ? 1u : 0u) << (bc >> 1);
+                        res |= (v > CT(0) ? 1u : 0u) << (bc / SPLIT_NP);
                     }
                 });
                 if (A.final_lam) {
                     const Where w(p4, A.batch);
                     static_for<0, Plan::NBC>([&](auto bcc) {
                         constexpr int bc = decltype(bcc)::value;
-                        if constexpr ((bc & 1) == P) A.final_lam[w.fN + bc * SZ + w.r0] = (double)lds_ld<CT>(lds, p4 | (bc * V * ES));
+                        if constexpr ((bc % SPLIT_NP) == P) A.final_lam[w.fN + bc * SZ + w.r0] = (double)lds_ld<CT>(lds, p4 | (bc * V * ES));
                     });
                 }
             }
@@ -329,7 +335,7 @@ __device__ __forceinline__ void split_body(const FusedArgs &A, char *lds, const 
     if (A.step_mode) {
         static_for<0, Plan::NBC>([&](auto bcc) {
             constexpr int bc = decltype(bcc)::value;
-            if constexpr ((bc & 1) == P) A.final_lam[w.fN + bc * SZ + w.r0] = (double)lds_ld<CT>(lds, p4 | (bc * V * ES));
+            if constexpr ((bc % SPLIT_NP) == P) A.final_lam[w.fN + bc * SZ + w.r0] = (double)lds_ld<CT>(lds, p4 | (bc * V * ES));
         });
         static_for<0, Plan::NBR>([&](auto brc) {
             constexpr int br = decltype(brc)::value;
@@ -349,19 +355,19 @@ __device__ __forceinline__ void split_body(const FusedArgs &A, char *lds, const 
     if (converged) {
         static_for<0, Plan::NBC>([&](auto bcc) {
             constexpr int bc = decltype(bcc)::value;
-            if constexpr ((bc & 1) == P) A.bits[w.fN + bc * SZ + w.r0] = (res >> (bc >> 1)) & 1u;
+            if constexpr ((bc % SPLIT_NP) == P) A.bits[w.fN + bc * SZ + w.r0] = (res >> (bc / SPLIT_NP)) & 1u;
         });
     } else {
         static_for<0, Plan::NBC>([&](auto bcc) {
             constexpr int bc = decltype(bcc)::value;
-            if constexpr ((bc & 1) == P) A.bits[w.fN + bc * SZ + w.r0] = (res >> (bc >> 1)) & 1u;   // hard(channel LLR)
+            if constexpr ((bc % SPLIT_NP) == P) A.bits[w.fN + bc * SZ + w.r0] = (res >> (bc / SPLIT_NP)) & 1u;   // hard(channel LLR)
         });
         if (A.final_lam) {
             with_llr_format(A.llr_fmt, [&](auto fc) {
                 constexpr int FMT = decltype(fc)::value;
                 static_for<0, Plan::NBC>([&](auto bcc) {
                     constexpr int bc = decltype(bcc)::value;
-                    if constexpr ((bc & 1) == P) {
+                    if constexpr ((bc % SPLIT_NP) == P) {
                         const size_t gi = w.fN + bc * SZ + w.r0;
                         A.final_lam[gi] = (double)maybe_round_f16<CT>(load_llr_as<CT, FMT>(A.llr, gi), A.llr_round16);
                     }
@@ -376,7 +382,7 @@ __device__ __forceinline__ void split_body(const FusedArgs &A, char *lds, const 
 }
 
 template <int SZ> struct SplitGeom {
-    static constexpr int CPW = SZ >= 64 ? 1 : 64 / SZ, V = SZ * CPW, THREADS = 2 * V, NW = THREADS / 64;
+    static constexpr int CPW = SZ >= 64 ? 1 : 64 / SZ, V = SZ * CPW, THREADS = SPLIT_NP * V, NW = THREADS / 64;
 };
 
 template <typename CT, int VARIANT, class Plan, int SZ, class T>
@@ -387,9 +393,11 @@ void fused_split_kernel(FusedArgs A) {
     __shared__ __attribute__((aligned(16))) char lds[Plan::NBC * G::V * (int)sizeof(CT) + 4 * G::NW];
     const uint32_t tid = threadIdx.x;
     const uint32_t pair = __builtin_amdgcn_readfirstlane(tid / G::V);  // wave-uniform (V is a multiple of 64)
-    // both programs execute the same number of barriers (same loop structure and round count)
-    if (pair == 0) split_body<CT, VARIANT, Plan, SZ, T, 0>(A, lds, tid);
-    else split_body<CT, VARIANT, Plan, SZ, T, 1>(A, lds, tid);
+    // all programs execute the same number of barriers (same loop structure and round count)
+    static_for<0, SPLIT_NP>([&](auto pc) {
+        constexpr int P = decltype(pc)::value;
+        if (pair == (uint32_t)P) split_body<CT, VARIANT, Plan, SZ, T, P>(A, lds, tid);
+    });
 }
 
 bool fused_split_has(int variant, int dtype, int sz, int static_id) {

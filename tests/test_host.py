@@ -172,3 +172,40 @@ def test_native_cli_matches_python_cli(hip, capsys):
     assert len(native) == len(py) == 4
     for a, b in zip(native, py):
         assert a[1:6] == b[1:6] and a[-1] == b[-1]     # name, Eb/N0, frames, bit errors, BER ... [path]
+
+
+@pytest.mark.gpu
+def test_contexts_release_their_memory(hip):
+    """Create / use / destroy in a loop (every path, host entry points included so that the staging, latency-path and
+    zero-copy buffers get allocated): the device must end up with the memory it started with."""
+    import torch
+    c = load("jpl.1024.4.5")
+    mk = load("1920.1280.3.303")
+    _, llr = c.frames(40, 3.0, seed=1)
+    _, llr_mk = mk.frames(40, 2.0, seed=2)
+    pin = hip.PinnedArray((40, c.N), np.float32); pin.array[:] = llr
+    pout = hip.PinnedArray((40, c.N), np.uint8)
+
+    def cycle():
+        for path in ("fused", "flood"):
+            d = hip.Decoder(c.hip_code(hip), "min", "f32", 64, path=path)
+            d.decode_batch(llr.astype(np.float32), 10)
+            d.decode_batch(llr[:3].astype(np.float32), 10)                 # latency path
+            d.decode_batch(pin.array, 10, out_bits=pout.array)             # zero-copy path
+            d.decode_batch(llr, 5, want_lam=True)
+            d.close(); d.code.close()
+        d = hip.Decoder(mk.hip_code(hip), "tanh", "f32", 64)
+        d.decode_batch(llr_mk.astype(np.float32), 10)
+        d.close(); d.code.close()
+        e = hip.ECC(CODES, "ldpc/hip-minsum/jpl.1024.4.5/50/4/5", max_batch=64)
+        e.decode(llr[0][: e.codeword_length])
+        e.close()
+
+    cycle()
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info()
+    for _ in range(15):
+        cycle()
+    torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info()
+    assert free0 - free1 < 8 << 20, (free0, free1)

@@ -200,8 +200,8 @@ __global__ __launch_bounds__(kCsrThreads) void fused_csr_kernel(CsrArgs A) {
 // by the known count of padded slots), an absent column slot at a cell holding 0.
 // (row weights <= 8: 4 waves/SIMD = 128 VGPRs with a few spilled registers measured 2-4 % faster than 3 waves
 //  without; the weight-20 instance needs its 211-256 registers)
-template <typename CT, int VARIANT, int DMAX, int RPT, int CPT, int CD>
-__global__ __launch_bounds__(kCsrThreads, (DMAX <= 8 ? 4 : 1)) void fused_csr_batched_kernel(CsrArgs A) {
+template <typename CT, int VARIANT, int DMAX, int RPT, int CPT, int CD, int THREADS>
+__global__ __launch_bounds__(THREADS, (DMAX <= 8 ? (THREADS > 256 ? 6 : 4) : 1)) void fused_csr_batched_kernel(CsrArgs A) {
     static_assert(sizeof(CT) == 4 && DMAX % 2 == 0 && CD % 2 == 0, "pairs of 16-bit offsets");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -219,7 +219,7 @@ __global__ __launch_bounds__(kCsrThreads, (DMAX <= 8 ? 4 : 1)) void fused_csr_ba
     CT mreg[RPT][DMAX], oreg[CPT];
 #pragma unroll
     for (int i = 0; i < RPT; i++) {
-        const int m = tid + i * kCsrThreads;                 // a row POSITION; the row behind it:
+        const int m = tid + i * THREADS;                 // a row POSITION; the row behind it:
         const int row = (m < M) ? A.row_of_pos[m] : 0;
         const int e0 = (m < M) ? A.row_ptr[row] : 0;
         rdeg[i] = (m < M) ? A.row_ptr[row + 1] - e0 : 0;
@@ -233,7 +233,7 @@ __global__ __launch_bounds__(kCsrThreads, (DMAX <= 8 ? 4 : 1)) void fused_csr_ba
     }
 #pragma unroll
     for (int i = 0; i < CPT; i++) {
-        const int c = tid + i * kCsrThreads;
+        const int c = tid + i * THREADS;
 #pragma unroll
         for (int j = 0; j < CD; j++) {
             const int slot = (c < N && j < A.cdmax) ? A.csc_slot[j * N + c] : -1;
@@ -258,7 +258,7 @@ __global__ __launch_bounds__(kCsrThreads, (DMAX <= 8 ? 4 : 1)) void fused_csr_ba
     const int turns = A.step_mode ? 1 : A.max_iters;
     for (int n = 0;; n++) {
         if (A.trace)
-            for (int c = tid; c < N; c += kCsrThreads) A.trace[((size_t)frame * (A.max_iters + 1) + n) * N + A.col_of_pos[c]] = (double)lam[c];
+            for (int c = tid; c < N; c += THREADS) A.trace[((size_t)frame * (A.max_iters + 1) + n) * N + A.col_of_pos[c]] = (double)lam[c];
         const bool last = n >= turns;
         // ---- rows: every lam gather of the thread first, then syndrome + check-node updates out of registers
         CT l[RPT][DMAX];
@@ -279,7 +279,7 @@ __global__ __launch_bounds__(kCsrThreads, (DMAX <= 8 ? 4 : 1)) void fused_csr_ba
                 par ^= (l[i][k] > CT(0)) ? 1u : 0u;
                 t[k] = l[i][k] - mreg[i][k];             // padded slot: inf - finite = inf
             }
-            unsat |= (tid + i * kCsrThreads < M) ? (int)(par & 1u) : 0;
+            unsat |= (tid + i * THREADS < M) ? (int)(par & 1u) : 0;
             if (!last) {
                 cn_update_padded<CT, VARIANT, DMAX>(t, rdeg[i]);
 #pragma unroll
@@ -289,7 +289,7 @@ __global__ __launch_bounds__(kCsrThreads, (DMAX <= 8 ? 4 : 1)) void fused_csr_ba
         if (!last) {
 #pragma unroll
             for (int i = 0; i < RPT; i++) {
-                const int m = tid + i * kCsrThreads;
+                const int m = tid + i * THREADS;
                 if (m < M) {
 #pragma unroll
                     for (int k = 0; k < DMAX; k++) msg[k * M + m] = mreg[i][k];
@@ -315,7 +315,7 @@ __global__ __launch_bounds__(kCsrThreads, (DMAX <= 8 ? 4 : 1)) void fused_csr_ba
             }
 #pragma unroll
         for (int i = 0; i < CPT; i++) {
-            const int c = tid + i * kCsrThreads;
+            const int c = tid + i * THREADS;
             CT acc = oreg[i];
 #pragma unroll
             for (int j = 0; j < CD; j++) acc = v[i][j] + acc;   // absent slots add 0 (they follow the present ones)
@@ -326,10 +326,10 @@ __global__ __launch_bounds__(kCsrThreads, (DMAX <= 8 ? 4 : 1)) void fused_csr_ba
     }
 
     if (A.step_mode) {
-        for (int c = tid; c < N; c += kCsrThreads) A.final_lam[fN + A.col_of_pos[c]] = (double)lam[c];
+        for (int c = tid; c < N; c += THREADS) A.final_lam[fN + A.col_of_pos[c]] = (double)lam[c];
 #pragma unroll
         for (int i = 0; i < RPT; i++) {
-            const int m = tid + i * kCsrThreads;
+            const int m = tid + i * THREADS;
             if (m < M) {
                 const int e0 = A.row_ptr[A.row_of_pos[m]];
 #pragma unroll
@@ -341,7 +341,7 @@ __global__ __launch_bounds__(kCsrThreads, (DMAX <= 8 ? 4 : 1)) void fused_csr_ba
     }
 #pragma unroll
     for (int i = 0; i < CPT; i++) {
-        const int c = tid + i * kCsrThreads;
+        const int c = tid + i * THREADS;
         if (c < N) {
             const int col = A.col_of_pos[c];
             CT vv = converged ? lam[c] : oreg[i];
@@ -358,7 +358,7 @@ __global__ __launch_bounds__(kCsrThreads, (DMAX <= 8 ? 4 : 1)) void fused_csr_ba
 // ------------------------------------------------------------------ host side
 struct CsrState {
     int variant = 0, dtype = 0, M = 0, N = 0, E = 0, dmax = 0, cdmax = 0, round16 = 0;
-    bool want_batched = true, want_cache = true;   // A/B switches, read from the environment once, at creation
+    bool want_batched = true, want_cache = true, want_wide = true;   // A/B switches, read from the environment once, at creation
     int32_t *d_ell = nullptr, *d_csc = nullptr, *d_row_ptr = nullptr;
     // batched kernel: the same tables in POSITION space (conflict-aware placement of rows and columns in LDS)
     int32_t *d_ell_b = nullptr, *d_csc_b = nullptr, *d_row_of_pos = nullptr, *d_col_of_pos = nullptr;
@@ -528,6 +528,8 @@ CsrState *fused_csr_create(const ldpc_code &c, int variant, int dtype) {
         const char *bz = getenv("LDPC_CSR_BATCHED");
         s->want_batched = !(bz && !strcmp(bz, "0"));
         s->want_cache = getenv("LDPC_CSR_NOCACHE") == nullptr;
+        const char *wz = getenv("LDPC_CSR_WIDE");   // LDPC_CSR_WIDE=0: 256 threads per frame even where 512 fit
+        s->want_wide = !(wz && !strcmp(wz, "0"));
     }
     std::vector<int32_t> ell((size_t)s->dmax * c.M, -1), csc((size_t)std::max(s->cdmax, 1) * c.N, -1), slot_of_edge((size_t)c.E);
     for (int m = 0; m < c.M; m++)
@@ -600,12 +602,12 @@ static int launch_csr(CsrState &s, hipStream_t st, CsrArgs &a) {
     return LDPC_OK;
 }
 
-template <typename CT, int VARIANT, int DMAX, int RPT, int CPT, int CD>
+template <typename CT, int VARIANT, int DMAX, int RPT, int CPT, int CD, int THREADS = kCsrThreads>
 static int launch_csr_batched(CsrState &s, hipStream_t st, CsrArgs &a) {
-    auto kern = fused_csr_batched_kernel<CT, VARIANT, DMAX, RPT, CPT, CD>;
+    auto kern = fused_csr_batched_kernel<CT, VARIANT, DMAX, RPT, CPT, CD, THREADS>;
     const size_t lds = ((size_t)s.N + (size_t)DMAX * s.M + 2) * sizeof(CT);   // lam, messages, the +inf and 0 cells; <= 64 KB
     if (s.timer && !a.step_mode) s.timer->begin(st);
-    hipLaunchKernelGGL(kern, dim3(a.batch), dim3(kCsrThreads), lds, st, a);
+    hipLaunchKernelGGL(kern, dim3(a.batch), dim3(THREADS), lds, st, a);
     if (s.timer && !a.step_mode) s.timer->end(st);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return set_error(LDPC_EHIP, "fused_csr (batched) launch: %s", hipGetErrorString(e));
@@ -619,7 +621,13 @@ static int dispatch_dmax(CsrState &s, hipStream_t st, CsrArgs &a) {
         const int shape = (s.d_ell_b && s.want_batched) ? batched_shape(s) : 0;
         if (shape) {
             a.ell_col = s.d_ell_b; a.csc_slot = s.d_csc_b; a.row_of_pos = s.d_row_of_pos; a.col_of_pos = s.d_col_of_pos;
-            if (shape == 1) return launch_csr_batched<CT, VARIANT, 4, 6, 8, 4>(s, st, a);
+            if (shape == 1) {
+                // 512 threads per frame when the share then is <= 3 rows / 4 columns per thread: 75-80 VGPRs, 6 waves per
+                // SIMD.  Measured on 1920.1280.3.303 against the 256-thread instance: tanh 4.14 -> 4.22 Gbit/s at 1 dB,
+                // 12.8 -> 13.6 at 3 dB; min-sum 4.95 -> 5.42 and 17.1 -> 20.7 (1024 threads: slower than either)
+                if (s.want_wide && (s.M + 511) / 512 <= 3 && (s.N + 511) / 512 <= 4) return launch_csr_batched<CT, VARIANT, 4, 3, 4, 4, 512>(s, st, a);
+                return launch_csr_batched<CT, VARIANT, 4, 6, 8, 4>(s, st, a);
+            }
             if (shape == 2) return launch_csr_batched<CT, VARIANT, 8, 2, 4, 8>(s, st, a);
             return launch_csr_batched<CT, VARIANT, 20, 2, 6, 8>(s, st, a);
         }

@@ -136,3 +136,18 @@ def test_placement_changes_nothing_but_speed(hip, monkeypatch):
         outs.append((d.decode_batch(llr, 50, want_lam=True), d.decode_trace(llr[:6], 50), d.debug_step(orig, lam, ne)))
     for x, y in zip(outs[0], outs[1]):
         assert all(np.array_equal(p, q) for p, q in zip(x, y))
+
+
+def test_wide_workgroups_change_nothing_but_speed(hip, monkeypatch):
+    """1920.1280.3.303 runs the batched kernel with 512 threads per frame (3 rows / 4 columns per thread);
+    LDPC_CSR_WIDE=0 keeps 256 threads.  Same arithmetic, same order: identical outputs."""
+    c = load("1920.1280.3.303")
+    llr = _frames(c, 20, (1.0, 2.0), 2300).astype(np.float32)
+    code = _code(hip, c)
+    outs = []
+    for wide in ("1", "0"):
+        monkeypatch.setenv("LDPC_CSR_WIDE", wide)
+        for variant in ("min", "tanh"):
+            outs.append(hip.Decoder(code, variant, "f32", len(llr), path="fused").decode_batch(llr.astype(np.float64), 50, want_lam=True))
+    for x, y in ((outs[0], outs[2]), (outs[1], outs[3])):
+        assert all(np.array_equal(p, q) for p, q in zip(x, y))

@@ -39,15 +39,22 @@ __device__ __forceinline__ void cn_row_regs(const FloodDev &d, ST *__restrict__ 
     using CT = typename Store<ST>::CT;
     CT t[DEG];
     unsigned par = 0;
+    // column indices first (wave-uniform scalar loads, issued together), then every lam / message load, then the
+    // arithmetic: written as one loop the row paid one scalar-load round trip per edge before its vector loads
+    int col[DEG];
+#pragma unroll
+    for (int k = 0; k < DEG; k++) col[k] = d.col_idx[ebeg + k];
+    CT l[DEG];
+#pragma unroll
+    for (int k = 0; k < DEG; k++) l[k] = Store<ST>::ld(lam + (size_t)col[k] * d.Bp + b);
+    if (!syndrome_only) {
+#pragma unroll
+        for (int k = 0; k < DEG; k++) t[k] = Store<ST>::ld(msg + (size_t)(ebeg + k) * d.Bp + b);
+    }
 #pragma unroll
     for (int k = 0; k < DEG; k++) {
-        int col = d.col_idx[ebeg + k]; // wave-uniform
-        CT l = Store<ST>::ld(lam + (size_t)col * d.Bp + b);
-        par ^= hard(l) ? 1u : 0u;
-        if (!syndrome_only) {
-            CT m = Store<ST>::ld(msg + (size_t)(ebeg + k) * d.Bp + b);
-            t[k] = l - m;
-        }
+        par ^= hard(l[k]) ? 1u : 0u;
+        if (!syndrome_only) t[k] = l[k] - t[k];
     }
     if (par) d.unsat[b] = stamp; // benign race: every writer stores the same value
     if (syndrome_only) return;
@@ -168,6 +175,24 @@ __global__ __launch_bounds__(kWave *kCnWaves) void flood_cn_kernel(FloodDev d, S
 }
 
 // ------------------------------------------------------------------ VN update
+// One column of weight DEG for 64 codewords: edge indices (scalar), then all DEG message loads, then the sum in
+// the reference's order (Orig.hs:96: foldr => last row first).  A function per weight keeps the loads free of
+// per-edge branches, so they are all in flight together.
+template <typename ST, int DEG>
+__device__ __forceinline__ typename Store<ST>::CT vn_sum(const FloodDev &d, const ST *__restrict__ msg, int qe, size_t b,
+                                                         typename Store<ST>::CT acc) {
+    using CT = typename Store<ST>::CT;
+    int e[DEG];
+    CT v[DEG];
+#pragma unroll
+    for (int j = 0; j < DEG; j++) e[j] = d.csc_edge[qe - 1 - j];
+#pragma unroll
+    for (int j = 0; j < DEG; j++) v[j] = Store<ST>::ld(msg + (size_t)e[j] * d.Bp + b);
+#pragma unroll
+    for (int j = 0; j < DEG; j++) acc = v[j] + acc;
+    return acc;
+}
+
 // grid: (Bp/64) x ceil(N/4) blocks of 4 waves; wave = (column, 64 codewords).
 template <typename ST>
 __global__ __launch_bounds__(256) void flood_vn_kernel(FloodDev d, const ST *__restrict__ msg,
@@ -188,12 +213,30 @@ __global__ __launch_bounds__(256) void flood_vn_kernel(FloodDev d, const ST *__r
     }
     CT acc = Store<ST>::ld(orig + (size_t)col * d.Bp + b);
     const int qb = d.col_ptr[col], qe = d.col_ptr[col + 1];
-    // Orig.hs:96: foldr => last row first.  Columns of weight <= 8: every edge index (scalar loads), then every
-    // message load, are issued before the first sum -- with a dynamic loop the wave pays one memory round trip per
-    // edge (measured on jpl.4096, 16 384 frames: 699 -> 596 us per launch).
-    constexpr int U = 8;
-    if (qe - qb <= U) {
-        const int deg = qe - qb;   // wave-uniform
+    const int deg = qe - qb;   // wave-uniform
+    // Two ways of getting a column's message loads in flight together (a plain loop pays one memory round trip per
+    // edge): a function per weight, or predicated loads after clustered index loads.  Measured on one box, jpl.4096,
+    // 16 384 frames, whole flood path: f32 1 050 (predicated) vs 990 Mbit/s (per weight), fp16 storage 1 110 vs
+    // 1 250 -- so the choice follows the storage type.
+    if (deg > 8) {
+        for (int q = qe - 1; q >= qb; q--) {   // Orig.hs:96: foldr => last row first
+            int e = d.csc_edge[q];
+            acc = Store<ST>::ld(msg + (size_t)e * d.Bp + b) + acc;
+        }
+    } else if constexpr (sizeof(ST) == 2) {
+        switch (deg) {
+            case 1: acc = vn_sum<ST, 1>(d, msg, qe, b, acc); break;
+            case 2: acc = vn_sum<ST, 2>(d, msg, qe, b, acc); break;
+            case 3: acc = vn_sum<ST, 3>(d, msg, qe, b, acc); break;
+            case 4: acc = vn_sum<ST, 4>(d, msg, qe, b, acc); break;
+            case 5: acc = vn_sum<ST, 5>(d, msg, qe, b, acc); break;
+            case 6: acc = vn_sum<ST, 6>(d, msg, qe, b, acc); break;
+            case 7: acc = vn_sum<ST, 7>(d, msg, qe, b, acc); break;
+            case 8: acc = vn_sum<ST, 8>(d, msg, qe, b, acc); break;
+            default: break;
+        }
+    } else {
+        constexpr int U = 8;
         int e[U];
         CT v[U];
 #pragma unroll
@@ -203,11 +246,6 @@ __global__ __launch_bounds__(256) void flood_vn_kernel(FloodDev d, const ST *__r
 #pragma unroll
         for (int j = 0; j < U; j++)
             if (j < deg) acc = v[j] + acc;
-    } else {
-        for (int q = qe - 1; q >= qb; q--) {
-            int e = d.csc_edge[q];
-            acc = Store<ST>::ld(msg + (size_t)e * d.Bp + b) + acc;
-        }
     }
     Store<ST>::st(lam + (size_t)col * d.Bp + b, acc);
 }

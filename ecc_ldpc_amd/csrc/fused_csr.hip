@@ -90,20 +90,26 @@ __global__ __launch_bounds__(kCsrThreads) void fused_csr_kernel(CsrArgs A) {
         }
     }
 
-    // one row: parity of hard(lam) over its columns (syndrome bit) and, unless `last`, the message update
+    // one row: parity of hard(lam) over its columns (syndrome bit) and, unless `last`, the message update.  All
+    // column indices first, then all lam and message reads, then the arithmetic: as one loop per edge the row paid
+    // a global-memory round trip (index) plus an LDS round trip per edge.
     auto do_row = [&](int m, int deg, auto colof, bool last) -> int {
-        CT t[DMAX];
+        int col[DMAX];
+#pragma unroll
+        for (int k = 0; k < DMAX; k++) col[k] = colof(k);
+        CT l[DMAX], t[DMAX];
+#pragma unroll
+        for (int k = 0; k < DMAX; k++) l[k] = lam[col[k] < 0 ? 0 : col[k]];
+        if (!last) {
+#pragma unroll
+            for (int k = 0; k < DMAX; k++) t[k] = msg[k * M + m];
+        }
         bool par = false;
 #pragma unroll
         for (int k = 0; k < DMAX; k++) {
-            const int col = colof(k);
-            if (col >= 0) {
-                CT l = lam[col];
-                par ^= (l > CT(0));
-                t[k] = last ? CT(0) : l - msg[k * M + m];
-            } else {
-                t[k] = CT(INFINITY);
-            }
+            const bool on = col[k] >= 0;
+            par ^= on && (l[k] > CT(0));
+            t[k] = on ? (last ? CT(0) : l[k] - t[k]) : CT(INFINITY);
         }
         if (!last) {
             cn_update_padded<CT, VARIANT, DMAX>(t, deg);
@@ -157,9 +163,21 @@ __global__ __launch_bounds__(kCsrThreads) void fused_csr_kernel(CsrArgs A) {
         } else {
             for (int c = tid; c < N; c += kCsrThreads) {
                 CT acc = orig[c];
-                for (int j = 0; j < A.cdmax; j++) {
-                    const int slot = A.csc_slot[j * N + c];
-                    if (slot >= 0) acc = msg[slot] + acc;
+                if (A.cdmax <= kCdMax) {   // slots first, then the message reads, then the sum (descending rows)
+                    int slot[kCdMax];
+                    CT v[kCdMax];
+#pragma unroll
+                    for (int j = 0; j < kCdMax; j++) slot[j] = (j < A.cdmax) ? A.csc_slot[j * N + c] : -1;
+#pragma unroll
+                    for (int j = 0; j < kCdMax; j++) v[j] = msg[slot[j] < 0 ? 0 : slot[j]];
+#pragma unroll
+                    for (int j = 0; j < kCdMax; j++)
+                        if (slot[j] >= 0) acc = v[j] + acc;
+                } else {
+                    for (int j = 0; j < A.cdmax; j++) {
+                        const int slot = A.csc_slot[j * N + c];
+                        if (slot >= 0) acc = msg[slot] + acc;
+                    }
                 }
                 lam[c] = acc;
             }

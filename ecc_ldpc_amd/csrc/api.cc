@@ -328,6 +328,7 @@ ldpc_ctx *ldpc_ctx_create_ex(const ldpc_code *code_c, int variant, int dtype, in
     d.M = code->M; d.N = code->N; d.E = code->E; d.Bp = ctx->Bp;
     d.row_ptr = code->d_row_ptr; d.col_idx = code->d_col_idx; d.col_ptr = code->d_col_ptr; d.csc_edge = code->d_csc_edge;
     d.unsat = nullptr; d.iters = nullptr; d.conv = nullptr; d.done = nullptr;
+    d.wide_rows = 0;
     ctx->flood.variant = variant; ctx->flood.dtype = dtype; ctx->flood.timer = &ctx->timer;
     // (the staging buffers of the host-pointer entry points are allocated on first use: a context driven
     //  through ldpc_decode_batch_dev with 65 536 frames would otherwise park 3 GB of HBM)
@@ -335,9 +336,13 @@ ldpc_ctx *ldpc_ctx_create_ex(const ldpc_code *code_c, int variant, int dtype, in
         CTX_HIP(hipMalloc(&ctx->flood.msg, std::max<size_t>((size_t)code->E, 1) * Bp * es));
         // scratch is only touched by rows whose degree has no register kernel
         bool need_scratch = false;
+        const char *wz = getenv("LDPC_FLOOD_WIDE");   // LDPC_FLOOD_WIDE=0: rows of weight 9..32 through the O(d^2) fallback (A/B)
+        const bool paddable = !(variant == LDPC_TANH && dtype == LDPC_F64) && !(wz && !strcmp(wz, "0"));
         for (int m = 0; m < code->M; m++) {
             int dg = code->row_ptr[m + 1] - code->row_ptr[m];
-            if (!(dg <= 8 || dg == 18)) need_scratch = true;
+            if (dg <= 8 || dg == 18) continue;
+            if (paddable && dg <= 32) { ctx->flood.has_wide_rows = true; d.wide_rows = 1; }   // padded register rows (second CN instance)
+            else need_scratch = true;                                    // O(d^2) fallback writes through scratch
         }
         if (need_scratch) CTX_HIP(hipMalloc(&ctx->flood.scratch, std::max<size_t>((size_t)code->E, 1) * Bp * es));
         CTX_HIP(hipMalloc(&ctx->flood.lam, (size_t)code->N * Bp * es));

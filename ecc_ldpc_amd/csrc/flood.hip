@@ -63,7 +63,38 @@ __device__ __forceinline__ void cn_row_regs(const FloodDev &d, ST *__restrict__ 
     for (int k = 0; k < DEG; k++) Store<ST>::st(msg + (size_t)(ebeg + k) * d.Bp + b, t[k]);
 }
 
-// any degree: O(deg^2) re-reads (served by L1/L2); correctness path for unusual row weights.
+// row weights 9..32 without an exact-degree instance: the row in DMAX registers, slots k >= deg padded with
+// t = +inf (neutral for both rules; cn_update_padded is bit-identical to the exact-degree code, ldpc_math.h).
+// Loads and stores of the padding slots are skipped by wave-uniform branches.
+template <typename ST, int VARIANT, int DMAX>
+__device__ __forceinline__ void cn_row_padded(const FloodDev &d, ST *__restrict__ msg, const ST *__restrict__ lam,
+                                              int ebeg, int deg, size_t b, int stamp, bool syndrome_only) {
+    using CT = typename Store<ST>::CT;
+    int col[DMAX];
+#pragma unroll
+    for (int k = 0; k < DMAX; k++) col[k] = (k < deg) ? d.col_idx[ebeg + k] : 0;
+    CT l[DMAX], t[DMAX];
+#pragma unroll
+    for (int k = 0; k < DMAX; k++) l[k] = (k < deg) ? Store<ST>::ld(lam + (size_t)col[k] * d.Bp + b) : CT(0);
+    if (!syndrome_only) {
+#pragma unroll
+        for (int k = 0; k < DMAX; k++) t[k] = (k < deg) ? Store<ST>::ld(msg + (size_t)(ebeg + k) * d.Bp + b) : CT(0);
+    }
+    unsigned par = 0;
+#pragma unroll
+    for (int k = 0; k < DMAX; k++) {
+        par ^= (k < deg && hard(l[k])) ? 1u : 0u;
+        if (!syndrome_only) t[k] = (k < deg) ? l[k] - t[k] : CT(INFINITY);
+    }
+    if (par) d.unsat[b] = stamp; // benign race: every writer stores the same value
+    if (syndrome_only) return;
+    cn_update_padded<CT, VARIANT, DMAX>(t, deg);
+#pragma unroll
+    for (int k = 0; k < DMAX; k++)
+        if (k < deg) Store<ST>::st(msg + (size_t)(ebeg + k) * d.Bp + b, t[k]);
+}
+
+// any degree (here: above 32): O(deg^2) re-reads (served by L1/L2); correctness path for unusual row weights.
 template <typename ST, int VARIANT>
 __device__ void cn_row_generic(const FloodDev &d, ST *__restrict__ msg, ST *__restrict__ scratch,
                                const ST *__restrict__ lam, int ebeg, int deg, size_t b, int stamp,
@@ -124,7 +155,11 @@ __device__ void cn_row_generic(const FloodDev &d, ST *__restrict__ msg, ST *__re
 // grid: 1-D, (Bp/64) slabs x ceil(M/kCnWaves) row groups, remapped so that all row groups of one
 // codeword slab run back to back on ONE XCD (blocks are dealt round-robin over the 8 XCDs, so
 // block ids congruent mod 8 share an L2): lam[col] of the slab is then re-read from that L2.
-template <typename ST, int VARIANT>
+// WIDE = false: the kernel every code runs (exact-degree rows 1..8 and 18, O(d^2) fallback above 32); rows of weight
+// 9..32 are left to the WIDE = true instance, launched right after it only for codes that have such rows -- kept
+// apart because their 12..32-register rows would otherwise set the register count (56 -> 78..107 VGPRs, 8 -> 4..6
+// waves/SIMD) of a kernel that lives on occupancy.
+template <typename ST, int VARIANT, bool WIDE>
 __global__ __launch_bounds__(kWave *kCnWaves) void flood_cn_kernel(FloodDev d, ST *msg, ST *scratch,
                                                                    const ST *lam, int stamp,
                                                                    int syndrome_only, int force) {
@@ -156,21 +191,32 @@ __global__ __launch_bounds__(kWave *kCnWaves) void flood_cn_kernel(FloodDev d, S
     const int ebeg = d.row_ptr[row];
     const int deg = d.row_ptr[row + 1] - ebeg;
     const bool so = syndrome_only != 0;
-    switch (deg) {
-        case 0: break;
-        case 1:
-            if constexpr (VARIANT == LDPC_V_TANH) cn_row_regs<ST, VARIANT, 1>(d, msg, lam, ebeg, b, stamp, so);
-            else cn_row_generic<ST, VARIANT>(d, msg, scratch, lam, ebeg, deg, b, stamp, true); // rejected at ctx_create
-            break;
-        case 2: cn_row_regs<ST, VARIANT, 2>(d, msg, lam, ebeg, b, stamp, so); break;
-        case 3: cn_row_regs<ST, VARIANT, 3>(d, msg, lam, ebeg, b, stamp, so); break;
-        case 4: cn_row_regs<ST, VARIANT, 4>(d, msg, lam, ebeg, b, stamp, so); break;
-        case 5: cn_row_regs<ST, VARIANT, 5>(d, msg, lam, ebeg, b, stamp, so); break;
-        case 6: cn_row_regs<ST, VARIANT, 6>(d, msg, lam, ebeg, b, stamp, so); break;
-        case 7: cn_row_regs<ST, VARIANT, 7>(d, msg, lam, ebeg, b, stamp, so); break;
-        case 8: cn_row_regs<ST, VARIANT, 8>(d, msg, lam, ebeg, b, stamp, so); break;
-        case 18: cn_row_regs<ST, VARIANT, 18>(d, msg, lam, ebeg, b, stamp, so); break;
-        default: cn_row_generic<ST, VARIANT>(d, msg, scratch, lam, ebeg, deg, b, stamp, so); break;
+    constexpr bool kPaddable = !(VARIANT == LDPC_V_TANH && sizeof(typename Store<ST>::CT) == 8);  // f64 tanh: O(d^2) anyway
+    const bool wide_row = kPaddable && d.wide_rows && deg > 8 && deg <= 32 && deg != 18;
+    if constexpr (WIDE) {
+        if (!wide_row) return;
+        if (deg <= 12) cn_row_padded<ST, VARIANT, 12>(d, msg, lam, ebeg, deg, b, stamp, so);
+        else if (deg <= 16) cn_row_padded<ST, VARIANT, 16>(d, msg, lam, ebeg, deg, b, stamp, so);
+        else if (deg <= 24) cn_row_padded<ST, VARIANT, 24>(d, msg, lam, ebeg, deg, b, stamp, so);
+        else cn_row_padded<ST, VARIANT, 32>(d, msg, lam, ebeg, deg, b, stamp, so);
+    } else {
+        if (wide_row) return;
+        switch (deg) {
+            case 0: break;
+            case 1:
+                if constexpr (VARIANT == LDPC_V_TANH) cn_row_regs<ST, VARIANT, 1>(d, msg, lam, ebeg, b, stamp, so);
+                else cn_row_generic<ST, VARIANT>(d, msg, scratch, lam, ebeg, deg, b, stamp, true); // rejected at ctx_create
+                break;
+            case 2: cn_row_regs<ST, VARIANT, 2>(d, msg, lam, ebeg, b, stamp, so); break;
+            case 3: cn_row_regs<ST, VARIANT, 3>(d, msg, lam, ebeg, b, stamp, so); break;
+            case 4: cn_row_regs<ST, VARIANT, 4>(d, msg, lam, ebeg, b, stamp, so); break;
+            case 5: cn_row_regs<ST, VARIANT, 5>(d, msg, lam, ebeg, b, stamp, so); break;
+            case 6: cn_row_regs<ST, VARIANT, 6>(d, msg, lam, ebeg, b, stamp, so); break;
+            case 7: cn_row_regs<ST, VARIANT, 7>(d, msg, lam, ebeg, b, stamp, so); break;
+            case 8: cn_row_regs<ST, VARIANT, 8>(d, msg, lam, ebeg, b, stamp, so); break;
+            case 18: cn_row_regs<ST, VARIANT, 18>(d, msg, lam, ebeg, b, stamp, so); break;
+            default: cn_row_generic<ST, VARIANT>(d, msg, scratch, lam, ebeg, deg, b, stamp, so); break;
+        }
     }
 }
 
@@ -385,12 +431,14 @@ static void enqueue_turns(FloodState &s, hipStream_t st, int max_iters, int batc
     for (int n = 0; n < max_iters; n++) {
         if (d_trace) hipLaunchKernelGGL((trace_store_kernel<ST>), tr_grid, dim3(256), 0, st, d, lam, d_trace, n, max_iters + 1, batch);
         if (s.timer) s.timer->begin(st);
-        hipLaunchKernelGGL((flood_cn_kernel<ST, VARIANT>), cn_grid, cn_block, 0, st, d, msg, scr, lam, n + 1, 0, 0);
+        hipLaunchKernelGGL((flood_cn_kernel<ST, VARIANT, false>), cn_grid, cn_block, 0, st, d, msg, scr, lam, n + 1, 0, 0);
         if (s.timer) s.timer->end(st);
+        if (s.has_wide_rows) hipLaunchKernelGGL((flood_cn_kernel<ST, VARIANT, true>), cn_grid, cn_block, 0, st, d, msg, scr, lam, n + 1, 0, 0);
         hipLaunchKernelGGL((flood_vn_kernel<ST>), vn_grid, vn_block, 0, st, d, msg, orig, lam, n, 0);
     }
     if (d_trace) hipLaunchKernelGGL((trace_store_kernel<ST>), tr_grid, dim3(256), 0, st, d, lam, d_trace, max_iters, max_iters + 1, batch);
-    hipLaunchKernelGGL((flood_cn_kernel<ST, VARIANT>), cn_grid, cn_block, 0, st, d, msg, scr, lam, max_iters + 1, 1, 0);
+    hipLaunchKernelGGL((flood_cn_kernel<ST, VARIANT, false>), cn_grid, cn_block, 0, st, d, msg, scr, lam, max_iters + 1, 1, 0);
+    if (s.has_wide_rows) hipLaunchKernelGGL((flood_cn_kernel<ST, VARIANT, true>), cn_grid, cn_block, 0, st, d, msg, scr, lam, max_iters + 1, 1, 0);
     hipLaunchKernelGGL(flood_finalize_kernel, dim3((d.Bp + 255) / 256), dim3(256), 0, st, d, max_iters);
 }
 
@@ -468,7 +516,8 @@ static int step_impl(FloodState &s, hipStream_t st, int batch, const double *d_o
     hipLaunchKernelGGL((upload_rows_kernel<ST>), blocks((size_t)d.E * d.Bp), dim3(256), 0, st, d_ne, msg, batch, d.E, d.Bp);
     const int slabs = d.Bp / kWave;
     const int row_groups = (d.M + kCnWaves - 1) / kCnWaves;
-    hipLaunchKernelGGL((flood_cn_kernel<ST, VARIANT>), dim3(slabs * row_groups), dim3(kWave * kCnWaves), 0, st, d, msg, scr, lam, 1, 0, 1);
+    hipLaunchKernelGGL((flood_cn_kernel<ST, VARIANT, false>), dim3(slabs * row_groups), dim3(kWave * kCnWaves), 0, st, d, msg, scr, lam, 1, 0, 1);
+    if (s.has_wide_rows) hipLaunchKernelGGL((flood_cn_kernel<ST, VARIANT, true>), dim3(slabs * row_groups), dim3(kWave * kCnWaves), 0, st, d, msg, scr, lam, 1, 0, 1);
     hipLaunchKernelGGL((flood_vn_kernel<ST>), dim3(slabs, (d.N + 3) / 4), dim3(256), 0, st, d, msg, orig, lam, 0, 1);
     hipLaunchKernelGGL((download_rows_kernel<ST>), blocks((size_t)d.E * d.Bp), dim3(256), 0, st, msg, d_ne_out, batch, d.E, d.Bp);
     hipLaunchKernelGGL((download_rows_kernel<ST>), blocks((size_t)d.N * d.Bp), dim3(256), 0, st, lam, d_lam_out, batch, d.N, d.Bp);

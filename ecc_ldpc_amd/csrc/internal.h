@@ -17,6 +17,7 @@ int set_error(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3
 // device view of the graph + per-frame bookkeeping of the flood path (passed by value to kernels)
 struct FloodDev {
     int M, N, E, Bp;
+    int wide_rows;           // rows of weight 9..32 go to the padded-register CN instance (0: O(d^2) fallback, A/B)
     const int32_t *row_ptr;  // [M+1]
     const int32_t *col_idx;  // [E]   CSR, ascending column inside a row
     const int32_t *col_ptr;  // [N+1]
@@ -66,6 +67,7 @@ struct FloodState {
     FloodDev dev;
     int variant, dtype;
     KernelTimer *timer = nullptr;
+    bool has_wide_rows = false;   // some check row has weight 9..32 (not 18): second CN kernel instance, flood.hip
     void *msg = nullptr, *scratch = nullptr, *lam = nullptr, *orig = nullptr;
     // The turn loop (2 launches per turn, no host decision inside: finished frames are frozen on the device)
     // touches only this context's buffers, so it is captured once per max_iters into a hipGraph and

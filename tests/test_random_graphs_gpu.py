@@ -88,3 +88,24 @@ def test_tanh_f64_with_degree_one_rows(hip):
     with pytest.raises(hip.LdpcError) as e:
         hip.Decoder(code, "min", "f32", 4)
     assert e.value.code == -6
+
+
+@pytest.mark.parametrize("label,M,N,degs,iters", CASES[1:3])
+def test_flood_padded_rows_equal_the_fallback(hip, monkeypatch, label, M, N, degs, iters):
+    """Rows of weight 9..32 run in a second CN kernel instance with the row padded into registers
+    (LDPC_FLOOD_WIDE=0: the O(d^2) re-read fallback).  min-sum is exact arithmetic: identical outputs, f32 and f64;
+    the tanh rule differs only in summation order: identical bits on these frames."""
+    import zlib
+    rng = np.random.default_rng(zlib.crc32(("wide" + label).encode()))
+    H = random_h(rng, M, N, degs)
+    g = oracle.Graph.from_dense(H)
+    x = llrs(rng, 48, N, 2.5)
+    out = {}
+    for wide in ("1", "0"):
+        monkeypatch.setenv("LDPC_FLOOD_WIDE", wide)
+        code = hip.Code.from_csr(g.row_ptr, g.col_idx, N)
+        for variant, dtype in (("min", "f32"), ("min", "f64"), ("tanh", "f32")):
+            out[(wide, variant, dtype)] = hip.Decoder(code, variant, dtype, len(x), path="flood").decode_batch(x, iters, want_lam=True)
+    for variant, dtype in (("min", "f32"), ("min", "f64")):
+        assert all(np.array_equal(a, b) for a, b in zip(out[("1", variant, dtype)], out[("0", variant, dtype)]))
+    assert np.array_equal(out[("1", "tanh", "f32")][0], out[("0", "tanh", "f32")][0])

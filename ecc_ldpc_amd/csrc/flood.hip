@@ -239,6 +239,23 @@ __device__ __forceinline__ typename Store<ST>::CT vn_sum(const FloodDev &d, cons
     return acc;
 }
 
+// the same for any weight <= U: clustered index loads, then message loads predicated on the (wave-uniform) weight
+template <typename ST, int U>
+__device__ __forceinline__ typename Store<ST>::CT vn_sum_pred(const FloodDev &d, const ST *__restrict__ msg, int qe, int deg,
+                                                              size_t b, typename Store<ST>::CT acc) {
+    using CT = typename Store<ST>::CT;
+    int e[U];
+    CT v[U];
+#pragma unroll
+    for (int j = 0; j < U; j++) e[j] = (j < deg) ? d.csc_edge[qe - 1 - j] : 0;
+#pragma unroll
+    for (int j = 0; j < U; j++) v[j] = (j < deg) ? Store<ST>::ld(msg + (size_t)e[j] * d.Bp + b) : CT(0);
+#pragma unroll
+    for (int j = 0; j < U; j++)
+        if (j < deg) acc = v[j] + acc;
+    return acc;
+}
+
 // grid: (Bp/64) x ceil(N/4) blocks of 4 waves; wave = (column, 64 codewords).
 template <typename ST>
 __global__ __launch_bounds__(256) void flood_vn_kernel(FloodDev d, const ST *__restrict__ msg,
@@ -264,11 +281,13 @@ __global__ __launch_bounds__(256) void flood_vn_kernel(FloodDev d, const ST *__r
     // edge): a function per weight, or predicated loads after clustered index loads.  Measured on one box, jpl.4096,
     // 16 384 frames, whole flood path: f32 1 050 (predicated) vs 990 Mbit/s (per weight), fp16 storage 1 110 vs
     // 1 250 -- so the choice follows the storage type.
-    if (deg > 8) {
+    if (deg > 16) {
         for (int q = qe - 1; q >= qb; q--) {   // Orig.hs:96: foldr => last row first
             int e = d.csc_edge[q];
             acc = Store<ST>::ld(msg + (size_t)e * d.Bp + b) + acc;
         }
+    } else if (deg > 8) {
+        acc = vn_sum_pred<ST, 16>(d, msg, qe, deg, b, acc);
     } else if constexpr (sizeof(ST) == 2) {
         switch (deg) {
             case 1: acc = vn_sum<ST, 1>(d, msg, qe, b, acc); break;
@@ -282,16 +301,7 @@ __global__ __launch_bounds__(256) void flood_vn_kernel(FloodDev d, const ST *__r
             default: break;
         }
     } else {
-        constexpr int U = 8;
-        int e[U];
-        CT v[U];
-#pragma unroll
-        for (int j = 0; j < U; j++) e[j] = (j < deg) ? d.csc_edge[qe - 1 - j] : 0;
-#pragma unroll
-        for (int j = 0; j < U; j++) v[j] = (j < deg) ? Store<ST>::ld(msg + (size_t)e[j] * d.Bp + b) : CT(0);
-#pragma unroll
-        for (int j = 0; j < U; j++)
-            if (j < deg) acc = v[j] + acc;
+        acc = vn_sum_pred<ST, 8>(d, msg, qe, deg, b, acc);
     }
     Store<ST>::st(lam + (size_t)col * d.Bp + b, acc);
 }

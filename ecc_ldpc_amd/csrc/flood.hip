@@ -186,10 +186,11 @@ __global__ __launch_bounds__(kWave *kCnWaves) void flood_cn_kernel(FloodDev d, S
     const int row = rg * kCnWaves + wave;
     if (row >= d.M) return;
     const size_t b = (size_t)slab * kWave + lane;
-    const bool active = force ? true : (d.done[b] == 0);
-    if (!active) return; // lanes of finished (or padding) frames drop out; an all-done wave exits
+    // (row extent requested before the frame flag is looked at: two independent round trips instead of a chain)
     const int ebeg = d.row_ptr[row];
     const int deg = d.row_ptr[row + 1] - ebeg;
+    const bool active = force ? true : (d.done[b] == 0);
+    if (!active) return; // lanes of finished (or padding) frames drop out; an all-done wave exits
     const bool so = syndrome_only != 0;
     constexpr bool kPaddable = !(VARIANT == LDPC_V_TANH && sizeof(typename Store<ST>::CT) == 8);  // f64 tanh: O(d^2) anyway
     const bool wide_row = kPaddable && d.wide_rows && deg > 8 && deg <= 32 && deg != 18;

@@ -133,9 +133,12 @@ int ldpc_decode_batch_f16(ldpc_ctx *ctx, int max_iters, int batch, const uint16_
                           int32_t *iters, uint8_t *converged);
 int ldpc_decode_batch_dev_f16(ldpc_ctx *ctx, int max_iters, int batch, const uint16_t *d_llr,
                               uint8_t *d_bits, int32_t *d_iters, uint8_t *d_converged, void *stream);
-/* page-locked host memory for the host-pointer entry points: with buffers from ldpc_host_alloc the chunked
- * H2D / decode / D2H pipeline inside ldpc_decode_batch runs at PCIe speed instead of the pageable-copy
- * rate (the reference pokes pageable Storable vectors, GPU/CUDA/Arraylet2.hs:158-159).  NULL on failure. */
+/* page-locked host memory for the host-pointer entry points.  With llr AND bits buffers from ldpc_host_alloc (or
+ * registered with hipHostRegister) ldpc_decode_batch runs zero-copy: the decode kernel itself reads the LLRs and
+ * writes the bits over PCIe (10-11 Gbit/s PCIe-inclusive on jpl.4096); pageable buffers go through a chunked
+ * H2D / decode / D2H pipeline at the pageable-copy rate (2-3.5 Gbit/s); up to 16 frames (ldpc_decode_one) take a
+ * latency path through internal page-locked bounce buffers.  (The reference pokes pageable Storable vectors,
+ * GPU/CUDA/Arraylet2.hs:158-159.)  NULL on failure. */
 void *ldpc_host_alloc(size_t bytes);
 void ldpc_host_free(void *p);
 /* wait for everything enqueued on the context's stream */

@@ -2,9 +2,11 @@
 no Python or CPU fallback: if the shared object is missing or a call fails this module raises."""
 from __future__ import annotations
 
+import atexit
 import ctypes as C
 import os
 import sys
+import weakref
 
 import numpy as np
 
@@ -18,7 +20,7 @@ PATH_AUTO, PATH_FLOOD, PATH_FUSED = 0, 1, 2
 
 # every symbol include/ldpc_hip.h declares (tests/test_abi.py checks the library exports them all)
 ABI_SYMBOLS = [
-    "ldpc_init", "ldpc_shutdown", "ldpc_last_error", "ldpc_last_error_code", "ldpc_abi_version", "ldpc_device_count",
+    "ldpc_init", "ldpc_shutdown", "ldpc_current_device", "ldpc_ctx_create_on", "ldpc_sim_create_on", "ldpc_last_error", "ldpc_last_error_code", "ldpc_abi_version", "ldpc_device_count",
     "ldpc_code_create_qc", "ldpc_code_create_csr", "ldpc_code_destroy", "ldpc_code_dims", "ldpc_code_csr",
     "ldpc_ctx_create", "ldpc_ctx_create_ex", "ldpc_ctx_destroy", "ldpc_ctx_path", "ldpc_ctx_synchronize",
     "ldpc_decode_one", "ldpc_decode_batch", "ldpc_decode_batch_f64", "ldpc_decode_batch_dev",
@@ -42,6 +44,46 @@ class LdpcError(RuntimeError):
 
 
 _lib = None
+
+# ---- deterministic teardown.  Every object that owns a native handle registers here; close_all() -- run by atexit,
+# i.e. at the START of interpreter finalisation, while the HIP runtime and every module are still intact -- releases
+# them in dependency order (records, replicas, frame sources, graphs, page-locked buffers).  After that, and whenever
+# the interpreter is finalising, __del__ does nothing: no hipFree / hipStreamDestroy ever runs from a finaliser during
+# shutdown, when the order against the HIP runtime's own exit handlers is not defined.
+_live = weakref.WeakSet()
+_CLOSE_ORDER = {"ECC": 0, "Batcher": 1, "Decoder": 2, "Sim": 3, "Code": 4, "Matrix": 5, "PinnedArray": 6}
+_closed_all = False
+
+
+def _register(obj):
+    _live.add(obj)
+
+
+def _finalizing():
+    return _closed_all or sys is None or sys.is_finalizing()
+
+
+def close_all():
+    """Release every live native object now (idempotent).  Called automatically at interpreter exit."""
+    for o in sorted(list(_live), key=lambda o: _CLOSE_ORDER.get(type(o).__name__, 9)):
+        try:
+            o.close()
+        except Exception:
+            pass
+
+
+def _at_exit():
+    global _closed_all
+    close_all()
+    _closed_all = True
+    if _lib is not None:
+        try:
+            _lib.ldpc_shutdown()
+        except Exception:
+            pass
+
+
+atexit.register(_at_exit)
 
 
 def _preload_hip_runtime():
@@ -99,6 +141,10 @@ def lib():
     L.ldpc_ctx_create.argtypes = [vp, C.c_int, C.c_int, C.c_int]
     L.ldpc_ctx_create_ex.restype = vp
     L.ldpc_ctx_create_ex.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int]
+    L.ldpc_ctx_create_on.restype = vp
+    L.ldpc_ctx_create_on.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
+    L.ldpc_sim_create_on.restype = vp
+    L.ldpc_sim_create_on.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, u8p, C.c_int]
     L.ldpc_ctx_destroy.restype = None
     L.ldpc_ctx_destroy.argtypes = [vp]
     L.ldpc_ctx_path.argtypes = [vp]
@@ -181,13 +227,19 @@ class PinnedArray:
             raise LdpcError(lib().ldpc_last_error_code(), last_error())
         buf = (C.c_char * self.nbytes).from_address(self._p)
         self.array = np.frombuffer(buf, dtype=dtype).reshape(shape)
+        _register(self)
+
+    def close(self):
+        if self._p:
+            self.array = None
+            lib().ldpc_host_free(self._p)
+            self._p = None
 
     def __del__(self):
+        if _finalizing():
+            return
         try:
-            if self._p:
-                self.array = None
-                lib().ldpc_host_free(self._p)
-                self._p = None
+            self.close()
         except Exception:
             pass
 
@@ -209,6 +261,7 @@ class Code:
             raise LdpcError(lib().ldpc_last_error_code(), last_error())
         self._h = handle
         self._owned = owned
+        _register(self)
         M, N, E = C.c_int(), C.c_int(), C.c_int()
         check(lib().ldpc_code_dims(self._h, C.byref(M), C.byref(N), C.byref(E)))
         self.M, self.N, self.E = M.value, N.value, E.value
@@ -250,6 +303,8 @@ class Code:
         self._h = None
 
     def __del__(self):
+        if _finalizing():
+            return
         try:
             self.close()
         except Exception:
@@ -259,14 +314,19 @@ class Code:
 class Decoder:
     """One decoder replica (ldpc_ctx): the object behind the reference's per-frame closure."""
 
-    def __init__(self, code: Code, variant="min", dtype="f32", max_batch=64, path="auto", _handle=None):
+    def __init__(self, code: Code, variant="min", dtype="f32", max_batch=64, path="auto", _handle=None, device=None):
         self.code = code
         self.max_batch = int(max_batch)
         self._owned = _handle is None
-        self._h = _handle if _handle is not None else lib().ldpc_ctx_create_ex(
-            code._h, _VARIANTS[variant], _DTYPES[dtype], int(max_batch), _PATHS[path])
+        if _handle is not None:
+            self._h = _handle
+        elif device is None:
+            self._h = lib().ldpc_ctx_create_ex(code._h, _VARIANTS[variant], _DTYPES[dtype], int(max_batch), _PATHS[path])
+        else:   # explicit device: replicas of one code on several GPUs of this process
+            self._h = lib().ldpc_ctx_create_on(code._h, int(device), _VARIANTS[variant], _DTYPES[dtype], int(max_batch), _PATHS[path])
         if not self._h:
             raise LdpcError(lib().ldpc_last_error_code(), last_error())
+        _register(self)
         self.path = {PATH_FLOOD: "flood", PATH_FUSED: "fused"}[lib().ldpc_ctx_path(self._h)]
 
     def decode_one(self, llr, max_iters):
@@ -348,6 +408,8 @@ class Decoder:
         self._h = None
 
     def __del__(self):
+        if _finalizing():
+            return
         try:
             self.close()
         except Exception:
@@ -361,6 +423,7 @@ class Matrix:
         if not handle:
             raise LdpcError(lib().ldpc_last_error_code(), last_error())
         self._h = handle
+        _register(self)
         v = [C.c_int() for _ in range(5)]
         check(lib().ldpc_matrix_info(self._h, *[C.byref(x) for x in v]))
         self.rows, self.cols, self.sz, self.block_rows, self.block_cols = [x.value for x in v]
@@ -389,6 +452,8 @@ class Matrix:
             self._h = None
 
     def __del__(self):
+        if _finalizing():
+            return
         try:
             self.close()
         except Exception:
@@ -398,19 +463,23 @@ class Matrix:
 class Sim:
     """Device-side frame source + error tally (ldpc_sim)."""
 
-    def __init__(self, code: Code, k, n_tx, G=None, max_batch=64, _handle=None):
+    def __init__(self, code: Code, k, n_tx, G=None, max_batch=64, _handle=None, device=None):
         self.code, self.k, self.n_tx = code, int(k), int(n_tx)
         self._owned = _handle is None
         if _handle is None:
+            dev = int(device) if device is not None else lib().ldpc_current_device()
+            if dev < 0:
+                raise LdpcError(ENODEVICE, "ldpc_init() has not succeeded")
             if G is not None:
                 G = np.ascontiguousarray(G, np.uint8)
                 assert G.shape[0] == k
-                _handle = lib().ldpc_sim_create(code._h, int(k), int(n_tx), G.shape[1], ptr(G, C.c_uint8), int(max_batch))
+                _handle = lib().ldpc_sim_create_on(code._h, dev, int(k), int(n_tx), G.shape[1], ptr(G, C.c_uint8), int(max_batch))
             else:
-                _handle = lib().ldpc_sim_create(code._h, int(k), int(n_tx), 0, None, int(max_batch))
+                _handle = lib().ldpc_sim_create_on(code._h, dev, int(k), int(n_tx), 0, None, int(max_batch))
         if not _handle:
             raise LdpcError(lib().ldpc_last_error_code(), last_error())
         self._h = _handle
+        _register(self)
 
     def generate(self, seed, first_frame, batch, ebn0_db, d_llr_ptr, d_msg_ptr=None, stream=None, llr_f16=False):
         fn = lib().ldpc_sim_generate_f16 if llr_f16 else lib().ldpc_sim_generate
@@ -431,6 +500,8 @@ class Sim:
         self._h = None
 
     def __del__(self):
+        if _finalizing():
+            return
         try:
             self.close()
         except Exception:
@@ -445,6 +516,7 @@ class ECC:
         self._h = lib().ldpc_ecc_create(str(codes_dir).encode(), code_name.encode(), int(max_batch))
         if not self._h:
             raise LdpcError(lib().ldpc_last_error_code(), last_error())
+        _register(self)
         L = lib()
         self.name = L.ldpc_ecc_name(self._h).decode()
         self.message_length = L.ldpc_ecc_message_length(self._h)
@@ -479,6 +551,8 @@ class ECC:
             self._h = None
 
     def __del__(self):
+        if _finalizing():
+            return
         try:
             self.close()
         except Exception:

@@ -67,7 +67,7 @@ struct ldpc_ctx {
     // bounce buffers and ONE device block for bits|iters|converged, so a call costs one H2D copy, one launch and
     // one D2H copy instead of four pageable copies
     static constexpr int kSmallFrames = 16;
-    void *h_small_in = nullptr;
+    void *h_small_in = nullptr, *d_small_in = nullptr;   // its own 16-frame device input: no full-size staging
     uint8_t *h_small_out = nullptr, *d_small_out = nullptr;
     // zero-copy path: outputs the caller gave as pageable memory while llr/bits are page-locked
     int32_t *d_zc_iters = nullptr;
@@ -75,14 +75,45 @@ struct ldpc_ctx {
     ldpc::KernelTimer timer;
 };
 
+// Device selection.  ldpc_init(d) validates device d and makes it the CALLING THREAD's device (thread-local); the first
+// device any thread initialised is the process default for threads that never called ldpc_init.  Objects remember
+// the device they were created on, so several threads can drive several GPUs from one process
+// (Utils.hs:53,63-69: maxThreadCount replicas, chosen by thread).  ldpc_ctx_create_on names the device explicitly.
 static std::mutex g_mu;
-static int g_device = -1;
+static int g_default_device = -1;
+static uint64_t g_checked_mask = 0;          // devices that passed check_device (bit d)
+static thread_local int t_device = -1;
+
+static int check_device(int device) {
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        if (device >= 0 && device < 64 && ((g_checked_mask >> device) & 1u)) return LDPC_OK;
+    }
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return set_error(LDPC_ENODEVICE, "no HIP device visible (%s); the HIP path has no CPU fallback",
+                         e == hipSuccess ? "count = 0" : hipGetErrorString(e));
+    if (device < 0 || device >= n || device >= 64) return set_error(LDPC_EINVAL, "device %d out of range [0,%d)", device, n);
+    hipDeviceProp_t p;
+    HIPCHK(hipGetDeviceProperties(&p, device));
+    if (strncmp(p.gcnArchName, "gfx950", 6) != 0)
+        return set_error(LDPC_ENODEVICE, "device %d is %s; libldpc_hip.so carries gfx950 code objects only", device, p.gcnArchName);
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_checked_mask |= 1ull << device;
+    return LDPC_OK;
+}
+static int current_device() {   // the calling thread's device, else the process default, else -1
+    if (t_device >= 0) return t_device;
+    std::lock_guard<std::mutex> lk(g_mu);
+    return g_default_device;
+}
 
 extern "C" {
 
 const char *ldpc_last_error(void) { return ldpc::g_err; }
 int ldpc_last_error_code(void) { return ldpc::g_err_code; }
-int ldpc_abi_version(void) { return 1; }
+int ldpc_abi_version(void) { return 2; }
 
 int ldpc_device_count(void) {
     int n = 0;
@@ -91,27 +122,23 @@ int ldpc_device_count(void) {
 }
 
 int ldpc_init(int device) {
-    int n = 0;
-    hipError_t e = hipGetDeviceCount(&n);
-    if (e != hipSuccess || n <= 0)
-        return set_error(LDPC_ENODEVICE, "no HIP device visible (%s); the HIP path has no CPU fallback",
-                         e == hipSuccess ? "count = 0" : hipGetErrorString(e));
-    if (device < 0 || device >= n) return set_error(LDPC_EINVAL, "device %d out of range [0,%d)", device, n);
+    int rc = check_device(device);
+    if (rc != LDPC_OK) return rc;
     HIPCHK(hipSetDevice(device));
-    hipDeviceProp_t p;
-    HIPCHK(hipGetDeviceProperties(&p, device));
-    if (strncmp(p.gcnArchName, "gfx950", 6) != 0)
-        return set_error(LDPC_ENODEVICE, "device %d is %s; libldpc_hip.so carries gfx950 code objects only", device, p.gcnArchName);
+    t_device = device;
     std::lock_guard<std::mutex> lk(g_mu);
-    g_device = device;
+    if (g_default_device < 0) g_default_device = device;
     return LDPC_OK;
 }
 
 int ldpc_shutdown(void) {
+    t_device = -1;
     std::lock_guard<std::mutex> lk(g_mu);
-    g_device = -1;
+    g_default_device = -1;
     return LDPC_OK;
 }
+
+int ldpc_current_device(void) { return current_device(); }
 
 // ------------------------------------------------------------------------------- graph
 static int finish_code(ldpc_code *c) {
@@ -207,11 +234,15 @@ ldpc_code *ldpc_code_create_qc(int sz, int block_rows, int block_cols, const int
 }
 
 static void code_free_device(ldpc_code *c) {
-    if (c->device >= 0) {
-        hipFree(c->d_row_ptr); hipFree(c->d_col_idx); hipFree(c->d_col_ptr); hipFree(c->d_csc_edge);
-        c->d_row_ptr = c->d_col_idx = c->d_col_ptr = c->d_csc_edge = nullptr;
-        c->device = -1;
+    std::lock_guard<std::mutex> lk(c->dev_mu);
+    int prev = -1;
+    (void)hipGetDevice(&prev);
+    for (auto &kv : c->dev) {
+        if (hipSetDevice(kv.first) != hipSuccess) continue;
+        (void)hipFree(kv.second.row_ptr); (void)hipFree(kv.second.col_idx); (void)hipFree(kv.second.col_ptr); (void)hipFree(kv.second.csc_edge);
     }
+    c->dev.clear();
+    if (prev >= 0) (void)hipSetDevice(prev);
 }
 
 void ldpc_code_destroy(ldpc_code *code) {
@@ -235,10 +266,12 @@ int ldpc_code_csr(const ldpc_code *code, int32_t *row_ptr, int32_t *col_idx) {
     return LDPC_OK;
 }
 
-static int code_upload(ldpc_code *c, int device) {
-    std::lock_guard<std::mutex> lk(g_mu);
-    if (c->device == device) return LDPC_OK;
-    if (c->device >= 0) return set_error(LDPC_EUNSUPPORTED, "code already bound to device %d", c->device);
+// the graph tables on `device` (uploaded by the first caller); the calling thread's current device must be `device`
+static int code_upload(ldpc_code *c, int device, ldpc_code_dev *out) {
+    std::lock_guard<std::mutex> lk(c->dev_mu);
+    auto it = c->dev.find(device);
+    if (it != c->dev.end()) { *out = it->second; return LDPC_OK; }
+    ldpc_code_dev t;
     auto up = [&](int32_t **dst, const std::vector<int32_t> &v) -> int {
         size_t bytes = sizeof(int32_t) * std::max<size_t>(v.size(), 1);
         HIPCHK(hipMalloc((void **)dst, bytes));
@@ -246,19 +279,20 @@ static int code_upload(ldpc_code *c, int device) {
         return LDPC_OK;
     };
     int rc;
-    if ((rc = up(&c->d_row_ptr, c->row_ptr)) || (rc = up(&c->d_col_idx, c->col_idx)) ||
-        (rc = up(&c->d_col_ptr, c->col_ptr)) || (rc = up(&c->d_csc_edge, c->csc_edge))) {
-        (void)hipFree(c->d_row_ptr); (void)hipFree(c->d_col_idx); (void)hipFree(c->d_col_ptr); (void)hipFree(c->d_csc_edge);
-        c->d_row_ptr = c->d_col_idx = c->d_col_ptr = c->d_csc_edge = nullptr;   // a half-uploaded graph is not kept
+    if ((rc = up(&t.row_ptr, c->row_ptr)) || (rc = up(&t.col_idx, c->col_idx)) ||
+        (rc = up(&t.col_ptr, c->col_ptr)) || (rc = up(&t.csc_edge, c->csc_edge))) {
+        (void)hipFree(t.row_ptr); (void)hipFree(t.col_idx); (void)hipFree(t.col_ptr); (void)hipFree(t.csc_edge);   // a half-uploaded graph is not kept
         return rc;
     }
-    c->device = device;
+    c->dev[device] = t;
+    *out = t;
     return LDPC_OK;
 }
 
 // ------------------------------------------------------------------------------- contexts
 void ldpc_ctx_destroy(ldpc_ctx *ctx) {
     if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
     if (ctx->stream) hipStreamSynchronize(ctx->stream);
     ldpc::flood_graph_release(ctx->flood);
     hipFree(ctx->flood.msg); hipFree(ctx->flood.scratch); hipFree(ctx->flood.lam); hipFree(ctx->flood.orig);
@@ -268,7 +302,7 @@ void ldpc_ctx_destroy(ldpc_ctx *ctx) {
     for (int i = 1; i < ldpc_ctx::kSlots; i++) if (ctx->pstream[i]) hipStreamDestroy(ctx->pstream[i]);
     if (ctx->h_small_in) (void)hipHostFree(ctx->h_small_in);
     if (ctx->h_small_out) (void)hipHostFree(ctx->h_small_out);
-    (void)hipFree(ctx->d_small_out);
+    (void)hipFree(ctx->d_small_out); (void)hipFree(ctx->d_small_in);
     (void)hipFree(ctx->d_zc_iters); (void)hipFree(ctx->d_zc_conv);
     if (ctx->fused) ldpc::fused_destroy(ctx->fused);
     ctx->timer.destroy();
@@ -276,7 +310,16 @@ void ldpc_ctx_destroy(ldpc_ctx *ctx) {
     delete ctx;
 }
 
-ldpc_ctx *ldpc_ctx_create_ex(const ldpc_code *code_c, int variant, int dtype, int max_batch, int path) {
+ldpc_ctx *ldpc_ctx_create_ex(const ldpc_code *code, int variant, int dtype, int max_batch, int path) {
+    const int device = current_device();
+    if (device < 0) {
+        set_error(LDPC_ENODEVICE, "ldpc_init() has not succeeded: no GPU bound (there is no CPU fallback)");
+        return nullptr;
+    }
+    return ldpc_ctx_create_on(code, device, variant, dtype, max_batch, path);
+}
+
+ldpc_ctx *ldpc_ctx_create_on(const ldpc_code *code_c, int device, int variant, int dtype, int max_batch, int path) {
     ldpc_code *code = const_cast<ldpc_code *>(code_c);
     if (!code || max_batch <= 0 || (variant != LDPC_TANH && variant != LDPC_MINSUM) ||
         (dtype != LDPC_F32 && dtype != LDPC_F64 && dtype != LDPC_F16) ||
@@ -288,17 +331,10 @@ ldpc_ctx *ldpc_ctx_create_ex(const ldpc_code *code_c, int variant, int dtype, in
         set_error(LDPC_EDEGREE, "min-sum on a check row of degree 1 (the reference's foldr1 min' fails on [], Min.hs:79)");
         return nullptr;
     }
-    int device;
-    {
-        std::lock_guard<std::mutex> lk(g_mu);
-        device = g_device;
-    }
-    if (device < 0) {
-        set_error(LDPC_ENODEVICE, "ldpc_init() has not succeeded: no GPU bound (there is no CPU fallback)");
-        return nullptr;
-    }
+    if (check_device(device) != LDPC_OK) return nullptr;
     HIPCHK_NULL(hipSetDevice(device));
-    if (code_upload(code, device) != LDPC_OK) return nullptr;
+    ldpc_code_dev tabs;
+    if (code_upload(code, device, &tabs) != LDPC_OK) return nullptr;
 
     const bool fused_ok = ldpc::fused_supported(*code, variant, dtype);
     if (path == LDPC_PATH_FUSED && !fused_ok) {
@@ -326,7 +362,7 @@ ldpc_ctx *ldpc_ctx_create_ex(const ldpc_code *code_c, int variant, int dtype, in
     const size_t Bp = (size_t)ctx->Bp;
     ldpc::FloodDev &d = ctx->flood.dev;
     d.M = code->M; d.N = code->N; d.E = code->E; d.Bp = ctx->Bp;
-    d.row_ptr = code->d_row_ptr; d.col_idx = code->d_col_idx; d.col_ptr = code->d_col_ptr; d.csc_edge = code->d_csc_edge;
+    d.row_ptr = tabs.row_ptr; d.col_idx = tabs.col_idx; d.col_ptr = tabs.col_ptr; d.csc_edge = tabs.csc_edge;
     d.unsat = nullptr; d.iters = nullptr; d.conv = nullptr; d.done = nullptr;
     d.wide_rows = 0;
     ctx->flood.variant = variant; ctx->flood.dtype = dtype; ctx->flood.timer = &ctx->timer;
@@ -481,20 +517,20 @@ static int decode_host(ldpc_ctx *ctx, int max_iters, int batch, const void *llr,
             return rc;
         }
     }
-    if ((rc = ensure_staging(ctx, final_lam != nullptr)) != LDPC_OK) return rc;
     const size_t N = (size_t)ctx->code->N, es = fmt == ldpc::LLR_F64 ? 8 : (fmt == ldpc::LLR_F16 ? 2 : 4);
-    if (batch <= ldpc_ctx::kSmallFrames && !final_lam && !trace_lam) {   // latency path
+    if (batch <= ldpc_ctx::kSmallFrames && !final_lam && !trace_lam) {   // latency path (allocates 16 frames, never the full-size staging)
         const size_t cap = (size_t)ldpc_ctx::kSmallFrames;
         const size_t out_cap = cap * N + cap * sizeof(int32_t) + cap + 16;
         if (!ctx->h_small_in) {
             hipError_t e = hipHostMalloc(&ctx->h_small_in, cap * N * sizeof(double), hipHostMallocDefault);
             if (e == hipSuccess) e = hipHostMalloc((void **)&ctx->h_small_out, out_cap, hipHostMallocDefault);
             if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_small_out, out_cap);
+            if (e == hipSuccess) e = hipMalloc(&ctx->d_small_in, cap * N * sizeof(double));
             if (e != hipSuccess) {
                 if (ctx->h_small_in) (void)hipHostFree(ctx->h_small_in);
                 if (ctx->h_small_out) (void)hipHostFree(ctx->h_small_out);
-                (void)hipFree(ctx->d_small_out);
-                ctx->h_small_in = nullptr; ctx->h_small_out = nullptr; ctx->d_small_out = nullptr;
+                (void)hipFree(ctx->d_small_out); (void)hipFree(ctx->d_small_in);
+                ctx->h_small_in = nullptr; ctx->h_small_out = nullptr; ctx->d_small_out = nullptr; ctx->d_small_in = nullptr;
                 return set_error(LDPC_ENOMEM, "latency-path buffers: %s", hipGetErrorString(e));
             }
         }
@@ -502,9 +538,9 @@ static int decode_host(ldpc_ctx *ctx, int max_iters, int batch, const void *llr,
         const size_t off_it = (nb * N + 3) / 4 * 4, off_cv = off_it + nb * sizeof(int32_t), out_bytes = off_cv + nb;
         memcpy(ctx->h_small_in, llr, in_bytes);
         hipStream_t st = ctx->stream;
-        hipError_t e = hipMemcpyAsync(ctx->d_in[0], ctx->h_small_in, in_bytes, hipMemcpyHostToDevice, st);
+        hipError_t e = hipMemcpyAsync(ctx->d_small_in, ctx->h_small_in, in_bytes, hipMemcpyHostToDevice, st);
         if (e == hipSuccess) {
-            rc = decode_dev(ctx, st, max_iters, batch, ctx->d_in[0], fmt, ctx->d_small_out, (int32_t *)(ctx->d_small_out + off_it),
+            rc = decode_dev(ctx, st, max_iters, batch, ctx->d_small_in, fmt, ctx->d_small_out, (int32_t *)(ctx->d_small_out + off_it),
                             ctx->d_small_out + off_cv, nullptr, nullptr);
             if (rc == LDPC_OK) e = hipMemcpyAsync(ctx->h_small_out, ctx->d_small_out, out_bytes, hipMemcpyDeviceToHost, st);
         }
@@ -517,6 +553,7 @@ static int decode_host(ldpc_ctx *ctx, int max_iters, int batch, const void *llr,
         if (converged) memcpy(converged, ctx->h_small_out + off_cv, nb);
         return LDPC_OK;
     }
+    if ((rc = ensure_staging(ctx, final_lam != nullptr)) != LDPC_OK) return rc;
     double *d_trace = nullptr;
     const size_t turns = (size_t)max_iters + 1;
     if (trace_lam) {  // verification path: one device buffer for the whole batch
@@ -672,19 +709,24 @@ extern "C" {
 
 void ldpc_sim_destroy(ldpc_sim *sim) {
     if (!sim) return;
+    (void)hipSetDevice(sim->device);
     hipFree(sim->d_gt);
     hipFree(sim->d_msgw);
     delete sim;
 }
 
 ldpc_sim *ldpc_sim_create(const ldpc_code *code, int k, int n_tx, int p, const uint8_t *G, int max_batch) {
+    const int device = current_device();
+    if (device < 0) { set_error(LDPC_ENODEVICE, "ldpc_init() has not succeeded"); return nullptr; }
+    return ldpc_sim_create_on(code, device, k, n_tx, p, G, max_batch);
+}
+
+ldpc_sim *ldpc_sim_create_on(const ldpc_code *code, int device, int k, int n_tx, int p, const uint8_t *G, int max_batch) {
     if (!code || k <= 0 || n_tx < k || n_tx > code->N || max_batch <= 0 || (G && (p <= 0 || k + p < n_tx))) {
         set_error(LDPC_EINVAL, "ldpc_sim_create: bad arguments (k=%d n_tx=%d p=%d N=%d)", k, n_tx, p, code ? code->N : -1);
         return nullptr;
     }
-    int device;
-    { std::lock_guard<std::mutex> lk(g_mu); device = g_device; }
-    if (device < 0) { set_error(LDPC_ENODEVICE, "ldpc_init() has not succeeded"); return nullptr; }
+    if (check_device(device) != LDPC_OK) return nullptr;
     ldpc_sim *s = new (std::nothrow) ldpc_sim();
     if (!s) { set_error(LDPC_ENOMEM, "out of host memory"); return nullptr; }
     s->device = device; s->p = G ? p : 0; s->max_batch = max_batch;

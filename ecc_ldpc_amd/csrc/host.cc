@@ -176,6 +176,11 @@ static int parse_alist_mackay(const std::string &text, ldpc_matrix *m) {
     size_t pos = 4;
     std::vector<long> colw(t.begin() + pos, t.begin() + pos + N); pos += N;
     std::vector<long> roww(t.begin() + pos, t.begin() + pos + M); pos += M;
+    // a weight beyond the header's maxima would walk past the column's / row's slot (and past the token vector)
+    for (long c = 0; c < N; c++)
+        if (colw[(size_t)c] < 0 || colw[(size_t)c] > maxc) return set_error(LDPC_EFORMAT, "alist: weight %ld of column %ld outside [0,%ld]", colw[(size_t)c], c + 1, maxc);
+    for (long r = 0; r < M; r++)
+        if (roww[(size_t)r] < 0 || roww[(size_t)r] > maxr) return set_error(LDPC_EFORMAT, "alist: weight %ld of row %ld outside [0,%ld]", roww[(size_t)r], r + 1, maxr);
     m->rows = (int)M; m->cols = (int)N;
     m->dense.assign((size_t)M * N, 0);
     for (long c = 0; c < N; c++, pos += maxc)

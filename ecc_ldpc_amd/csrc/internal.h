@@ -2,6 +2,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -85,7 +87,10 @@ size_t flood_elem_size(int dtype);
 
 }  // namespace ldpc
 
-// host-side graph (immutable after creation)
+// host-side graph (immutable after creation, except for the lazily created per-device copies of its tables)
+struct ldpc_code_dev {
+    int32_t *row_ptr = nullptr, *col_idx = nullptr, *col_ptr = nullptr, *csc_edge = nullptr;
+};
 struct ldpc_code {
     int M = 0, N = 0, E = 0;
     std::vector<int32_t> row_ptr, col_idx, col_ptr, csc_edge;
@@ -93,7 +98,8 @@ struct ldpc_code {
     // quasi-cyclic description when created through ldpc_code_create_qc (sz = 0 otherwise)
     int sz = 0, block_rows = 0, block_cols = 0;
     std::vector<int32_t> offsets;
-    // device copies (created lazily by the first context on that device)
-    int device = -1;
-    int32_t *d_row_ptr = nullptr, *d_col_idx = nullptr, *d_col_ptr = nullptr, *d_csc_edge = nullptr;
+    // device copies, one set per HIP device (created by the first context on that device): a code may be shared by
+    // replicas on several GPUs of one process (Utils.hs:53 replicateM maxThreadCount)
+    std::mutex dev_mu;
+    std::map<int, ldpc_code_dev> dev;
 };

@@ -68,8 +68,14 @@ typedef enum {
 /* ---- library life-cycle -------------------------------------------------------------------
  * replaces  initialize :: IO CudaAllocations  (GPU/CUDA/Arraylet2.hs:287-293: dummy malloc to
  * create the context + loadFile "cudabits/arraylet2.ptx") and finalize (:295-297).          */
-int ldpc_init(int device);          /* idempotent; selects the HIP device for the calling thread */
+/* ldpc_init: idempotent; checks that `device` is a gfx950 GPU and makes it the CALLING THREAD's device: objects the
+ * thread creates afterwards live there.  The first device any thread initialised is the default of threads that
+ * never called ldpc_init.  One process can drive several GPUs: one thread per GPU each calling ldpc_init(its device),
+ * or one thread using the *_on constructors below (the reference makes maxThreadCount replicas in one process and
+ * picks one by thread, Utils.hs:53,63-69). */
+int ldpc_init(int device);
 int ldpc_shutdown(void);
+int ldpc_current_device(void);      /* the calling thread's device (see ldpc_init), -1 if none */
 const char *ldpc_last_error(void);  /* thread-local, never NULL */
 int ldpc_last_error_code(void);     /* the LDPC_E* code that message belongs to (0 if none yet) */
 int ldpc_abi_version(void);         /* bumps when a signature in this header changes */
@@ -97,6 +103,9 @@ int ldpc_code_csr(const ldpc_code *code, int32_t *row_ptr /*M+1*/, int32_t *col_
  * buffers and one HIP stream; sized for frames <= max_batch per call. */
 ldpc_ctx *ldpc_ctx_create(const ldpc_code *code, int variant, int dtype, int max_batch);
 ldpc_ctx *ldpc_ctx_create_ex(const ldpc_code *code, int variant, int dtype, int max_batch, int path);
+/* the same on an explicitly named device (no ldpc_init needed on this thread; a code may have replicas on several
+ * devices, its graph tables are uploaded once per device) */
+ldpc_ctx *ldpc_ctx_create_on(const ldpc_code *code, int device, int variant, int dtype, int max_batch, int path);
 void ldpc_ctx_destroy(ldpc_ctx *ctx);
 /* LDPC_PATH_FLOOD or LDPC_PATH_FUSED: what the context resolved to */
 int ldpc_ctx_path(const ldpc_ctx *ctx);
@@ -176,6 +185,7 @@ const char *ldpc_ctx_kernel_name(const ldpc_ctx *ctx);
  * positions n_tx..N-1 are punctured: LLR 0 (Utils.hs:55). */
 typedef struct ldpc_sim ldpc_sim;
 ldpc_sim *ldpc_sim_create(const ldpc_code *code, int k, int n_tx, int p, const uint8_t *G, int max_batch);
+ldpc_sim *ldpc_sim_create_on(const ldpc_code *code, int device, int k, int n_tx, int p, const uint8_t *G, int max_batch);
 void ldpc_sim_destroy(ldpc_sim *sim);
 /* frames [first_frame, first_frame+batch) of the stream identified by `seed`, at Eb/N0 (dB):
  * d_llr [batch][N] float32 (device), d_msg [batch][k] bytes (device, may be NULL).  Enqueued on

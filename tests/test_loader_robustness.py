@@ -67,3 +67,18 @@ def test_qc_descriptor_limits():
         E.Code.from_qc(1 << 20, np.zeros((1 << 6, 1 << 6), np.int32))     # M, N overflow guard
     with pytest.raises(E.LdpcError):
         E.Code.from_qc(8, np.full((2, 2), 8, np.int32))                    # offset == sz
+
+
+def test_mackay_weights_beyond_header_maxima_are_rejected(tmp_path):
+    """A column (row) weight above the header's max must not walk past its slot: 4 columns x 2 rows, maxc = 2,
+    but column 1 claims weight 9 (host.cc parse_alist_mackay)."""
+    good = b"4 2\n2 4\n2 2 2 2\n4 4\n1 2\n1 2\n1 2\n1 2\n1 2 3 4\n1 2 3 4\n"
+    assert _try(tmp_path, good, "mackay", "good") is None
+    bad_col = good.replace(b"2 2 2 2\n", b"9 2 2 2\n", 1)
+    msg = _try(tmp_path, bad_col, "mackay", "badcol")
+    assert msg and "weight 9 of column 1" in msg
+    bad_row = good.replace(b"4 4\n1 2", b"4 7\n1 2", 1)
+    msg = _try(tmp_path, bad_row, "mackay", "badrow")
+    assert msg and "weight 7 of row 2" in msg
+    neg = good.replace(b"2 2 2 2\n", b"-1 2 2 2\n", 1)
+    assert _try(tmp_path, neg, "mackay", "neg")

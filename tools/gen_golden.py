@@ -28,15 +28,25 @@ CASES = [
     ("jpl.1024.4.5", "min", 12, [(3.0, 41), (4.0, 42), (2.0, 43)], False),
     ("1920.1280.3.303", "tanh", 10, [(2.5, 51), (4.0, 52)], False),
     ("1920.1280.3.303", "min", 10, [(2.5, 61), (4.0, 62)], False),
+    # the headline code (added in round 2; these fixtures also carry the QC description so that the GPU test can run the
+    # fused QC kernels on them, not only the CSR paths)
+    ("jpl.4096.4.5", "min", 10, [(3.4, 71), (3.9, 72), (2.0, 73)], False),
+    ("jpl.4096.4.5", "tanh", 8, [(3.4, 81), (2.0, 82)], False),
 ]
 
 
 def main():
     os.makedirs(OUT, exist_ok=True)
+    only = [a for a in sys.argv[1:] if not a.startswith("-")]   # e.g. `python tools/gen_golden.py jpl.4096.4.5`
     for name, variant, iters, frames, use_literal in CASES:
+        if only and name not in only:
+            continue
         c = load(name)
         rec = dict(row_ptr=c.graph.row_ptr, col_idx=c.graph.col_idx, N=np.int32(c.N), max_iters=np.int32(iters),
                    variant=np.array(variant))
+        if name == "jpl.4096.4.5":
+            rec["qc_sz"] = np.int32(c.sz)
+            rec["qc_offsets"] = c.offsets.astype(np.int32)
         for i, (db, seed) in enumerate(frames):
             cw, llr = c.frames(1, db, seed)
             llr = llr[0]

@@ -24,6 +24,8 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+N_SIMD, CLOCK_HZ = 256 * 4, 2.4e9          # 256 CUs x 4 SIMDs, peak engine clock
+VALU_PEAK = N_SIMD * CLOCK_HZ / 2          # wave-instructions / s: a full-rate VALU instruction issues every 2 clk per SIMD
 
 
 def main():
@@ -84,6 +86,7 @@ def main():
     k, n_tx, N, Eg = ecc.message_length, ecc.codeword_length, code.N, code.E
     B = args.batch
     s_bytes = {"f32": 4, "f64": 8, "f16": 2}[args.dtype]
+    B_cw = args.iters * (3 * Eg + 3 * N) * s_bytes + n_tx * s_bytes + (k + 7) // 8   # SURVEY.md section 8d, at max_iters
 
     # one explicit non-default stream for everything the library enqueues (a NULL handle would mean
     # "the context's own stream" for decode but the default stream for the frame source)
@@ -138,31 +141,21 @@ def main():
     frames_total = world * args.steps * B
     value = frames_total * k / elapsed / 1e6
 
-    # ---- roofline of the dominant kernel (HIP events on the launch stream, live in this run)
-    B_iter = (3 * Eg + 3 * N) * s_bytes
-    B_cw = args.iters * B_iter + n_tx * s_bytes + (k + 7) // 8
-    if dec.path == "fused":
-        bytes_per_launch = B * B_cw
-        bytes_note = "B_cw * frames per launch"
-    else:
-        bytes_per_launch = B * (2 * Eg + N) * s_bytes
-        bytes_note = "(2E+N)*s * frames per launch (check-node kernel's share of B_iter)"
-    avg_ms = kernel_ms / max(launches, 1)
-    achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if launches else 0.0
-    roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": measured_traffic(args, dec, B),
-                "kernel": dec.kernel_name, "launches": launches, "avg_launch_ms": round(avg_ms, 4),
-                "algorithmic_bytes_per_launch": bytes_per_launch, "bytes_model": bytes_note}
-    if dec.path == "fused":
-        # the fused kernels keep the BP state on-chip, so `frac` (the contract's HBM byte model) exceeds 1; what binds
-        # them is VALU issue -- figures from the committed PMC passes of this workload, when there are any
-        roofline["binding_resource"] = onchip_note(args)
+    # ---- iterations the timed steps really ran (early exit): one untimed pass per distinct input buffer
+    sum_iters_buf = []
+    for i in range(nbuf):
+        step(i)
+        torch.cuda.synchronize()
+        sum_iters_buf.append(int(iters_t.sum().item()))
+    turns_timed = sum(sum_iters_buf[(args.warmup + i) % nbuf] for i in range(args.steps))   # frame-turns of this rank
+    roofline, roofline_hbm = rooflines(args, dec, B, Eg, N, n_tx, k, s_bytes, launches, kernel_ms, turns_timed)
+    pow_obj = proof_of_work(args, E, ecc, dec, sim, llr[0], msg[0], bits, iters_t, conv_t, sp, f16) if rank == 0 else None
 
     out = None
     if rank == 0:
         t = tally.tolist()
         out = {
-            "metric": "decoded info Mbit/s @ 50 BP iters, jpl.4096.4.5, Eb/N0=2 dB",
+            "metric": f"decoded info Mbit/s @ {args.iters} BP iters, {args.code}, Eb/N0={args.ebn0:g} dB",
             "value": round(value, 2), "unit": "Mbit/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
@@ -171,6 +164,8 @@ def main():
                        "batch_per_gpu": B, "parallelism": f"frames sharded over {world} GPU(s), tallies all-reduced"},
             **({"rehearsal": "ranks share GPUs over gloo; not a measurement"} if rehearse else {}),
             "roofline": roofline,
+            **({"roofline_hbm_model": roofline_hbm} if roofline_hbm else {}),
+            "proof_of_work": pow_obj,
             "hbm_roofline_mbit_s": round(HBM_PEAK_GBS * 1e9 / B_cw * k / 1e6, 1),
             "frac_of_hbm_roofline_throughput": round(value / world / (HBM_PEAK_GBS * 1e9 / B_cw * k / 1e6), 4),
             "ber": t[2] / max(t[0] * k, 1), "fer": t[1] / max(t[0], 1), "mean_iters": t[3] / max(t[0], 1),
@@ -187,39 +182,138 @@ def main():
         dist.destroy_process_group()
 
 
-def measured_traffic(args, dec, B):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
-    (profiles/*_pmc.json: FETCH_SIZE and WRITE_SIZE collected in separate --pmc runs of this same
-    command), scaled by frames per launch; None when no profile of this configuration is committed."""
-    if not (dec.path == "fused" and args.variant == "minsum" and args.dtype == "f32"):
-        return None
-    tag = {"jpl.4096.4.5": "r01_final_jpl4096_f32_minsum", "jpl.1024.4.5": "r01_final_jpl1024_f32_minsum"}.get(args.code)
-    if tag is None:
-        return None
-    try:
-        prof = json.load(open(os.path.join(ROOT, "profiles", tag + "_pmc.json")))
-        h = prof["hbm_bytes_per_launch"]   # collected at 65536 frames per launch (tools/profile.sh)
-        fetch = h.get("FETCH_SIZE_corrected_bytes", 2 * h["FETCH_SIZE_raw_bytes"])   # gfx950: raw FETCH_SIZE is 1/2 of the bytes
-        return int((fetch + h["WRITE_SIZE_bytes"]) * B / 65536)
-    except Exception:
-        return None
+PROFILE_TAGS = {   # committed rocprofv3 PMC passes of these workloads at 65 536 frames per launch (tools/profile.sh)
+    ("jpl.4096.4.5", "minsum", "f32"): "jpl4096_f32_minsum", ("jpl.1024.4.5", "minsum", "f32"): "jpl1024_f32_minsum",
+    ("jpl.4096.4.5", "tanh", "f32"): "jpl4096_f32_tanh", ("1920.1280.3.303", "tanh", "f32"): "mackay_f32_tanh"}
 
 
-def onchip_note(args):
-    tag = {("jpl.4096.4.5", "minsum"): "r01_final_jpl4096_f32_minsum", ("jpl.1024.4.5", "minsum"): "r01_final_jpl1024_f32_minsum",
-           ("jpl.4096.4.5", "tanh"): "r01_final_jpl4096_f32_tanh", ("1920.1280.3.303", "tanh"): "r01_final_mackay_f32_tanh"}.get((args.code, args.variant))
-    note = {"bound": "valu issue + LDS round trips (state on-chip; HBM carries the LLRs in and the bits out only)"}
+def committed_traffic(args, dec, B):
+    """HBM bytes per launch of the dominant kernel from a COMMITTED rocprofv3 PMC pass (profiles/*_pmc.json:
+    FETCH_SIZE and WRITE_SIZE collected in separate --pmc runs of this same command, FETCH_SIZE doubled as the
+    gfx950 guide prescribes), scaled by frames per launch -> (bytes, source file) or (None, None).  Counters cannot be
+    read from inside the process; this value is therefore NOT measured in this run and says which file it is from."""
+    tag = PROFILE_TAGS.get((args.code, args.variant, args.dtype))
+    if dec.path != "fused" or tag is None:
+        return None, None
+    for rnd in ("r02_final_", "r01_final_"):
+        path = os.path.join(ROOT, "profiles", rnd + tag + "_pmc.json")
+        try:
+            h = json.load(open(path))["hbm_bytes_per_launch"]
+            fetch = h.get("FETCH_SIZE_corrected_bytes", 2 * h["FETCH_SIZE_raw_bytes"])
+            return int((fetch + h["WRITE_SIZE_bytes"]) * B / 65536), os.path.relpath(path, ROOT)
+        except Exception:
+            continue
+    return None, None
+
+
+def isa_entry(kernel_name):
+    """instruction histogram of the kernel's iteration loop from the build's own assembly
+    (ecc_ldpc_amd/build/isa_stats.json, written by build.py with tools/isa_histogram.py)"""
     try:
-        m = json.load(open(os.path.join(ROOT, "profiles", tag + "_pmc.json")))["per_dispatch_mean"]
-        gui = m["GRBM_GUI_ACTIVE"] / 8          # summed over the 8 XCDs
-        note.update({"source": f"profiles/{tag}_pmc.json",
-                     "valu_issue_interval_clk_per_simd": round(gui * 1024 / m["SQ_INSTS_VALU"], 2),
-                     "waves_per_cu": round(m["SQ_WAVE_CYCLES"] * 4 / gui / 256, 1),
-                     "lds_busy": round(m["SQ_LDS_IDX_ACTIVE"] / (gui * 256), 2),
-                     "lds_bank_conflict_share": round(m["SQ_LDS_BANK_CONFLICT"] / max(m["SQ_LDS_IDX_ACTIVE"], 1), 2)})
+        stats = json.load(open(os.path.join(ROOT, "ecc_ldpc_amd", "build", "isa_stats.json")))
     except Exception:
-        pass
-    return note
+        return None
+    hits = [r for r in stats if kernel_name and kernel_name in r["kernel"]]
+    if len(hits) != 1 or any(lp.get("inner_loops") for lp in hits[0]["loops"]):
+        return None     # data-dependent inner loops (row-by-row generic kernel): a static count does not price a turn
+    return hits[0]
+
+
+def rooflines(args, dec, B, Eg, N, n_tx, k, s_bytes, launches, kernel_ms, turns_timed):
+    """-> (roofline, second object or None).
+    On-chip (fused) kernels keep the BP state in LDS/registers: HBM sees the LLRs in and the bits out, so the bound is
+    VALU issue.  achieved = VALU wave-instructions per second = (VALU instructions one wave issues per ordinary turn of
+    the iteration loop, counted in the build's assembly) x waves per frame x frame-turns REALLY run in the timed steps
+    (sum of the per-frame iteration counts -- early exit priced as it happened) / summed launch time (HIP events on the
+    launch stream); peak = 1024 SIMDs x 2.4 GHz / 2 clk (full-rate issue, MI355X_MICROARCH.md).  The contract's HBM
+    byte model (a two-kernel decoder with state in HBM) is kept as `roofline_hbm_model`, priced with
+    the same iteration sum; its frac > 1 is the on-chip residency, not a measurement of HBM."""
+    avg_ms = kernel_ms / max(launches, 1)
+    steps = max(args.steps, 1)
+    frames_timed = steps * B
+    B_iter = (3 * Eg + 3 * N) * s_bytes
+    # sum over frames of iters_f * B_iter  +  per frame: one more syndrome pass (reads lam), LLRs in, bits out
+    model_bytes = turns_timed * B_iter + frames_timed * (N * s_bytes + n_tx * s_bytes + (k + 7) // 8)
+    hbm = {"bound": "hbm", "achieved": round(model_bytes / (kernel_ms * 1e-3) / 1e9, 1) if kernel_ms else 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+           "bytes_model": "sum_frames(iters_f)*(3E+3N)*s + frames*(N*s + n_tx*s + ceil(k/8)) -- SURVEY.md section 8d priced with the iterations run",
+           "algorithmic_bytes_timed": model_bytes, "mean_iters_timed": round(turns_timed / frames_timed, 3)}
+    hbm["frac"] = round(hbm["achieved"] / HBM_PEAK_GBS, 4)
+    traffic, tsrc = committed_traffic(args, dec, B)
+    if dec.path != "fused":
+        # flood path: state in HBM, two kernels per turn; the timed kernel is the check-node kernel and every launch of
+        # it streams (2E+N)*s bytes per frame of the batch
+        bytes_per_launch = B * (2 * Eg + N) * s_bytes
+        ach = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if launches else 0.0
+        r = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
+             "traffic": None, "kernel": dec.kernel_name, "launches": launches, "avg_launch_ms": round(avg_ms, 4),
+             "algorithmic_bytes_per_launch": bytes_per_launch, "bytes_model": "(2E+N)*s * frames per check-node launch"}
+        return r, hbm
+    threads, fpw = dec.kernel_geometry
+    ent = isa_entry(dec.kernel_name)
+    r = {"bound": "valu", "unit": "G wave-instr/s", "peak": round(VALU_PEAK / 1e9, 1), "kernel": dec.kernel_name, "launches": launches,
+         "avg_launch_ms": round(avg_ms, 4), "traffic": traffic, "traffic_source": tsrc and f"{tsrc} (committed PMC pass, not measured in this run)",
+         "frame_turns_timed": turns_timed, "threads_per_workgroup": threads, "frames_per_workgroup": fpw}
+    if ent is None or not threads or not fpw or not kernel_ms:
+        r.update({"achieved": None, "frac": None, "note": "no static instruction count for this kernel instance (build/isa_stats.json)"})
+        return r, hbm
+    loops = ent["loops"]          # one per wave-group program; a wave runs exactly one of them, groups are equal in size
+    valu_wave = sum(lp["hot_turn"]["units"].get("valu", 0) for lp in loops) / len(loops)
+    clk_wave = sum(lp["hot_turn"]["valu_cost_weighted_clk"] for lp in loops) / len(loops)
+    lds_wave = sum(lp["hot_turn"]["units"].get("lds", 0) for lp in loops) / len(loops)
+    waves_per_frame = threads / 64.0 / fpw
+    t = kernel_ms * 1e-3
+    ach = valu_wave * waves_per_frame * turns_timed / t
+    by_class = {}
+    for lp in loops:
+        for c, v in lp["hot_turn"]["valu_by_class"].items():
+            by_class[c] = by_class.get(c, 0) + v / len(loops)
+    r.update({"achieved": round(ach / 1e9, 1), "frac": round(ach / VALU_PEAK, 4),
+              "valu_instr_per_wave_turn": round(valu_wave, 1), "valu_instr_per_wave_turn_by_issue_class": {c: round(v, 1) for c, v in sorted(by_class.items())},
+              "lds_instr_per_wave_turn": round(lds_wave, 1), "waves_per_frame": waves_per_frame,
+              # share of all SIMD cycles in which the VALU pipe was busy if every instruction took exactly its issue cost
+              "valu_pipe_busy_frac": round(clk_wave * waves_per_frame * turns_timed / (N_SIMD * CLOCK_HZ * t), 4),
+              "isa_source": "ecc_ldpc_amd/build/isa_stats.json = tools/isa_histogram.py over this build's own assembly (hot turn of the iteration loop; "
+                            "prologue, the final syndrome-only pass and convergence snapshots are not counted: achieved is a lower bound)"})
+    return r, hbm
+
+
+def proof_of_work(args, E, ecc, dec, sim, llr_t, msg_t, bits, iters_t, conv_t, sp, f16):
+    """Outside the timed region: the kernel that was timed against the flood path (a different implementation: two
+    kernels per turn, state in HBM, one codeword per lane) on a 1024-frame sample, at the metric's Eb/N0 (below the
+    waterfall nearly every frame fails, and a failed frame outputs the channel's hard decisions by the reference's
+    rule Orig.hs:70 -- so agreement there shows little) AND at a point in the waterfall, where the frames converge
+    at different turns: identical hard bits, iteration counts and flags, CRC32 of each printed."""
+    import zlib
+    import torch
+    n = min(1024, llr_t.shape[0])
+    k = ecc.message_length
+    flood_dtype = "f32" if args.dtype == "f16" else args.dtype     # fused-F16(llr) == F32 decoder on the fp16-rounded LLRs
+    variant = "min" if args.variant == "minsum" else "tanh"
+    out = {"sample_frames": n, "checked_against": "flood path (ldpc_ctx_create_ex path=LDPC_PATH_FLOOD)", "points": []}
+    try:
+        flood = E.Decoder(ecc.code, variant, flood_dtype, n, path="flood")
+    except E.LdpcError as e:
+        out["error"] = str(e)
+        return out
+    fb = torch.empty_like(bits[:n])
+    fi = torch.empty_like(iters_t[:n])
+    fc = torch.empty_like(conv_t[:n])
+    for db in (args.ebn0, args.ebn0 + 1.6):
+        sim.generate(args.seed, 1 << 40, n, db, llr_t.data_ptr(), msg_t.data_ptr(), sp, llr_f16=f16)
+        dec.decode_batch_dev(llr_t.data_ptr(), bits.data_ptr(), n, args.iters, iters_t.data_ptr(), conv_t.data_ptr(), sp, llr_f16=f16)
+        flood.decode_batch_dev(llr_t.data_ptr(), fb.data_ptr(), n, args.iters, fi.data_ptr(), fc.data_ptr(), sp, llr_f16=f16)
+        torch.cuda.synchronize()
+        b, it, cv = bits[:n].cpu().numpy(), iters_t[:n].cpu().numpy(), conv_t[:n].cpu().numpy()
+        raw = ((llr_t[:n, :k] > 0).to(torch.uint8) != msg_t[:n]).sum().item()
+        dec_err = (bits[:n, :k] != msg_t[:n]).sum().item()
+        out["points"].append({
+            "ebn0_db": db, "bits_equal": bool((bits[:n] == fb).all().item()), "iters_equal": bool((iters_t[:n] == fi).all().item()),
+            "converged_equal": bool((conv_t[:n] == fc).all().item()), "crc32_bits": zlib.crc32(b.tobytes()), "crc32_iters": zlib.crc32(it.tobytes()),
+            "converged_frac": round(float(cv.mean()), 4), "mean_iters": round(float(it.mean()), 2), "distinct_iteration_counts": int(len(set(it.tolist()))),
+            "channel_bit_errors": int(raw), "decoded_bit_errors": int(dec_err)})
+    flood.close()
+    out["ok"] = all(p["bits_equal"] and p["iters_equal"] and p["converged_equal"] for p in out["points"])
+    return out
 
 
 def host_cores():

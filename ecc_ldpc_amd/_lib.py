@@ -27,7 +27,7 @@ ABI_SYMBOLS = [
     "ldpc_decode_batch_f16", "ldpc_decode_batch_dev_f16", "ldpc_sim_generate_f16",
     "ldpc_debug_step", "ldpc_decode_trace",
     "ldpc_host_alloc", "ldpc_host_free",
-    "ldpc_ctx_set_timing", "ldpc_ctx_kernel_time", "ldpc_ctx_kernel_name",
+    "ldpc_ctx_set_timing", "ldpc_ctx_kernel_time", "ldpc_ctx_kernel_name", "ldpc_ctx_kernel_geometry",
     "ldpc_sim_create", "ldpc_sim_destroy", "ldpc_sim_generate", "ldpc_sim_tally", "ldpc_sim_encode_host",
     "ldpc_matrix_load", "ldpc_matrix_load_mackay", "ldpc_matrix_destroy", "ldpc_matrix_info", "ldpc_matrix_dense",
     "ldpc_matrix_qc_offsets", "ldpc_code_from_matrix",
@@ -115,9 +115,14 @@ def lib():
     if not os.path.exists(SO_PATH) and "LDPC_SO" not in os.environ:
         # a fresh checkout (built artefacts are not in git): compile the product, never substitute for it
         try:
+            import fcntl
             from . import build as _build
-            print(f"[ecc_ldpc_amd] {SO_PATH} missing: building it with hipcc", file=sys.stderr, flush=True)
-            _build.build(verbose=False)
+            # several ranks of one job may get here together on a fresh checkout: one builds, the others wait
+            with open(os.path.join(HERE, ".build.lock"), "w") as lock:
+                fcntl.flock(lock, fcntl.LOCK_EX)
+                if not os.path.exists(SO_PATH):
+                    print(f"[ecc_ldpc_amd] {SO_PATH} missing: building it with hipcc", file=sys.stderr, flush=True)
+                    _build.build(verbose=False)
         except Exception as e:
             raise ImportError(f"{SO_PATH} is missing and could not be built ({e}); run `python ecc_ldpc_amd/build.py` "
                               "(the HIP library is the only decode path; there is no fallback)") from e
@@ -165,6 +170,7 @@ def lib():
     L.ldpc_ctx_kernel_time.argtypes = [vp, ip, f64p]
     L.ldpc_ctx_kernel_name.restype = C.c_char_p
     L.ldpc_ctx_kernel_name.argtypes = [vp]
+    L.ldpc_ctx_kernel_geometry.argtypes = [vp, ip, ip]
     L.ldpc_sim_create.restype = vp
     L.ldpc_sim_create.argtypes = [vp, C.c_int, C.c_int, C.c_int, u8p, C.c_int]
     L.ldpc_sim_destroy.restype = None
@@ -401,6 +407,13 @@ class Decoder:
     @property
     def kernel_name(self):
         return lib().ldpc_ctx_kernel_name(self._h).decode()
+
+    @property
+    def kernel_geometry(self):
+        """-> (threads per workgroup, frames per workgroup) of the dominant kernel's last launch (0, 0: flood path)"""
+        t, f = C.c_int(), C.c_int()
+        check(lib().ldpc_ctx_kernel_geometry(self._h, C.byref(t), C.byref(f)))
+        return t.value, f.value
 
     def close(self):
         if self._h and self._owned:

@@ -41,7 +41,9 @@ def build(force: bool = False, verbose: bool = True) -> str:
         obj = os.path.join(objdir, s + ".o")
         objs.append(obj)
         if force or _stale(obj, [src] + hdrs):
-            cmd = [HIPCC] + FLAGS + ["-x", "hip", "-c", src, "-o", obj]
+            # -save-temps=obj keeps the device assembly (<stem>-hip-amdgcn-amd-amdhsa-gfx950.s) next to the object:
+            # the input of tools/isa_histogram.py (instruction histogram of the iteration loops -> build/isa_stats.json)
+            cmd = [HIPCC] + FLAGS + (["-save-temps=obj"] if s.endswith(".hip") else []) + ["-x", "hip", "-c", src, "-o", obj]
             if verbose:
                 print(" ".join(cmd), flush=True)
             procs.append((s, subprocess.Popen(cmd)))
@@ -53,6 +55,10 @@ def build(force: bool = False, verbose: bool = True) -> str:
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
+    isa_stats(objdir, force or bool(procs))
+    for f in os.listdir(objdir):   # the other -save-temps by-products are not needed by anything
+        if f.endswith((".bc", ".hipi", ".out", ".resolution.txt", ".hipfb")) or (f.endswith(".s") and "-host-" in f) or f.endswith("gfx950.o"):
+            os.remove(os.path.join(objdir, f))
     # the native command-line driver (host code only; binds the C ABI like any other C/C++ host would)
     cli_src = os.path.join(CSRC, "cli_main.cc")
     if force or _stale(CLI, [cli_src, OUT] + hdrs):
@@ -61,6 +67,29 @@ def build(force: bool = False, verbose: bool = True) -> str:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
     return OUT
+
+
+def isa_stats(objdir, force=False):
+    """build/isa_stats.json: per kernel, the instruction histogram of its iteration loop (tools/isa_histogram.py) --
+    what bench.py's VALU roofline multiplies by the iterations a run really executed."""
+    import glob
+    import importlib.util
+    import json
+    out = os.path.join(objdir, "isa_stats.json")
+    asm = sorted(glob.glob(os.path.join(objdir, "fused*-hip-amdgcn-amd-amdhsa-gfx950.s")))
+    if not asm or not (force or _stale(out, asm)):
+        return out
+    tool = os.path.join(HERE, "..", "tools", "isa_histogram.py")
+    if not os.path.exists(tool):
+        return out
+    spec = importlib.util.spec_from_file_location("isa_histogram", tool)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    res = mod.run(asm)
+    for r in res:
+        r["source"] = os.path.basename(r["source"])
+    json.dump(res, open(out, "w"), indent=1)
+    return out
 
 
 if __name__ == "__main__":

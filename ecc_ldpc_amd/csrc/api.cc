@@ -697,6 +697,15 @@ const char *ldpc_ctx_kernel_name(const ldpc_ctx *ctx) {
     return "flood_cn_kernel";
 }
 
+int ldpc_ctx_kernel_geometry(const ldpc_ctx *ctx, int *threads_per_workgroup, int *frames_per_workgroup) {
+    if (!ctx) return set_error(LDPC_EINVAL, "null ctx");
+    int t = 0, f = 0;
+    if (ctx->path == LDPC_PATH_FUSED && ctx->fused) { const ldpc::LaunchInfo &li = ldpc::fused_launch_info(*ctx->fused); t = li.threads; f = li.frames_per_wg; }
+    if (threads_per_workgroup) *threads_per_workgroup = t;
+    if (frames_per_workgroup) *frames_per_workgroup = f;
+    return LDPC_OK;
+}
+
 // ------------------------------------------------------------------------------- frame source
 }  // extern "C"
 struct ldpc_sim {

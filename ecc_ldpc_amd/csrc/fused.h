@@ -18,8 +18,10 @@ int fused_decode(FusedState &s, hipStream_t st, int max_iters, int batch, const 
 int fused_step(FusedState &s, hipStream_t st, int batch, const double *d_orig, const double *d_lam,
                const double *d_ne, double *d_ne_out, double *d_lam_out, uint8_t *d_syn);
 
-// name of the kernel fused_decode launches for this state (as rocprofv3 lists it, without template arguments)
+// name of the kernel fused_decode launches for this state (as rocprofv3 lists it; without template arguments before
+// the first launch, with the instance-selecting ones after it) and the geometry of that launch
 const char *fused_kernel_name(const FusedState &s);
+const LaunchInfo &fused_launch_info(const FusedState &s);
 // whether the kernel fused_decode launches reads every channel LLR from memory exactly once (then the LLRs may sit in
 // page-locked HOST memory and be read over PCIe by the kernel itself: api.cc zero-copy path)
 bool fused_reads_llr_once(const FusedState &s, int max_iters);
@@ -31,6 +33,7 @@ CsrState *fused_csr_create(const ldpc_code &code, int variant, int dtype);
 void fused_csr_destroy(CsrState *s);
 void fused_csr_set_timer(CsrState *s, KernelTimer *t);
 const char *fused_csr_kernel_name(const CsrState &s);
+const LaunchInfo &fused_csr_launch_info(const CsrState &s);
 void fused_csr_set_round16(CsrState *s, int on);  // LDPC_F16 context: LLRs count as stored in fp16
 int fused_csr_decode(CsrState &s, hipStream_t st, int max_iters, int batch, const void *d_llr, int llr_fmt, uint8_t *d_bits,
                      int32_t *d_iters, uint8_t *d_conv, double *d_final, double *d_trace);

@@ -60,8 +60,8 @@ __device__ __forceinline__ double rec_msg(double m1s, double m2s, uint32_t sgi, 
 template <typename CT, int D, int RPL, int HSTEP, bool SYNDROME_ONLY>
 __device__ __forceinline__ bool rows_phase_a(const char *lds, ctab_t tabrow, uint32_t p4, uint32_t vmask,
                                              CT *m1s, CT *m2s, uint32_t *sgi) {
-    constexpr uint32_t ES = sizeof(CT);
     asm volatile("" : "+v"(p4));
+    if constexpr (SYNDROME_ONLY) LDPC_COLD_PATH();
     CT l[RPL][D];
 #pragma unroll
     for (int k = 0; k < D; k++) {
@@ -136,7 +136,6 @@ __device__ __forceinline__ bool rows_phase_a(const char *lds, ctab_t tabrow, uin
 template <typename CT, int D, int RPL, int HSTEP>
 __device__ __forceinline__ void rows_phase_b(char *lds, ctab_t tabrow, uint32_t p4, uint32_t vmask,
                                              const CT *m1s, const CT *m2s, const uint32_t *sgi) {
-    constexpr uint32_t ES = sizeof(CT);
     asm volatile("" : "+v"(p4));
     uint32_t idx[RPL];
 #pragma unroll
@@ -238,6 +237,7 @@ __global__ __launch_bounds__((FusedCfg<CT, Plan, SZ>::THREADS), (FusedCfg<CT, Pl
     for (int n = 0;; n++) {
         if (!__any(active)) break;
         if (A.trace && active) {  // lam at the top of loop turn n
+            LDPC_COLD_PATH();
             static_for<0, Plan::NBC>([&](auto bcc) {
                 constexpr int bc = decltype(bcc)::value;
 #pragma unroll
@@ -350,6 +350,7 @@ struct FusedState {
     bool use_split = false;  // four waves per frame, block rows split between wave pairs (fused_split.hip)
     bool use_msg = true;  // per-edge-message kernel (fused_msg.hip) vs compressed-record kernel (this file)
     KernelTimer *timer = nullptr;
+    LaunchInfo info;
     uint32_t *d_tab = nullptr;
     std::vector<int32_t> row_ptr;  // host copy for the step-mode record conversion
 };
@@ -397,6 +398,10 @@ static int launch(FusedState &s, hipStream_t st, FusedArgs &a) {
     using Cfg = FusedCfg<CT, PlanAR4JA45, SZ>;
     const int grid = (a.batch + Cfg::CPW - 1) / Cfg::CPW;
     auto kern = fused_decode_kernel<CT, PlanAR4JA45, SZ>;
+    if (!a.step_mode) {
+        snprintf(s.info.name, sizeof(s.info.name), "ldpc::fused_decode_kernel<%s, ldpc::PlanAR4JA45, %d>", sizeof(CT) == 8 ? "double" : "float", SZ);
+        s.info.threads = Cfg::THREADS; s.info.frames_per_wg = Cfg::CPW;
+    }
     if (s.timer && !a.step_mode) s.timer->begin(st);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(Cfg::THREADS), 0, st, a);
     if (s.timer && !a.step_mode) s.timer->end(st);
@@ -486,7 +491,11 @@ bool fused_reads_llr_once(const FusedState &s, int max_iters) {
     return s.csr != nullptr || (s.use_split && max_iters <= kSplitMaxIters);
 }
 
+const LaunchInfo &fused_launch_info(const FusedState &s) { return s.csr ? fused_csr_launch_info(*s.csr) : s.info; }
+
 const char *fused_kernel_name(const FusedState &s) {
+    const LaunchInfo &li = fused_launch_info(s);
+    if (li.name[0]) return li.name;
     if (s.csr) return fused_csr_kernel_name(*s.csr);
     if (s.use_split) return "fused_split_kernel";
     if (s.use_msg) return "fused_msg_kernel";
@@ -500,8 +509,8 @@ int fused_decode(FusedState &s, hipStream_t st, int max_iters, int batch, const 
     a.tab = s.d_tab; a.llr = d_llr; a.llr_fmt = llr_fmt; a.llr_round16 = s.round16; a.bits = d_bits; a.iters = d_iters; a.conv = d_conv;
     a.final_lam = d_final; a.trace = d_trace; a.batch = batch; a.max_iters = max_iters; a.step_mode = 0;
     // (the split kernel packs a frame's result into one register: 9 bits for the turn it converged at)
-    if (s.use_split && max_iters <= kSplitMaxIters) return fused_split_launch(s.variant, s.sz, st, a, s.timer);
-    if (s.use_msg) return fused_msg_launch(s.variant, s.dtype, s.sz, s.static_id, st, a, s.timer);
+    if (s.use_split && max_iters <= kSplitMaxIters) return fused_split_launch(s.variant, s.sz, st, a, s.timer, &s.info);
+    if (s.use_msg) return fused_msg_launch(s.variant, s.dtype, s.sz, s.static_id, st, a, s.timer, &s.info);
     return dispatch(s, st, a);
 }
 
@@ -562,8 +571,8 @@ int fused_step(FusedState &s, hipStream_t st, int batch, const double *d_orig, c
         FusedArgs a{};
         a.tab = s.d_tab; a.llr = d_orig; a.llr_fmt = LLR_F64; a.llr_round16 = 0; a.batch = batch; a.max_iters = 1; a.step_mode = 1;
         a.st_lam = d_lam; a.st_ne_in = d_ne; a.st_ne_out = d_ne_out; a.final_lam = d_lam_out; a.st_syn = d_syn;
-        if (s.use_split) return fused_split_launch(s.variant, s.sz, st, a, nullptr);
-        return fused_msg_launch(s.variant, s.dtype, s.sz, s.static_id, st, a, nullptr);
+        if (s.use_split) return fused_split_launch(s.variant, s.sz, st, a, nullptr, nullptr);
+        return fused_msg_launch(s.variant, s.dtype, s.sz, s.static_id, st, a, nullptr, nullptr);
     }
     if (s.dtype == LDPC_F64) return step_typed<double>(s, st, batch, d_orig, d_lam, d_ne, d_ne_out, d_lam_out, d_syn);
     return step_typed<float>(s, st, batch, d_orig, d_lam, d_ne, d_ne_out, d_lam_out, d_syn);

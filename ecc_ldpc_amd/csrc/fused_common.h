@@ -104,11 +104,11 @@ struct FusedCfg {
 // launcher of the per-edge-message kernels (fused_msg.hip)
 bool fused_msg_has(int variant, int dtype, int sz);
 int fused_msg_static_id(int sz, const uint16_t *rot, const uint8_t *bc, int nedge);
-int fused_msg_launch(int variant, int dtype, int sz, int static_id, hipStream_t st, FusedArgs &a, KernelTimer *timer);
+int fused_msg_launch(int variant, int dtype, int sz, int static_id, hipStream_t st, FusedArgs &a, KernelTimer *timer, LaunchInfo *info);
 
 // four-wave variant with the block rows split between two wave pairs (fused_split.hip)
 bool fused_split_has(int variant, int dtype, int sz, int static_id);
-int fused_split_launch(int variant, int sz, hipStream_t st, FusedArgs &a, KernelTimer *timer);
+int fused_split_launch(int variant, int sz, hipStream_t st, FusedArgs &a, KernelTimer *timer, LaunchInfo *info);
 constexpr int kSplitMaxIters = 511;  // fused_split.hip result word: bits 23..31 hold the turn a frame converged at
 
 }  // namespace ldpc

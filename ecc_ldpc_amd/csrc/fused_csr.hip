@@ -124,8 +124,10 @@ __global__ __launch_bounds__(kCsrThreads) void fused_csr_kernel(CsrArgs A) {
     int n_done = 0;
     const int turns = A.step_mode ? 1 : A.max_iters;
     for (int n = 0;; n++) {
-        if (A.trace)
+        if (A.trace) {
+            LDPC_COLD_PATH();
             for (int c = tid; c < N; c += kCsrThreads) A.trace[((size_t)frame * (A.max_iters + 1) + n) * N + c] = (double)lam[c];
+        }
         const bool last = n >= turns;
         // ---- rows: syndrome + check-node update
         int unsat = 0;
@@ -275,8 +277,10 @@ __global__ __launch_bounds__(THREADS, (DMAX <= 8 ? (THREADS > 256 ? 6 : 4) : 1))
     int n_done = 0;
     const int turns = A.step_mode ? 1 : A.max_iters;
     for (int n = 0;; n++) {
-        if (A.trace)
+        if (A.trace) {
+            LDPC_COLD_PATH();
             for (int c = tid; c < N; c += THREADS) A.trace[((size_t)frame * (A.max_iters + 1) + n) * N + A.col_of_pos[c]] = (double)lam[c];
+        }
         const bool last = n >= turns;
         // ---- rows: every lam gather of the thread first, then syndrome + check-node updates out of registers
         CT l[RPT][DMAX];
@@ -381,6 +385,7 @@ struct CsrState {
     // batched kernel: the same tables in POSITION space (conflict-aware placement of rows and columns in LDS)
     int32_t *d_ell_b = nullptr, *d_csc_b = nullptr, *d_row_of_pos = nullptr, *d_col_of_pos = nullptr;
     KernelTimer *timer = nullptr;
+    LaunchInfo info;
 };
 
 static int pick_dmax(int maxdeg) { return maxdeg <= 4 ? 4 : maxdeg <= 8 ? 8 : maxdeg <= 20 ? 20 : maxdeg <= 32 ? 32 : 0; }
@@ -597,6 +602,7 @@ CsrState *fused_csr_create(const ldpc_code &c, int variant, int dtype) {
 }
 
 void fused_csr_set_timer(CsrState *s, KernelTimer *t) { if (s) s->timer = t; }
+const LaunchInfo &fused_csr_launch_info(const CsrState &s) { return s.info; }
 const char *fused_csr_kernel_name(const CsrState &s) {
     return (s.dtype == LDPC_F32 && s.d_ell_b && s.want_batched && batched_shape(s)) ? "fused_csr_batched_kernel" : "fused_csr_kernel";
 }
@@ -612,6 +618,10 @@ static int launch_csr(CsrState &s, hipStream_t st, CsrArgs &a) {
         if (e != hipSuccess) return set_error(LDPC_EHIP, "hipFuncSetAttribute(%zu B LDS): %s", lds, hipGetErrorString(e));
         attr_set = lds;
     }
+    if (!a.step_mode) {
+        snprintf(s.info.name, sizeof(s.info.name), "ldpc::fused_csr_kernel<%s, %d, %d, %d, %d>", sizeof(CT) == 8 ? "double" : "float", VARIANT, DMAX, RPT, CPT);
+        s.info.threads = kCsrThreads; s.info.frames_per_wg = 1;
+    }
     if (s.timer && !a.step_mode) s.timer->begin(st);
     hipLaunchKernelGGL(kern, dim3(a.batch), dim3(kCsrThreads), lds, st, a);
     if (s.timer && !a.step_mode) s.timer->end(st);
@@ -624,6 +634,10 @@ template <typename CT, int VARIANT, int DMAX, int RPT, int CPT, int CD, int THRE
 static int launch_csr_batched(CsrState &s, hipStream_t st, CsrArgs &a) {
     auto kern = fused_csr_batched_kernel<CT, VARIANT, DMAX, RPT, CPT, CD, THREADS>;
     const size_t lds = ((size_t)s.N + (size_t)DMAX * s.M + 2) * sizeof(CT);   // lam, messages, the +inf and 0 cells; <= 64 KB
+    if (!a.step_mode) {
+        snprintf(s.info.name, sizeof(s.info.name), "ldpc::fused_csr_batched_kernel<%s, %d, %d, %d, %d, %d, %d>", sizeof(CT) == 8 ? "double" : "float", VARIANT, DMAX, RPT, CPT, CD, THREADS);
+        s.info.threads = THREADS; s.info.frames_per_wg = 1;
+    }
     if (s.timer && !a.step_mode) s.timer->begin(st);
     hipLaunchKernelGGL(kern, dim3(a.batch), dim3(THREADS), lds, st, a);
     if (s.timer && !a.step_mode) s.timer->end(st);

@@ -12,6 +12,8 @@
 //            (Reference/Min.hs:75-86); tanh rule: ldpc_math.h cn_update (Reference/Orig.hs:81-92)
 //   phase B  lam[col] <- ne' + lam[col], block rows in descending order (Orig.hs:95-98)
 // Price: 200+ VGPRs -> 2 waves per SIMD.
+#include <stdio.h>
+
 #include "fused_rows.h"
 
 // LDPC_DBG: timing-only ablation builds (results are WRONG when non-zero; never shipped):
@@ -114,6 +116,7 @@ __global__ __launch_bounds__((MsgCfg<CT, VARIANT, Plan, SZ>::THREADS), (MsgCfg<C
     for (int n = 0;; n++) {
         if (!__any(active)) break;
         if (A.trace && active) {
+            LDPC_COLD_PATH();
             static_for<0, Plan::NBC>([&](auto bcc) {
                 constexpr int bc = decltype(bcc)::value;
 #pragma unroll
@@ -224,9 +227,14 @@ __global__ __launch_bounds__((MsgCfg<CT, VARIANT, Plan, SZ>::THREADS), (MsgCfg<C
 }
 
 template <typename CT, int VARIANT, int SZ, class Tab>
-static int launch_msg(hipStream_t st, FusedArgs &a, KernelTimer *timer) {
+static int launch_msg(hipStream_t st, FusedArgs &a, KernelTimer *timer, LaunchInfo *info) {
     using Cfg = MsgCfg<CT, VARIANT, PlanAR4JA45, SZ>;
     const int grid = (a.batch + Cfg::CPW - 1) / Cfg::CPW;
+    if (info && !a.step_mode) {
+        snprintf(info->name, sizeof(info->name), "ldpc::fused_msg_kernel<%s, %d, ldpc::PlanAR4JA45, %d, ldpc::%s", sizeof(CT) == 8 ? "double" : "float", VARIANT, SZ,
+                 std::is_same<Tab, DynTab>::value ? "DynTab" : "StatTab");
+        info->threads = Cfg::THREADS; info->frames_per_wg = Cfg::CPW;
+    }
     if (timer && !a.step_mode) timer->begin(st);
     hipLaunchKernelGGL((fused_msg_kernel<CT, VARIANT, PlanAR4JA45, SZ, Tab>), dim3(grid), dim3(Cfg::THREADS), 0, st, a);
     if (timer && !a.step_mode) timer->end(st);
@@ -255,19 +263,19 @@ int fused_msg_static_id(int sz, const uint16_t *rot, const uint8_t *bc, int nedg
     return 0;
 }
 
-int fused_msg_launch(int variant, int dtype, int sz, int static_id, hipStream_t st, FusedArgs &a, KernelTimer *timer) {
+int fused_msg_launch(int variant, int dtype, int sz, int static_id, hipStream_t st, FusedArgs &a, KernelTimer *timer, LaunchInfo *info) {
     // compile-time tables: f32 kernels of the shipped codes
     if (dtype == LDPC_F32 && static_id == 1 && sz == 32)
-        return variant == LDPC_MINSUM ? launch_msg<float, LDPC_V_MINSUM, 32, StatTab<TabJpl1024>>(st, a, timer)
-                                      : launch_msg<float, LDPC_V_TANH, 32, StatTab<TabJpl1024>>(st, a, timer);
+        return variant == LDPC_MINSUM ? launch_msg<float, LDPC_V_MINSUM, 32, StatTab<TabJpl1024>>(st, a, timer, info)
+                                      : launch_msg<float, LDPC_V_TANH, 32, StatTab<TabJpl1024>>(st, a, timer, info);
     if (dtype == LDPC_F32 && static_id == 2 && sz == 128)
-        return variant == LDPC_MINSUM ? launch_msg<float, LDPC_V_MINSUM, 128, StatTab<TabJpl4096>>(st, a, timer)
-                                      : launch_msg<float, LDPC_V_TANH, 128, StatTab<TabJpl4096>>(st, a, timer);
+        return variant == LDPC_MINSUM ? launch_msg<float, LDPC_V_MINSUM, 128, StatTab<TabJpl4096>>(st, a, timer, info)
+                                      : launch_msg<float, LDPC_V_TANH, 128, StatTab<TabJpl4096>>(st, a, timer, info);
 #define CASE_SZ(CT, V)                                                   \
     switch (sz) {                                                        \
-        case 32: return launch_msg<CT, V, 32, DynTab>(st, a, timer);     \
-        case 64: return launch_msg<CT, V, 64, DynTab>(st, a, timer);     \
-        case 128: return launch_msg<CT, V, 128, DynTab>(st, a, timer);   \
+        case 32: return launch_msg<CT, V, 32, DynTab>(st, a, timer, info);     \
+        case 64: return launch_msg<CT, V, 64, DynTab>(st, a, timer, info);     \
+        case 128: return launch_msg<CT, V, 128, DynTab>(st, a, timer, info);   \
     }
     if (variant == LDPC_MINSUM && dtype == LDPC_F32) { CASE_SZ(float, LDPC_V_MINSUM) }
     else if (variant == LDPC_MINSUM && dtype == LDPC_F64) { CASE_SZ(double, LDPC_V_MINSUM) }

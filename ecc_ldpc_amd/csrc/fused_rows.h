@@ -119,6 +119,7 @@ __device__ __forceinline__ uint32_t row_addr(uint32_t a0, uint32_t p4, uint32_t 
 template <typename CT, int VARIANT, int D, int RPL, int HSTEP, bool SYNDROME_ONLY, class Row>
 __device__ __forceinline__ bool rows_a(const char *lds, Row tabrow, uint32_t p4, uint32_t vmask, CT *msg) {
     asm volatile("" : "+v"(p4));  // keeps the loop-invariant address arithmetic inside the turn loop, row by row
+    if constexpr (SYNDROME_ONLY) LDPC_COLD_PATH();   // the one extra pass after the last update (Orig.hs:69-70)
     CT l[RPL][D];
     static_for<0, D>([&](auto kc) {
         constexpr int k = decltype(kc)::value;

@@ -16,6 +16,8 @@
 // in descending row order = Orig.hs:96 per column): in a round each pair adds the edges it owns; all
 // targets of a round are distinct columns; one s_barrier (4 waves) per round.  Even/odd ownership makes
 // consecutive contributions of a column alternate between the pairs, which balances the rounds.
+#include <stdio.h>
+
 #include "fused_rows.h"
 
 #ifndef SPLIT_ORIG_REGS
@@ -258,6 +260,7 @@ __device__ __forceinline__ void split_body(const FusedArgs &A, char *lds, const 
     for (int n = 0;; n++) {
         if (done == FULL) break;
         if (A.trace && !((done >> ((p4 / ES) % CPW)) & 1u)) {
+            LDPC_COLD_PATH();
             const Where w(p4, A.batch);
             static_for<0, Plan::NBC>([&](auto bcc) {
                 constexpr int bc = decltype(bcc)::value;
@@ -298,6 +301,7 @@ __device__ __forceinline__ void split_body(const FusedArgs &A, char *lds, const 
         } else {
             const uint32_t newly = ~fbits & ~done & FULL;  // Orig.hs:69: frames whose syndrome is zero now
             if ((newly >> ((p4 / ES) % CPW)) & 1u) {
+                LDPC_COLD_PATH();   // once per frame
                 res = (1u << 22) | ((uint32_t)n << 23);
                 static_for<0, Plan::NBC>([&](auto bcc) {
                     constexpr int bc = decltype(bcc)::value;
@@ -412,7 +416,12 @@ static void launch_split(hipStream_t st, FusedArgs &a) {
     hipLaunchKernelGGL((fused_split_kernel<float, VARIANT, PlanAR4JA45, SZ, T>), dim3(grid), dim3(G::THREADS), 0, st, a);
 }
 
-int fused_split_launch(int variant, int sz, hipStream_t st, FusedArgs &a, KernelTimer *timer) {
+int fused_split_launch(int variant, int sz, hipStream_t st, FusedArgs &a, KernelTimer *timer, LaunchInfo *info) {
+    if (info && !a.step_mode) {
+        snprintf(info->name, sizeof(info->name), "ldpc::fused_split_kernel<float, %d, ldpc::PlanAR4JA45, %d, ", variant == LDPC_MINSUM ? LDPC_V_MINSUM : LDPC_V_TANH, sz);
+        info->threads = sz == 128 ? SplitGeom<128>::THREADS : SplitGeom<32>::THREADS;
+        info->frames_per_wg = sz == 128 ? SplitGeom<128>::CPW : SplitGeom<32>::CPW;
+    }
     if (timer && !a.step_mode) timer->begin(st);
     if (sz == 128) {
         if (variant == LDPC_MINSUM) launch_split<LDPC_V_MINSUM, 128, TabJpl4096>(st, a);

@@ -65,6 +65,15 @@ struct KernelTimer {
     void destroy() { for (auto e : ev) (void)hipEventDestroy(e); ev.clear(); used = 0; }
 };
 
+// what the last decode launch of a context's dominant kernel was: its name as rocprofv3 / the assembly list it
+// (demangled, up to the template arguments that select the instance) and its launch geometry.  bench.py uses it to
+// look the kernel's instruction histogram up in build/isa_stats.json (tools/isa_histogram.py).
+struct LaunchInfo {
+    char name[192] = "";
+    int threads = 0;         // per workgroup
+    int frames_per_wg = 0;   // frames one workgroup decodes (0: not a frame-per-workgroup kernel)
+};
+
 struct FloodState {
     FloodDev dev;
     int variant, dtype;

@@ -23,6 +23,11 @@
 #include "internal.h"
 #include <type_traits>
 
+// Marks the enclosing basic block as a COLD side path of the iteration loop (syndrome-only last turn, convergence
+// snapshot, ...).  Emits only an assembler comment; tools/isa_histogram.py reads it from the compiler's .s output to
+// tell the ordinary turn of the loop from the rare ones when it counts instructions.
+#define LDPC_COLD_PATH() asm volatile("; ldpc.cold")
+
 #define LDPC_V_TANH 0
 #define LDPC_V_MINSUM 1
 

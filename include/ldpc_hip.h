@@ -172,8 +172,12 @@ int ldpc_decode_trace(ldpc_ctx *ctx, int max_iters, int batch, const double *llr
  * last call.  Blocks until the recorded launches have finished. */
 int ldpc_ctx_set_timing(ldpc_ctx *ctx, int enabled);
 int ldpc_ctx_kernel_time(ldpc_ctx *ctx, int *launches, double *total_ms);
-/* name of that kernel as it appears in a rocprofv3 kernel trace (substring) */
+/* name of that kernel as it appears in a rocprofv3 kernel trace (substring): the kernel family before the context's
+ * first decode, narrowed to the launched template instance after it */
 const char *ldpc_ctx_kernel_name(const ldpc_ctx *ctx);
+/* launch geometry of that kernel after the first decode (fused paths: threads per workgroup and frames one workgroup
+ * decodes; 0/0 for the flood path, whose kernels are not frame-per-workgroup) */
+int ldpc_ctx_kernel_geometry(const ldpc_ctx *ctx, int *threads_per_workgroup, int *frames_per_workgroup);
 
 /* ---- frame source and error tally for a BER / throughput harness -----------------------------------
  * The reference leaves message generation, BPSK + AWGN and BER statistics to the external tester

@@ -33,10 +33,20 @@ def test_one_json_line_with_roofline_and_cpu_baseline():
     assert KEYS <= set(d) and d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1
     assert d["unit"] == "Mbit/s" and d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
     assert d["dtype"] == "f32" and d["data"] == "synthetic" and "workload" in d["config"] and "model" not in d["config"]
+    # on-chip kernel: VALU-issue roofline from the build's own assembly x the iterations really run, 0 < frac <= 1
     r = d["roofline"]
-    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and r["launches"] == 2
-    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and r["kernel"] == "fused_split_kernel"
-    assert r["traffic"] is None or r["traffic"] > 0
+    assert r["bound"] == "valu" and r["peak"] == 1228.8 and r["launches"] == 2 and "fused_split_kernel<float, 1" in r["kernel"]
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and 0.2 < r["frac"] <= 1.0 and 0.2 < r["valu_pipe_busy_frac"] <= 1.0
+    assert r["frame_turns_timed"] == 2 * 2048 * 50 and 900 < r["valu_instr_per_wave_turn"] < 1100 and r["waves_per_frame"] == 4
+    assert r["traffic"] is None or (r["traffic"] > 0 and "committed" in r["traffic_source"])
+    # the contract's HBM byte model rides along, priced with the same iteration sum
+    h = d["roofline_hbm_model"]
+    assert h["bound"] == "hbm" and h["unit"] == "GB/s" and h["peak"] == 8000.0 and h["mean_iters_timed"] == 50.0
+    # the timed kernel against the flood path, below and inside the waterfall
+    w = d["proof_of_work"]
+    assert w["ok"] and len(w["points"]) == 2 and w["points"][1]["converged_frac"] > 0.5 and w["points"][1]["distinct_iteration_counts"] > 3
+    assert w["points"][1]["decoded_bit_errors"] < w["points"][1]["channel_bit_errors"] / 10
+    assert d["metric"] == "decoded info Mbit/s @ 50 BP iters, jpl.4096.4.5, Eb/N0=2 dB"
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["unit"] == "Mbit/s" and c["cores"] >= 1 and c["value"] > 0 and "frames" in c["sample"]
     assert d["value"] > 100 * c["value"]
@@ -50,3 +60,18 @@ def test_two_ranks_rehearsal_aggregates_over_ranks():
              env={"LDPC_BENCH_REHEARSE": "1"}, only_line=False)
     assert d["n_gpus"] == 2 and "rehearsal" in d and "cpu_baseline" not in d
     assert abs(d["value"] - 2 * 2 * 2048 * 4096 / (d["ms_per_step"] * 2e-3) / 1e6) / d["value"] < 0.02   # whole-job aggregate
+
+
+def test_early_exit_is_priced_by_the_iterations_run():
+    """4 dB: frames converge after a few turns; both roofline objects must price what ran, not max_iters."""
+    d = _run([sys.executable, "bench.py", "--steps", "2", "--warmup", "1", "--batch", "2048", "--cpu-seconds", "0", "--ebn0", "4"])
+    r, h = d["roofline"], d["roofline_hbm_model"]
+    assert d["metric"].endswith("Eb/N0=4 dB") and d["mean_iters"] < 10
+    assert r["frame_turns_timed"] < 2 * 2048 * 10 and 0 < r["frac"] <= 1.0
+    assert abs(h["mean_iters_timed"] - d["mean_iters"]) < 1.0
+
+
+def test_flood_path_reports_an_hbm_roofline():
+    d = _run([sys.executable, "bench.py", "--steps", "2", "--warmup", "1", "--batch", "2048", "--cpu-seconds", "0", "--path", "flood"])
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and "flood_cn" in r["kernel"] and 0 < r["frac"] <= 1.0 and d["proof_of_work"]["ok"]

@@ -49,7 +49,8 @@ def test_bpsk_ber_at_0db_matches_notes_txt(hip):
     torch.cuda.synchronize()
     frames, _, bit_errors, sum_iters = tally.tolist()
     assert frames == F and sum_iters == 0
-    assert (llr[:, :1408] != 0).all() and llr.shape[1] == 1408     # nothing punctured
+    # nothing punctured (a punctured position is LLR 0.0 in every frame; an fp32 sample may hit 0.0 once in ~10^7)
+    assert llr.shape[1] == 1408 and int((llr == 0).sum(dim=0).max().item()) <= 2
     n = F * k
     ber = bit_errors / n
     theory = q(math.sqrt(2.0 * 1024 / 1408))

@@ -16,8 +16,14 @@
  *   src/ECC/Code/LDPC/Reference/Orig.hs:58-98   ldpc / loop / ans / ne' / lam'  (tanh rule)
  *   src/ECC/Code/LDPC/Reference/Min.hs:54-104   same loop, (-3/4) * foldr1 min' (min-sum)
  *   src/ECC/Code/LDPC/Utils.hs:113-117          atanh' clamp 18.714973875118524
+ *   src/ECC/Code/LDPC/Fast/CachedMult.hs:25-56,233-264   StableDiv / lit / smult / sdiv and the `arraylet-cm` loop
+ *       (variant ORACLE_TANH_CM: same real function as the tanh rule, different roundings -- the row product is
+ *        kept as (factor closest to zero, product of the others) and the leave-one-out value comes from a division;
+ *        the column sum is orig + foldr1 (+) instead of foldr (+) orig)
  *   ecc-manifold ECC.Types.hard (absent); restated in-tree at
  *   src/ECC/Code/LDPC/GPU/Reference.hs:59-60    hard x = x > 0
+ * Extension WITHOUT a reference counterpart (BASELINE.json configs[4]): oracle_decode_layered below -- a
+ * row-layered schedule of the same check rules with its own stopping rule; it is its own specification.
  * Third-party arithmetic the Haskell relies on (not under /root/reference):
  *   base-4.9.1.0 (GHC 8.0.2; stack.yaml:1 resolver lts-8.14), GHC.Float instance Floating Double:
  *     tanh  = C libm tanh;   atanh x = 0.5 * log ((1.0+x) / (1.0-x));   product = left fold from 1
@@ -34,6 +40,7 @@
 
 #define ORACLE_TANH 0
 #define ORACLE_MINSUM 1
+#define ORACLE_TANH_CM 2 /* the reference's `arraylet-cm` numerics (Fast/CachedMult.hs), sparse form only */
 
 #define ORACLE_OK 0
 #define ORACLE_EARG (-1)
@@ -187,6 +194,29 @@ static int step_sparse(const graph_t *g, int variant, const double *orig, const 
                 for (int j = 0; j < d; j++) if (j != k) prod = prod * tbuf[j];
                 ne2[b + k] = -2.0 * atanh_clamped(prod);
             }
+        } else if (variant == ORACLE_TANH_CM) {
+            /* CachedMult.hs:247-259: ne_tanh'mat, then per row  foldr1 smult [lit x | ascending block column]
+             * (foldColsMatrixletU, :184-188), then ne' = -2 * atanh' (S `sdiv` x) */
+            if (d == 0) continue;
+            for (int k = 0; k < d; k++) tbuf[k] = tanh(-((lam[g->col_idx[b + k]] - ne[b + k]) / 2.0));
+            double sa, sb;   /* StableDiv (a, b): a = factor closest to zero, b = product of the rest (:25-29) */
+            {   /* lit (:41-44): x >= 1 -> (1, x) else (x, 1) */
+                double x = tbuf[d - 1];
+                if (x >= 1.0) { sa = 1.0; sb = x; } else { sa = x; sb = 1.0; }
+            }
+            for (int k = d - 2; k >= 0; k--) {   /* smult (lit x_k) acc  (:46-50): (a,b) = lit x_k, (c,d) = acc */
+                double x = tbuf[k], a, bq;
+                if (x >= 1.0) { a = 1.0; bq = x; } else { a = x; bq = 1.0; }
+                double mn, mx;                      /* absMinMax a c (:31-34): abs a < abs c -> (a, c) else (c, a) */
+                if (fabs(a) < fabs(sa)) { mn = a; mx = sa; } else { mn = sa; mx = a; }
+                sb = (bq * mx) * sb;                /* b * maxOfMins * d, left-associated */
+                sa = mn;
+            }
+            for (int k = 0; k < d; k++) {           /* sdiv (:52-55) */
+                double c = tbuf[k];
+                double q = (sa == c) ? sb : sa * (sb / c);
+                ne2[b + k] = -2.0 * atanh_clamped(q);
+            }
         } else {
             if (d < 2) { if (d == 1) return ORACLE_EDEGREE; continue; }
             for (int k = 0; k < d; k++) tbuf[k] = -(lam[g->col_idx[b + k]] - ne[b + k]);
@@ -198,8 +228,18 @@ static int step_sparse(const graph_t *g, int variant, const double *orig, const 
         }
     }
     for (int j = 0; j < g->N; j++) {
+        const int q0 = g->col_ptr[j], q1 = g->col_ptr[j + 1];
+        if (variant == ORACLE_TANH_CM) {
+            /* CachedMult.hs:261-262  lam' = zipWith (+) orig_lam (foldRowsMatrixlet (+) ne'): per column
+             * foldr1 (+) over ascending block rows (:190-194), THEN orig + that ("assumes one value on every column") */
+            if (q1 == q0) { lam2[j] = orig[j]; continue; }
+            double acc = ne2[g->csc_edge[q1 - 1]];
+            for (int q = q1 - 2; q >= q0; q--) acc = ne2[g->csc_edge[q]] + acc;
+            lam2[j] = orig[j] + acc;
+            continue;
+        }
         double acc = orig[j];
-        for (int q = g->col_ptr[j + 1] - 1; q >= g->col_ptr[j]; q--) acc = ne2[g->csc_edge[q]] + acc;
+        for (int q = q1 - 1; q >= q0; q--) acc = ne2[g->csc_edge[q]] + acc;
         lam2[j] = acc;
     }
     return ORACLE_OK;
@@ -248,6 +288,106 @@ int oracle_decode(int M, int N, const int32_t *row_ptr, const int32_t *col_idx, 
             free(work);
         }
     }
+    graph_free(&g);
+    return rc;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * EXTENSION (no reference counterpart; BASELINE.json configs[4] "layered min-sum + early termination").
+ * Row-layered schedule of the same check rules.  Rows are partitioned into layers [layer_ptr[l], layer_ptr[l+1]);
+ * the rows of one layer must not share a column (for a quasi-cyclic H with at most one circulant per block: a layer
+ * = one block row), so the order inside a layer is immaterial.  Specification:
+ *     lam <- orig ; msg <- 0
+ *     if syndrome(hard lam) == 0: return lam, 0 sweeps                        (as Orig.hs:69 at n = 0)
+ *     sweep n = 1, 2, ...:  if n > max_iters: return ORIG (not converged)       (as Orig.hs:70)
+ *        for every layer, for every row m of it, with c_k its columns in ascending order:
+ *           t_k    = lam[c_k] - msg[m,k]
+ *           odd   |= XOR_k hard(lam[c_k])                 (parity of the decisions this row saw)
+ *           msg'   = the flooding check rule applied to t  ((-3/4) foldr1 min' / -2 atanh' prod: same formulas)
+ *           new_k  = t_k + msg'[m,k] ;  flip |= hard(new_k) /= hard(lam[c_k]) ;  lam[c_k] <- new_k ; msg[m,k] <- msg'
+ *        if not odd and not flip: return lam, n sweeps     (no decision changed during the sweep and every check it
+ *                                                           saw was satisfied => hard lam is a codeword)
+ * trace_lam: NULL or (max_iters+1) x N: lam after sweep n at row n (row 0 = orig).
+ * ---------------------------------------------------------------------------------------- */
+int oracle_decode_layered(int M, int N, const int32_t *row_ptr, const int32_t *col_idx, int n_layers,
+                          const int32_t *layer_ptr, int variant, int max_iters, const double *orig_lam, uint8_t *bits,
+                          int *iters_out, int *converged_out, double *final_lam, double *trace_lam) {
+    if (M <= 0 || N <= 0 || !row_ptr || !col_idx || !orig_lam || !bits || max_iters < 0 || n_layers <= 0 || !layer_ptr ||
+        layer_ptr[0] != 0 || layer_ptr[n_layers] != M || !(variant == ORACLE_TANH || variant == ORACLE_MINSUM))
+        return ORACLE_EARG;
+    graph_t g;
+    int rc = graph_build(&g, M, N, row_ptr, col_idx);
+    if (rc != ORACLE_OK) { graph_free(&g); return rc; }
+    /* layers must be column-disjoint */
+    int32_t *seen = malloc(sizeof(int32_t) * (size_t)N);
+    double *msg = calloc((size_t)(g.E > 0 ? g.E : 1), sizeof(double)), *lam = malloc(sizeof(double) * (size_t)N);
+    if (!seen || !msg || !lam) { free(seen); free(msg); free(lam); graph_free(&g); return ORACLE_ENOMEM; }
+    for (int j = 0; j < N; j++) seen[j] = -1;
+    for (int l = 0; l < n_layers && rc == ORACLE_OK; l++) {
+        if (layer_ptr[l + 1] < layer_ptr[l]) { rc = ORACLE_EARG; break; }
+        for (int m = layer_ptr[l]; m < layer_ptr[l + 1]; m++)
+            for (int e = row_ptr[m]; e < row_ptr[m + 1]; e++) {
+                if (seen[col_idx[e]] == l) { rc = ORACLE_EARG; break; }
+                seen[col_idx[e]] = l;
+            }
+    }
+    free(seen);
+    double t[4096], x[4096];
+    int n = 0, conv = 0;
+    const double *result = orig_lam;
+    if (rc == ORACLE_OK) {
+        memcpy(lam, orig_lam, sizeof(double) * (size_t)N);
+        if (trace_lam) memcpy(trace_lam, lam, sizeof(double) * (size_t)N);
+        if (syndrome_zero(&g, lam)) { conv = 1; result = lam; }
+        else for (;;) {
+            if (n >= max_iters) { conv = 0; result = orig_lam; break; }
+            int odd = 0, flip = 0;
+            for (int m = 0; m < M && rc == ORACLE_OK; m++) {   /* layers are contiguous row ranges in ascending order */
+                const int b = row_ptr[m], d = row_ptr[m + 1] - b;
+                if (d > 4096) { rc = ORACLE_EARG; break; }
+                int par = 0;
+                for (int k = 0; k < d; k++) {
+                    const double l = lam[col_idx[b + k]];
+                    par ^= hard(l);
+                    t[k] = l - msg[b + k];
+                }
+                odd |= par;
+                if (variant == ORACLE_TANH) {
+                    for (int k = 0; k < d; k++) x[k] = tanh(-(t[k] / 2.0));
+                    for (int k = 0; k < d; k++) {
+                        double prod = 1.0;
+                        for (int j = 0; j < d; j++) if (j != k) prod = prod * x[j];
+                        msg[b + k] = -2.0 * atanh_clamped(prod);
+                    }
+                } else {
+                    if (d == 1) { rc = ORACLE_EDEGREE; break; }
+                    for (int k = 0; k < d; k++) x[k] = -t[k];
+                    for (int k = 0; k < d; k++) {
+                        int have = 0; double acc = 0.0;
+                        for (int j = d - 1; j >= 0; j--) if (j != k) { acc = have ? min_prime(x[j], acc) : x[j]; have = 1; }
+                        msg[b + k] = (-3.0 / 4.0) * acc;
+                    }
+                }
+                for (int k = 0; k < d; k++) {
+                    const int c = col_idx[b + k];
+                    const double nw = t[k] + msg[b + k];
+                    flip |= hard(nw) != hard(lam[c]);
+                    lam[c] = nw;
+                }
+            }
+            if (rc != ORACLE_OK) break;
+            n++;
+            if (trace_lam) memcpy(trace_lam + (size_t)n * N, lam, sizeof(double) * (size_t)N);
+            if (!odd && !flip) { conv = 1; result = lam; break; }
+        }
+    }
+    if (rc == ORACLE_OK) {
+        for (int j = 0; j < N; j++) bits[j] = (uint8_t)hard(result[j]);
+        if (final_lam) memcpy(final_lam, result, sizeof(double) * (size_t)N);
+        if (iters_out) *iters_out = n;
+        if (converged_out) *converged_out = conv;
+    }
+    free(msg); free(lam);
     graph_free(&g);
     return rc;
 }

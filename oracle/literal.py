@@ -88,3 +88,124 @@ def ldpc(H: np.ndarray, variant: str, max_iterations: int, orig_lam, trace=None)
             lam2[j] = acc
         ne, lam = ne2, lam2
         n += 1
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# `arraylet-cm` (src/ECC/Code/LDPC/Fast/CachedMult.hs): the tanh rule with the row product cached as a StableDiv
+def _lit(x):                       # CachedMult.hs:41-44
+    return (1.0, x) if x >= 1 else (x, 1.0)
+
+
+def _abs_min_max(x, y):            # :31-34
+    return (x, y) if abs(x) < abs(y) else (y, x)
+
+
+def _smult(p, q):                  # :46-50
+    (a, b), (c, d) = p, q
+    mn, mx = _abs_min_max(a, c)
+    return (mn, b * mx * d)
+
+
+def _sdiv(p, c):                   # :52-55
+    a, b = p
+    return b if a == c else a * (b / c)
+
+
+def ldpc_cm(sz: int, offsets: np.ndarray, max_iterations: int, orig_lam, trace=None):
+    """CachedMult.hs:233-264 over the Matrixlet of a quasi-cyclic H (offsets[br][bc] = rotation or -1), written the
+    way the Haskell folds run: per block row a foldr1 over its non-empty blocks in ascending block column of
+    element-wise smult (:184-188), per block column a foldr1 (+) over ascending block rows (:190-194)."""
+    R, Cb = offsets.shape
+    N = Cb * sz
+    orig = [float(v) for v in orig_lam]
+    lam = list(orig)
+    ne = {(br, bc): [0.0] * sz for br in range(R) for bc in range(Cb) if offsets[br, bc] >= 0}   # indexed by row r'
+    col = lambda bc, br, r: bc * sz + (r + int(offsets[br, bc])) % sz                             # :84 arrayArraylet
+    n = 0
+    while True:
+        if trace is not None:
+            trace.append(list(lam))
+        ok = True
+        for br in range(R):                       # ans (:244-245): foldr1 (zipWith (/=)) over the row's blocks
+            blocks = [bc for bc in range(Cb) if offsets[br, bc] >= 0]
+            for r in range(sz):
+                p = False
+                for bc in blocks:
+                    p ^= hard(lam[col(bc, br, r)])
+                ok = ok and not p
+        if ok:
+            return np.array([hard(v) for v in lam], np.uint8), n, True
+        if n >= max_iterations:
+            return np.array([hard(v) for v in orig], np.uint8), n, False
+        th = {k: [math.tanh(-((lam[col(k[1], k[0], r)] - v[r]) / 2)) for r in range(sz)] for k, v in ne.items()}   # :247-251
+        ne2 = {}
+        for br in range(R):
+            blocks = [bc for bc in range(Cb) if offsets[br, bc] >= 0]
+            for r in range(sz):
+                acc = _lit(th[(br, blocks[-1])][r])
+                for bc in reversed(blocks[:-1]):                       # foldr1: l1 `smult` (l2 `smult` (... ld))
+                    acc = _smult(_lit(th[(br, bc)][r]), acc)
+                for bc in blocks:                                      # :256-259
+                    ne2.setdefault((br, bc), [0.0] * sz)[r] = -2 * atanh_prime(_sdiv(acc, th[(br, bc)][r]))
+        lam2 = list(orig)
+        for bc in range(Cb):
+            rows = [br for br in range(R) if offsets[br, bc] >= 0]
+            for c in range(sz):                                        # foldRowsArraylet: column c <- row (c - off) mod sz
+                vals = [ne2[(br, bc)][(c - int(offsets[br, bc])) % sz] for br in rows]
+                acc = vals[-1]
+                for v in reversed(vals[:-1]):
+                    acc = v + acc
+                lam2[bc * sz + c] = orig[bc * sz + c] + acc            # :261-262 zipWith (+) orig_lam
+        ne, lam, n = ne2, lam2, n + 1
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# EXTENSION (no reference counterpart): the row-layered schedule specified at oracle_decode_layered in ldpc_oracle.c
+def ldpc_layered(H: np.ndarray, layer_ptr, variant: str, max_iterations: int, orig_lam, trace=None):
+    M, N = H.shape
+    rows = [list(np.nonzero(H[m])[0]) for m in range(M)]
+    orig = [float(v) for v in orig_lam]
+    lam = list(orig)
+    msg = [[0.0] * len(rows[m]) for m in range(M)]
+    if trace is not None:
+        trace.append(list(lam))
+    if all(sum(hard(lam[j]) for j in rows[m]) % 2 == 0 for m in range(M)):
+        return np.array([hard(v) for v in lam], np.uint8), 0, True
+    n = 0
+    while True:
+        if n >= max_iterations:
+            return np.array([hard(v) for v in orig], np.uint8), n, False
+        odd = flip = False
+        for l in range(len(layer_ptr) - 1):
+            for m in range(layer_ptr[l], layer_ptr[l + 1]):
+                cs = rows[m]
+                t = [lam[c] - msg[m][k] for k, c in enumerate(cs)]
+                odd = odd or (sum(hard(lam[c]) for c in cs) % 2 == 1)
+                if variant == "tanh":
+                    x = [math.tanh(-(v / 2)) for v in t]
+                    new = []
+                    for k in range(len(cs)):
+                        prod = 1.0
+                        for j in range(len(cs)):
+                            if j != k:
+                                prod = prod * x[j]
+                        new.append(-2 * atanh_prime(prod))
+                else:
+                    x = [-v for v in t]
+                    new = []
+                    for k in range(len(cs)):
+                        others = [x[j] for j in range(len(cs)) if j != k]
+                        acc = others[-1]
+                        for v in reversed(others[:-1]):
+                            acc = min_prime(v, acc)
+                        new.append((-3 / 4) * acc)
+                for k, c in enumerate(cs):
+                    nw = t[k] + new[k]
+                    flip = flip or (hard(nw) != hard(lam[c]))
+                    lam[c] = nw
+                    msg[m][k] = new[k]
+        n += 1
+        if trace is not None:
+            trace.append(list(lam))
+        if not odd and not flip:
+            return np.array([hard(v) for v in lam], np.uint8), n, True

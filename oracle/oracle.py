@@ -10,7 +10,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "_build", "libldpc_oracle.so")
-TANH, MINSUM = 0, 1
+TANH, MINSUM, TANH_CM = 0, 1, 2
 _lib = None
 
 
@@ -33,6 +33,7 @@ def lib():
         L.oracle_decode_dense.argtypes = [C.c_int, C.c_int, u8p, C.c_int, C.c_int, f64p, u8p, ip, ip, f64p]
         L.oracle_step.argtypes = [C.c_int, C.c_int, i32p, i32p, C.c_int, f64p, f64p, f64p, f64p, f64p, ip]
         L.oracle_decode_batch.argtypes = [C.c_int, C.c_int, i32p, i32p, C.c_int, C.c_int, C.c_int, f64p, u8p, i32p, u8p, C.c_int]
+        L.oracle_decode_layered.argtypes = [C.c_int, C.c_int, i32p, i32p, C.c_int, i32p, C.c_int, C.c_int, f64p, u8p, ip, ip, f64p, f64p]
         L.oracle_encode_dense.argtypes = [C.c_int, C.c_int, u8p, u8p, u8p]
         L.oracle_encode_qc.argtypes = [C.c_int, C.c_int, C.c_int, u8p, u8p, u8p]
         _lib = L
@@ -48,6 +49,8 @@ def _variant(v):
         return TANH
     if v in (MINSUM, "min", "minsum", "min-sum"):
         return MINSUM
+    if v in (TANH_CM, "cm", "tanh-cm", "arraylet-cm"):
+        return TANH_CM
     raise ValueError(v)
 
 
@@ -84,6 +87,26 @@ def decode(g: Graph, variant, max_iters, llr, trace=False):
     if trace:
         out["trace_lam"] = tl[: it.value + 1]
         out["trace_ne"] = tn[: it.value]
+    return out
+
+
+def decode_layered(g: Graph, layer_ptr, variant, max_iters, llr, trace=False):
+    """EXTENSION (no reference counterpart): row-layered schedule, rows [layer_ptr[l], layer_ptr[l+1]) form layer l.
+    -> dict(bits, iters (sweeps), converged, lam[, trace_lam (iters+1, N): lam after each sweep, row 0 = the input])"""
+    llr = np.ascontiguousarray(llr, dtype=np.float64)
+    lp = np.ascontiguousarray(layer_ptr, dtype=np.int32)
+    bits = np.zeros(g.N, np.uint8)
+    it, cv = C.c_int(0), C.c_int(0)
+    lam = np.zeros(g.N, np.float64)
+    tl = np.zeros((max_iters + 1, g.N), np.float64) if trace else None
+    rc = lib().oracle_decode_layered(g.M, g.N, _p(g.row_ptr, C.c_int32), _p(g.col_idx, C.c_int32), len(lp) - 1, _p(lp, C.c_int32),
+                                     _variant(variant), int(max_iters), _p(llr, C.c_double), _p(bits, C.c_uint8), C.byref(it), C.byref(cv),
+                                     _p(lam, C.c_double), _p(tl, C.c_double))
+    if rc != 0:
+        raise RuntimeError(f"oracle_decode_layered rc={rc}")
+    out = dict(bits=bits, iters=it.value, converged=bool(cv.value), lam=lam)
+    if trace:
+        out["trace_lam"] = tl[: it.value + 1]
     return out
 
 

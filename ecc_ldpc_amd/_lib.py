@@ -27,7 +27,7 @@ ABI_SYMBOLS = [
     "ldpc_decode_batch_f16", "ldpc_decode_batch_dev_f16", "ldpc_sim_generate_f16",
     "ldpc_debug_step", "ldpc_decode_trace",
     "ldpc_host_alloc", "ldpc_host_free",
-    "ldpc_ctx_set_timing", "ldpc_ctx_kernel_time", "ldpc_ctx_kernel_name", "ldpc_ctx_kernel_geometry",
+    "ldpc_ctx_set_timing", "ldpc_ctx_kernel_time", "ldpc_ctx_kernel_name", "ldpc_ctx_kernel_geometry", "ldpc_jit_cache_dir", "ldpc_jit_source", "ldpc_jit_prepare",
     "ldpc_sim_create", "ldpc_sim_destroy", "ldpc_sim_generate", "ldpc_sim_tally", "ldpc_sim_encode_host",
     "ldpc_matrix_load", "ldpc_matrix_load_mackay", "ldpc_matrix_destroy", "ldpc_matrix_info", "ldpc_matrix_dense",
     "ldpc_matrix_qc_offsets", "ldpc_code_from_matrix",
@@ -171,6 +171,10 @@ def lib():
     L.ldpc_ctx_kernel_name.restype = C.c_char_p
     L.ldpc_ctx_kernel_name.argtypes = [vp]
     L.ldpc_ctx_kernel_geometry.argtypes = [vp, ip, ip]
+    L.ldpc_jit_cache_dir.restype = C.c_char_p
+    L.ldpc_jit_source.restype = C.c_long
+    L.ldpc_jit_source.argtypes = [vp, C.c_int, C.c_int, C.c_char_p, C.c_size_t]
+    L.ldpc_jit_prepare.argtypes = [vp, C.c_int, C.c_int, C.c_char_p, C.c_size_t, ip, f64p]
     L.ldpc_sim_create.restype = vp
     L.ldpc_sim_create.argtypes = [vp, C.c_int, C.c_int, C.c_int, u8p, C.c_int]
     L.ldpc_sim_destroy.restype = None
@@ -298,6 +302,22 @@ class Code:
         ci = np.zeros(self.E, np.int32)
         check(lib().ldpc_code_csr(self._h, ptr(rp, C.c_int32), ptr(ci, C.c_int32)))
         return rp, ci
+
+    def jit_source(self, variant="min", dtype="f32") -> str:
+        """the translation unit the run-time compiler would be given for this code (LdpcError -5 if there is none)"""
+        n = lib().ldpc_jit_source(self._h, _VARIANTS[variant], _DTYPES[dtype], None, 0)
+        if n < 0:
+            raise LdpcError(int(n), last_error())
+        buf = C.create_string_buffer(n + 1)
+        lib().ldpc_jit_source(self._h, _VARIANTS[variant], _DTYPES[dtype], buf, n + 1)
+        return buf.value.decode()
+
+    def jit_prepare(self, variant="min", dtype="f32"):
+        """compile this code's specialised kernel into the disk cache (no GPU needed) -> (kernel name, from_cache, seconds)"""
+        name = C.create_string_buffer(128)
+        fc, sec = C.c_int(), C.c_double()
+        check(lib().ldpc_jit_prepare(self._h, _VARIANTS[variant], _DTYPES[dtype], name, 128, C.byref(fc), C.byref(sec)))
+        return name.value.decode(), bool(fc.value), sec.value
 
     @classmethod
     def from_matrix(cls, matrix: "Matrix"):

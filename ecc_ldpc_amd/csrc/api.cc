@@ -10,6 +10,7 @@
 
 #include "internal.h"
 #include "fused.h"
+#include "jit.h"
 #include "sim.h"
 
 namespace ldpc {
@@ -704,6 +705,39 @@ int ldpc_ctx_kernel_geometry(const ldpc_ctx *ctx, int *threads_per_workgroup, in
     if (threads_per_workgroup) *threads_per_workgroup = t;
     if (frames_per_workgroup) *frames_per_workgroup = f;
     return LDPC_OK;
+}
+
+// ------------------------------------------------------------------------------- run-time specialised kernels
+const char *ldpc_jit_cache_dir(void) { return ldpc::jit_cache_dir(); }
+
+long ldpc_jit_source(const ldpc_code *code, int variant, int dtype, char *buf, size_t cap) {
+    if (!code) return set_error(LDPC_EINVAL, "null code");
+    try {
+        const char *why = ldpc::jit_split_why_not(*code, variant, dtype);
+        if (why) return set_error(LDPC_EUNSUPPORTED, "%s", why);
+        const std::string src = ldpc::jit_split_source(*code, variant, dtype, nullptr);
+        if (buf && cap) { size_t n = std::min(cap - 1, src.size()); memcpy(buf, src.data(), n); buf[n] = 0; }
+        return (long)src.size();
+    } catch (...) { return set_error(LDPC_ENOMEM, "out of host memory"); }
+}
+
+int ldpc_jit_prepare(const ldpc_code *code, int variant, int dtype, char *kernel_name, size_t cap, int *from_cache, double *seconds) {
+    if (!code) return set_error(LDPC_EINVAL, "null code");
+    try {
+        const char *why = ldpc::jit_split_why_not(*code, variant, dtype);
+        if (why) return set_error(LDPC_EUNSUPPORTED, "%s", why);
+        ldpc::JitKernel g;
+        const std::string src = ldpc::jit_split_source(*code, variant, dtype, &g);
+        std::vector<char> co;
+        bool fc = false;
+        double sec = 0;
+        int rc = ldpc::jit_compile_cached(src, g.name, co, &fc, &sec);
+        if (rc != LDPC_OK) return rc;
+        if (kernel_name && cap) snprintf(kernel_name, cap, "%s", g.name.c_str());
+        if (from_cache) *from_cache = fc ? 1 : 0;
+        if (seconds) *seconds = sec;
+        return LDPC_OK;
+    } catch (...) { return set_error(LDPC_ENOMEM, "out of host memory"); }
 }
 
 // ------------------------------------------------------------------------------- frame source

@@ -39,6 +39,7 @@
 #include "fused.h"
 #include "ldpc_math.h"
 #include "fused_common.h"
+#include "jit.h"
 
 namespace ldpc {
 
@@ -346,6 +347,7 @@ struct FusedState {
     int variant = 0, dtype = 0, max_batch = 0, sz = 0, M = 0, N = 0, E = 0;  // dtype: the COMPUTE type (f32/f64)
     int round16 = 0;          // LDPC_F16 context: fp16 channel LLRs, f32 state (nothing else of a fused decode lives in HBM)
     CsrState *csr = nullptr;  // set when the code has no QC plan: generic on-chip kernel (fused_csr.hip)
+    JitKernel *jit = nullptr; // run-time specialised split kernel (jit.cc): any single-circulant QC code without a built-in instance
     int static_id = 0;    // compiled-in rotation table matching this code (0 = none: table-driven kernel)
     bool use_split = false;  // four waves per frame, block rows split between wave pairs (fused_split.hip)
     bool use_msg = true;  // per-edge-message kernel (fused_msg.hip) vs compressed-record kernel (this file)
@@ -382,10 +384,12 @@ const char *fused_why_not(const ldpc_code &c, int variant, int dtype) {
     dtype = compute_dtype(dtype);
     const char *p = plan_why_not(c, variant, dtype);
     if (!p) return nullptr;
+    const char *j = jit_split_why_not(c, variant, dtype);
+    if (!j) return nullptr;
     const char *g = fused_csr_why_not(c, variant, dtype);
     if (!g) return nullptr;
-    static thread_local char buf[400];
-    snprintf(buf, sizeof(buf), "QC-plan kernel: %s; generic on-chip kernel: %s", p, g);
+    static thread_local char buf[600];
+    snprintf(buf, sizeof(buf), "built-in QC kernel: %s; run-time specialised QC kernel: %s; generic on-chip kernel: %s", p, j, g);
     return buf;
 }
 bool fused_supported(const ldpc_code &c, int variant, int dtype) { return fused_why_not(c, variant, dtype) == nullptr; }
@@ -435,13 +439,47 @@ FusedState *fused_create(const ldpc_code &c, int variant, int dtype, int max_bat
     s->round16 = dtype == LDPC_F16;
     dtype = compute_dtype(dtype);
     s->variant = variant; s->dtype = dtype; s->max_batch = max_batch; s->sz = c.sz; s->M = c.M; s->N = c.N; s->E = c.E;
+    s->row_ptr = c.row_ptr;
+    // Which kernel.  (1) a built-in instance with compile-time tables (the shipped matrices); (2) any other
+    // single-circulant QC code: the same split kernel specialised at run time (jit.cc) -- unless that cannot be built
+    // (compiler missing, shape out of range), in which case (3) the table-driven two-wave kernel if the block
+    // structure is the AR4JA plan, else (4) the generic on-chip kernel.
+    bool builtin = false;
+    if (plan_why_not(c, variant, dtype) == nullptr && dtype == LDPC_F32) {
+        std::vector<uint16_t> rot; std::vector<uint8_t> bcv;
+        for (int br = 0; br < c.block_rows; br++)
+            for (int bc = 0; bc < c.block_cols; bc++) {
+                int off = c.offsets[(size_t)br * c.block_cols + bc];
+                if (off >= 0) { rot.push_back((uint16_t)off); bcv.push_back((uint8_t)bc); }
+            }
+        const char *d = getenv("LDPC_FUSED_TABLE");
+        builtin = !(d && !strcmp(d, "dyn")) && fused_msg_static_id(c.sz, rot.data(), bcv.data(), (int)rot.size()) != 0;
+        if (d && !strcmp(d, "dyn")) builtin = true;   // forced table-driven kernel: not the run-time compiler either
+    }
+    {
+        const char *k = getenv("LDPC_FUSED_KERNEL");   // A/B switches name a built-in kernel
+        if (k && (!strcmp(k, "rec") || !strcmp(k, "msg"))) builtin = builtin || plan_why_not(c, variant, dtype) == nullptr;
+    }
+    if (!builtin && jit_split_why_not(c, variant, dtype) == nullptr) {
+        s->jit = jit_split_create(c, variant, dtype);
+        if (s->jit) {
+            snprintf(s->info.name, sizeof(s->info.name), "%s", s->jit->name.c_str());
+            s->info.threads = s->jit->threads; s->info.frames_per_wg = s->jit->frames_per_wg;
+            return s;
+        }
+        fprintf(stderr, "[libldpc_hip] run-time specialisation failed (%s); using a table-driven kernel\n", ldpc_last_error());
+    }
     if (plan_why_not(c, variant, dtype) != nullptr) {  // no QC plan: generic on-chip kernel
+        if (fused_csr_why_not(c, variant, dtype) != nullptr) {
+            delete s;
+            set_error(LDPC_EUNSUPPORTED, "no fused kernel could be built for this code (%s)", fused_why_not(c, variant, dtype) ? fused_why_not(c, variant, dtype) : "run-time compilation failed");
+            return nullptr;
+        }
         s->csr = fused_csr_create(c, variant, dtype);
         if (!s->csr) { delete s; return nullptr; }
         fused_csr_set_round16(s->csr, s->round16);
         return s;
     }
-    s->row_ptr = c.row_ptr;
     {   // LDPC_FUSED_KERNEL=rec selects the compressed-record kernel (min-sum only) for A/B measurements
         const char *k = getenv("LDPC_FUSED_KERNEL");
         s->use_msg = fused_msg_has(variant, dtype, c.sz) && !(k && !strcmp(k, "rec") && variant == LDPC_MINSUM);
@@ -480,6 +518,7 @@ FusedState *fused_create(const ldpc_code &c, int variant, int dtype, int max_bat
 
 void fused_destroy(FusedState *s) {
     if (!s) return;
+    jit_destroy(s->jit);
     fused_csr_destroy(s->csr);
     (void)hipFree(s->d_tab);
     delete s;
@@ -488,10 +527,20 @@ void fused_destroy(FusedState *s) {
 void fused_set_timer(FusedState *s, KernelTimer *t) { if (s) { s->timer = t; fused_csr_set_timer(s->csr, t); } }
 
 bool fused_reads_llr_once(const FusedState &s, int max_iters) {
-    return s.csr != nullptr || (s.use_split && max_iters <= kSplitMaxIters);
+    return s.jit != nullptr || s.csr != nullptr || (s.use_split && max_iters <= kSplitMaxIters);
 }
 
 const LaunchInfo &fused_launch_info(const FusedState &s) { return s.csr ? fused_csr_launch_info(*s.csr) : s.info; }
+
+static int launch_jit(FusedState &s, hipStream_t st, FusedArgs &a) {
+    const int grid = (a.batch + s.jit->frames_per_wg - 1) / s.jit->frames_per_wg;
+    void *params[] = {&a};
+    if (s.timer && !a.step_mode) s.timer->begin(st);
+    hipError_t e = hipModuleLaunchKernel(s.jit->fn, (unsigned)grid, 1, 1, (unsigned)s.jit->threads, 1, 1, 0, st, params, nullptr);
+    if (s.timer && !a.step_mode) s.timer->end(st);
+    if (e != hipSuccess) return set_error(LDPC_EHIP, "launch of %s: %s", s.jit->name.c_str(), hipGetErrorString(e));
+    return LDPC_OK;
+}
 
 const char *fused_kernel_name(const FusedState &s) {
     const LaunchInfo &li = fused_launch_info(s);
@@ -508,6 +557,7 @@ int fused_decode(FusedState &s, hipStream_t st, int max_iters, int batch, const 
     FusedArgs a{};
     a.tab = s.d_tab; a.llr = d_llr; a.llr_fmt = llr_fmt; a.llr_round16 = s.round16; a.bits = d_bits; a.iters = d_iters; a.conv = d_conv;
     a.final_lam = d_final; a.trace = d_trace; a.batch = batch; a.max_iters = max_iters; a.step_mode = 0;
+    if (s.jit) return launch_jit(s, st, a);
     // (the split kernel packs a frame's result into one register: 9 bits for the turn it converged at)
     if (s.use_split && max_iters <= kSplitMaxIters) return fused_split_launch(s.variant, s.sz, st, a, s.timer, &s.info);
     if (s.use_msg) return fused_msg_launch(s.variant, s.dtype, s.sz, s.static_id, st, a, s.timer, &s.info);
@@ -567,10 +617,11 @@ static int step_typed(FusedState &s, hipStream_t st, int batch, const double *d_
 int fused_step(FusedState &s, hipStream_t st, int batch, const double *d_orig, const double *d_lam, const double *d_ne,
                double *d_ne_out, double *d_lam_out, uint8_t *d_syn) {
     if (s.csr) return fused_csr_step(*s.csr, st, batch, d_orig, d_lam, d_ne, d_ne_out, d_lam_out, d_syn);
-    if (s.use_msg) {  // per-edge messages: the state goes in and out as it is
+    if (s.use_msg || s.jit) {  // per-edge messages: the state goes in and out as it is
         FusedArgs a{};
         a.tab = s.d_tab; a.llr = d_orig; a.llr_fmt = LLR_F64; a.llr_round16 = 0; a.batch = batch; a.max_iters = 1; a.step_mode = 1;
         a.st_lam = d_lam; a.st_ne_in = d_ne; a.st_ne_out = d_ne_out; a.final_lam = d_lam_out; a.st_syn = d_syn;
+        if (s.jit) return launch_jit(s, st, a);
         if (s.use_split) return fused_split_launch(s.variant, s.sz, st, a, nullptr, nullptr);
         return fused_msg_launch(s.variant, s.dtype, s.sz, s.static_id, st, a, nullptr, nullptr);
     }

@@ -1,21 +1,29 @@
 // fused_common.h -- pieces shared by the fused on-chip kernels (fused.hip: compressed-record min-sum;
 // fused_msg.hip: per-edge messages in VGPRs, min-sum and tanh).
 #pragma once
+#include "ldpc_math.h"   // first: it decides whether this is a device-only (run-time) compilation
+#ifndef LDPC_DEVICE_ONLY
 #include <string.h>
-
+#include "fused.h"
+#endif
 #include <type_traits>
 #include <utility>
-
-#include "fused.h"
-#include "ldpc_math.h"
 
 namespace ldpc {
 
 // ------------------------------------------------------------------ plans
 // AR4JA rate-4/5 protograph as shipped in codes/jpl.1024.4.5 and codes/jpl.4096.4.5:
 // 12 x 44 blocks, block rows 0-3 of weight 3, 4-11 of weight 18.
+// number of wave groups a frame's block rows are dealt to in the split kernel (block row br -> group br % SPLIT_NP);
+// 2 = the wave PAIRS of fused_split.hip.  Four groups (39 messages per thread, 5-6 waves/SIMD) measured slower on
+// jpl.4096 (13.3 vs 14.5 Gbit/s), about equal on jpl.1024.
+#ifndef SPLIT_NP
+#define SPLIT_NP 2
+#endif
 struct PlanAR4JA45 {
     static constexpr int NBR = 12, NBC = 44, NEDGE = 4 * 3 + 8 * 18, DMAX = 18;
+    static constexpr int NP = SPLIT_NP;
+    static constexpr int owner_br(int br) { return br % NP; }
     static constexpr int deg(int br) { return br < 4 ? 3 : 18; }
     static constexpr int ebeg(int br) { return br < 4 ? 3 * br : 12 + 18 * (br - 4); }
 };
@@ -101,6 +109,7 @@ struct FusedCfg {
 };
 
 
+#ifndef LDPC_DEVICE_ONLY
 // launcher of the per-edge-message kernels (fused_msg.hip)
 bool fused_msg_has(int variant, int dtype, int sz);
 int fused_msg_static_id(int sz, const uint16_t *rot, const uint8_t *bc, int nedge);
@@ -109,6 +118,7 @@ int fused_msg_launch(int variant, int dtype, int sz, int static_id, hipStream_t 
 // four-wave variant with the block rows split between two wave pairs (fused_split.hip)
 bool fused_split_has(int variant, int dtype, int sz, int static_id);
 int fused_split_launch(int variant, int sz, hipStream_t st, FusedArgs &a, KernelTimer *timer, LaunchInfo *info);
-constexpr int kSplitMaxIters = 511;  // fused_split.hip result word: bits 23..31 hold the turn a frame converged at
+#endif
+constexpr int kSplitMaxIters = 511;  // fused_split_body.h packed result word: bits 23..31 hold the turn a frame converged at
 
 }  // namespace ldpc

@@ -2,7 +2,9 @@
 // (fused_msg.hip: two waves per sz=128 frame; fused_split.hip: four waves, block rows split between pairs).
 #pragma once
 #include "fused_common.h"
+#ifndef LDPC_DEVICE_ONLY
 #include "generated_tables.h"
+#endif
 
 namespace ldpc {
 

@@ -1,0 +1,421 @@
+// jit.cc -- run-time specialisation of the fused quasi-cyclic split kernel (see jit.h).
+//   source   : generated plan + rotation table + one extern "C" kernel around split_kernel_body (fused_split_body.h);
+//              the device headers are embedded in the library at build time (jit_embed.inc, build.py)
+//   compiler : hiprtc, dlopen'ed (so the library has no link-time dependency on it and binds to the copy that belongs
+//              to the HIP runtime already in the process); LDPC_JIT_COMPILER=hipcc runs `hipcc --genco` instead
+//   cache    : <cache dir>/<hash of source + options>.hsaco, written atomically; LDPC_JIT_CACHE names the directory
+//              (default: jit_cache/ next to libldpc_hip.so if writable, else ~/.cache/ecc_ldpc_amd, else /tmp)
+#include "jit.h"
+
+#include <dlfcn.h>
+#include <hip/hiprtc.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <algorithm>
+#include <chrono>
+#include <fstream>
+#include <mutex>
+#include <sstream>
+
+#include "fused_common.h"
+
+namespace ldpc {
+
+namespace {
+struct EmbeddedHeader { const char *name; const char *text; };
+#include "jit_embed.inc"   // static const EmbeddedHeader kJitHeaders[]; static const int kJitHeaderCount;
+
+const char *const kOptions[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-w"};
+constexpr int kNumOptions = sizeof(kOptions) / sizeof(kOptions[0]);
+
+// ---------------------------------------------------------------------------------------------- hiprtc, loaded lazily
+struct Rtc {
+    void *h = nullptr;
+    hiprtcResult (*create)(hiprtcProgram *, const char *, const char *, int, const char **, const char **) = nullptr;
+    hiprtcResult (*compile)(hiprtcProgram, int, const char **) = nullptr;
+    hiprtcResult (*log_size)(hiprtcProgram, size_t *) = nullptr;
+    hiprtcResult (*log)(hiprtcProgram, char *) = nullptr;
+    hiprtcResult (*code_size)(hiprtcProgram, size_t *) = nullptr;
+    hiprtcResult (*code)(hiprtcProgram, char *) = nullptr;
+    hiprtcResult (*destroy)(hiprtcProgram *) = nullptr;
+    const char *(*err)(hiprtcResult) = nullptr;
+    std::string why;
+};
+
+Rtc &rtc() {
+    static Rtc r;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        std::vector<std::string> cand;
+        if (const char *e = getenv("LDPC_HIPRTC_LIB")) cand.push_back(e);
+        Dl_info di;   // the directory of the HIP runtime this process already runs on comes first
+        if (dladdr((void *)&hipGetDeviceCount, &di) && di.dli_fname) {
+            std::string d(di.dli_fname);
+            size_t p = d.rfind('/');
+            if (p != std::string::npos) { cand.push_back(d.substr(0, p) + "/libhiprtc.so.7"); cand.push_back(d.substr(0, p) + "/libhiprtc.so"); }
+        }
+        cand.push_back("libhiprtc.so.7");
+        cand.push_back("libhiprtc.so");
+        cand.push_back("/opt/rocm/lib/libhiprtc.so");
+        for (auto &c : cand) {
+            r.h = dlopen(c.c_str(), RTLD_NOW | RTLD_LOCAL);
+            if (r.h) break;
+            const char *de = dlerror();   // (a second call would return NULL: the first clears it)
+            r.why = de ? de : "dlopen failed";
+        }
+        if (!r.h) return;
+#define SYM(field, name) r.field = (decltype(r.field))dlsym(r.h, name)
+        SYM(create, "hiprtcCreateProgram"); SYM(compile, "hiprtcCompileProgram"); SYM(log_size, "hiprtcGetProgramLogSize");
+        SYM(log, "hiprtcGetProgramLog"); SYM(code_size, "hiprtcGetCodeSize"); SYM(code, "hiprtcGetCode");
+        SYM(destroy, "hiprtcDestroyProgram"); SYM(err, "hiprtcGetErrorString");
+#undef SYM
+        if (!r.create || !r.compile || !r.log_size || !r.log || !r.code_size || !r.code || !r.destroy) { r.why = "libhiprtc lacks a symbol"; dlclose(r.h); r.h = nullptr; }
+    });
+    return r;
+}
+
+// ---------------------------------------------------------------------------------------------- cache
+uint64_t fnv1a(const std::string &s, uint64_t seed) {
+    uint64_t h = 0xcbf29ce484222325ull ^ seed;
+    for (unsigned char c : s) { h ^= c; h *= 0x100000001b3ull; }
+    return h;
+}
+std::string hash_hex(const std::string &s) {
+    char b[40];
+    snprintf(b, sizeof(b), "%016llx%016llx", (unsigned long long)fnv1a(s, 0), (unsigned long long)fnv1a(s, 0x9e3779b97f4a7c15ull));
+    return b;
+}
+bool dir_writable(const std::string &d) {
+    if (mkdir(d.c_str(), 0755) != 0 && access(d.c_str(), F_OK) != 0) return false;
+    return access(d.c_str(), W_OK | X_OK) == 0;
+}
+std::string g_cache_dir;
+std::once_flag g_cache_once;
+void pick_cache_dir() {
+    std::vector<std::string> cand;
+    if (const char *e = getenv("LDPC_JIT_CACHE")) cand.push_back(e);
+    Dl_info di;
+    if (dladdr((void *)&pick_cache_dir, &di) && di.dli_fname) {
+        std::string d(di.dli_fname);
+        size_t p = d.rfind('/');
+        cand.push_back((p == std::string::npos ? std::string(".") : d.substr(0, p)) + "/jit_cache");
+    }
+    if (const char *h = getenv("HOME")) { std::string c = std::string(h) + "/.cache"; (void)mkdir(c.c_str(), 0755); cand.push_back(c + "/ecc_ldpc_amd"); }
+    cand.push_back("/tmp/ecc_ldpc_amd_jit_" + std::to_string((unsigned)getuid()));
+    for (auto &c : cand)
+        if (dir_writable(c)) { g_cache_dir = c; return; }
+    g_cache_dir = "";
+}
+
+bool read_all(const std::string &path, std::vector<char> &out) {
+    std::ifstream f(path, std::ios::binary);
+    if (!f) return false;
+    f.seekg(0, std::ios::end);
+    std::streamoff n = f.tellg();
+    if (n <= 0) return false;
+    out.resize((size_t)n);
+    f.seekg(0);
+    f.read(out.data(), n);
+    return (bool)f;
+}
+
+int compile_hiprtc(const std::string &source, std::vector<char> &co) {
+    Rtc &r = rtc();
+    if (!r.h) return set_error(LDPC_EUNSUPPORTED, "run-time compilation unavailable: libhiprtc not loadable (%s)", r.why.c_str());
+    std::vector<const char *> names, texts;
+    for (int i = 0; i < kJitHeaderCount; i++) { names.push_back(kJitHeaders[i].name); texts.push_back(kJitHeaders[i].text); }
+    hiprtcProgram prog = nullptr;
+    hiprtcResult rc = r.create(&prog, source.c_str(), "ldpc_jit.hip", (int)names.size(), texts.data(), names.data());
+    if (rc != HIPRTC_SUCCESS) return set_error(LDPC_EHIP, "hiprtcCreateProgram: %s", r.err ? r.err(rc) : "error");
+    const char *opts[kNumOptions];
+    for (int i = 0; i < kNumOptions; i++) opts[i] = kOptions[i];
+    rc = r.compile(prog, kNumOptions, opts);
+    if (rc != HIPRTC_SUCCESS) {
+        size_t n = 0;
+        std::string log;
+        if (r.log_size(prog, &n) == HIPRTC_SUCCESS && n > 1) { log.resize(n); r.log(prog, &log[0]); }
+        if (log.size() > 380) log = log.substr(0, 380);
+        r.destroy(&prog);
+        return set_error(LDPC_EHIP, "hiprtcCompileProgram: %s: %s", r.err ? r.err(rc) : "error", log.c_str());
+    }
+    size_t n = 0;
+    rc = r.code_size(prog, &n);
+    if (rc == HIPRTC_SUCCESS && n > 0) { co.resize(n); rc = r.code(prog, co.data()); }
+    r.destroy(&prog);
+    if (rc != HIPRTC_SUCCESS || n == 0) return set_error(LDPC_EHIP, "hiprtcGetCode failed");
+    return LDPC_OK;
+}
+
+// the tool-chain route: same source, same headers, same options through `hipcc --genco`
+int compile_hipcc(const std::string &source, std::vector<char> &co) {
+    char tmpl[] = "/tmp/ldpc_jit_XXXXXX";
+    if (!mkdtemp(tmpl)) return set_error(LDPC_EHIP, "mkdtemp failed");
+    std::string d(tmpl);
+    for (int i = 0; i < kJitHeaderCount; i++) { std::ofstream f(d + "/" + kJitHeaders[i].name); f << kJitHeaders[i].text; }
+    { std::ofstream f(d + "/ldpc_jit.hip"); f << source; }
+    const char *hipcc = getenv("HIPCC");
+    std::string cmd = std::string(hipcc ? hipcc : "/opt/rocm/bin/hipcc") + " --genco -DLDPC_JIT -I" + d;
+    for (int i = 0; i < kNumOptions; i++) cmd += std::string(" ") + kOptions[i];
+    cmd += " -x hip " + d + "/ldpc_jit.hip -o " + d + "/out.hsaco > " + d + "/log.txt 2>&1";
+    int rc = system(cmd.c_str());
+    bool ok = rc == 0 && read_all(d + "/out.hsaco", co);
+    std::string log;
+    if (!ok) { std::vector<char> l; if (read_all(d + "/log.txt", l)) log.assign(l.begin(), l.begin() + std::min<size_t>(l.size(), 380)); }
+    std::string rm = "rm -rf " + d;
+    (void)!system(rm.c_str());
+    if (!ok) return set_error(LDPC_EHIP, "hipcc --genco failed (%d): %s", rc, log.c_str());
+    return LDPC_OK;
+}
+}  // namespace
+
+const char *jit_cache_dir() {
+    std::call_once(g_cache_once, pick_cache_dir);
+    return g_cache_dir.c_str();
+}
+
+int jit_compile_cached(const std::string &source, const std::string &kernel_name, std::vector<char> &co, bool *from_cache, double *seconds) {
+    std::string keyed = source;
+    for (int i = 0; i < kNumOptions; i++) { keyed += "\n//opt "; keyed += kOptions[i]; }
+    for (int i = 0; i < kJitHeaderCount; i++) { keyed += "\n//hdr "; keyed += kJitHeaders[i].name; keyed += hash_hex(kJitHeaders[i].text); }
+    const std::string key = hash_hex(keyed);
+    const std::string dir = jit_cache_dir();
+    const std::string path = dir.empty() ? std::string() : dir + "/" + kernel_name + "-" + key + ".hsaco";
+    if (from_cache) *from_cache = false;
+    if (seconds) *seconds = 0;
+    const char *nc = getenv("LDPC_JIT_NOCACHE");
+    if (!path.empty() && !(nc && !strcmp(nc, "1")) && read_all(path, co)) {
+        if (from_cache) *from_cache = true;
+        return LDPC_OK;
+    }
+    auto t0 = std::chrono::steady_clock::now();
+    const char *which = getenv("LDPC_JIT_COMPILER");
+    int rc = (which && !strcmp(which, "hipcc")) ? compile_hipcc(source, co) : compile_hiprtc(source, co);
+    if (rc != LDPC_OK && !(which && !strcmp(which, "hiprtc")) && !(which && !strcmp(which, "hipcc"))) {
+        // hiprtc missing or failing: the tool chain, if there is one
+        std::string first = ldpc_last_error();
+        if (compile_hipcc(source, co) == LDPC_OK) rc = LDPC_OK;
+        else rc = set_error(LDPC_EHIP, "%s", first.c_str());
+    }
+    if (seconds) *seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (rc != LDPC_OK) return rc;
+    if (!path.empty()) {   // atomically: concurrent ranks may compile the same kernel
+        std::string tmp = path + ".tmp" + std::to_string((long)getpid());
+        std::ofstream f(tmp, std::ios::binary);
+        f.write(co.data(), (std::streamsize)co.size());
+        f.close();
+        if (!f || rename(tmp.c_str(), path.c_str()) != 0) (void)unlink(tmp.c_str());
+    }
+    return LDPC_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- plan generation
+namespace {
+struct PlanChoice {
+    int sz = 0, nbr = 0, nbc = 0, nedge = 0, dmax = 0, np = 1, waves_per_eu = 4, cpw = 1, v = 64;
+    std::vector<int> deg, ebeg, own, rot, bc;
+};
+
+constexpr int kMsgCapMinsum = 80, kMsgCapTanh = 78;   // messages per thread that still fit the register budget (4 / 3 waves per SIMD)
+
+// cost of dealing the block rows to `np` wave groups by `own`: (max messages per group, phase-B critical path + phase-A critical path)
+void deal_cost(const PlanChoice &p, const std::vector<int> &own, int np, int *max_msgs, long *path) {
+    std::vector<int> msgs(np, 0);
+    for (int br = 0; br < p.nbr; br++) msgs[own[br]] += p.deg[br];
+    *max_msgs = *std::max_element(msgs.begin(), msgs.end());
+    // round of an edge = number of later edges in the same block column (fused_rows.h Rounds)
+    std::vector<int> seen(p.nbc, 0), round_of(p.nedge, 0);
+    for (int e = p.nedge - 1; e >= 0; e--) { round_of[e] = seen[p.bc[e]]++; }
+    int nr = 0;
+    for (int e = 0; e < p.nedge; e++) nr = std::max(nr, round_of[e] + 1);
+    std::vector<int> cnt((size_t)nr * np, 0);
+    for (int br = 0; br < p.nbr; br++)
+        for (int e = p.ebeg[br]; e < p.ebeg[br + 1]; e++) cnt[(size_t)round_of[e] * np + own[br]]++;
+    long pb = 0;
+    for (int q = 0; q < nr; q++) pb += *std::max_element(cnt.begin() + (size_t)q * np, cnt.begin() + (size_t)(q + 1) * np);
+    *path = pb + 4L * *max_msgs;   // phase A costs ~4x a phase-B edge
+}
+
+const char *choose_plan(const ldpc_code &c, int variant, PlanChoice &p) {
+    if (c.sz <= 0) return "code was not created from a quasi-cyclic description";
+    if (c.sz < 16 || (c.sz & (c.sz - 1))) return "circulant size must be a power of two >= 16 for the split kernel";
+    if (c.sz > 1024) return "circulant size above 1024";
+    p.sz = c.sz; p.nbr = c.block_rows; p.nbc = c.block_cols;
+    p.cpw = c.sz >= 64 ? 1 : 64 / c.sz; p.v = c.sz * p.cpw;
+    p.deg.assign(p.nbr, 0); p.ebeg.assign(p.nbr + 1, 0);
+    for (int br = 0; br < p.nbr; br++) {
+        for (int bc = 0; bc < p.nbc; bc++) {
+            int off = c.offsets[(size_t)br * p.nbc + bc];
+            if (off >= 0) { p.rot.push_back(off); p.bc.push_back(bc); p.deg[br]++; }
+        }
+        p.ebeg[br + 1] = (int)p.rot.size();
+        p.dmax = std::max(p.dmax, p.deg[br]);
+        if (p.deg[br] == 0) return "an empty block row";
+    }
+    p.nedge = (int)p.rot.size();
+    if (p.dmax > 32) return "block-row weight above 32";
+    if (p.nbc > 4096 || p.nedge > 4096) return "more than 4096 block columns / circulants";
+    {   // every block column must be hit (the kernel seeds lam from round 0 of each column)
+        std::vector<char> hit(p.nbc, 0);
+        for (int b : p.bc) hit[b] = 1;
+        for (char h : hit) if (!h) return "an empty block column";
+    }
+    const size_t lds = (size_t)p.nbc * p.v * 4 + 64;
+    if (lds > 160 * 1024) return "a frame's LLRs do not fit in 160 KB of LDS";
+    const int cap = variant == LDPC_TANH ? kMsgCapTanh : kMsgCapMinsum;
+    const int max_np = std::min(1024 / p.v, p.nbr);
+    int best_np = 0;
+    std::vector<int> best_own;
+    for (int np = 1; np <= max_np && !best_np; np++) {
+        // candidates: round-robin (what the shipped AR4JA instances use), longest-processing-time, then pairwise swaps
+        std::vector<std::vector<int>> cands;
+        std::vector<int> rr(p.nbr), lpt(p.nbr, 0);
+        for (int br = 0; br < p.nbr; br++) rr[br] = br % np;
+        cands.push_back(rr);
+        {
+            std::vector<int> order(p.nbr), load(np, 0);
+            for (int i = 0; i < p.nbr; i++) order[i] = i;
+            std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return p.deg[a] > p.deg[b]; });
+            for (int br : order) { int g = (int)(std::min_element(load.begin(), load.end()) - load.begin()); lpt[br] = g; load[g] += p.deg[br]; }
+            cands.push_back(lpt);
+        }
+        // objective, lexicographic: (messages over the register budget, critical path of a turn)
+        auto score = [&](const std::vector<int> &o, int *m_out) {
+            int m; long pa;
+            deal_cost(p, o, np, &m, &pa);
+            if (m_out) *m_out = m;
+            return std::make_pair(std::max(m - cap, 0), pa);
+        };
+        std::vector<int> bo = cands[0];
+        auto bs = score(bo, nullptr);
+        for (auto &o : cands) { auto sc = score(o, nullptr); if (sc < bs) { bs = sc; bo = o; } }
+        for (int pass = 0; pass < 4; pass++) {
+            bool improved = false;
+            for (int a = 0; a < p.nbr; a++) {
+                for (int g = 0; g < np; g++) {          // move block row a to group g
+                    if (g == bo[a]) continue;
+                    const int old = bo[a];
+                    bo[a] = g;
+                    auto sc = score(bo, nullptr);
+                    if (sc < bs) { bs = sc; improved = true; } else bo[a] = old;
+                }
+                for (int b = a + 1; b < p.nbr; b++) {   // swap the groups of a and b
+                    if (bo[a] == bo[b]) continue;
+                    std::swap(bo[a], bo[b]);
+                    auto sc = score(bo, nullptr);
+                    if (sc < bs) { bs = sc; improved = true; } else std::swap(bo[a], bo[b]);
+                }
+            }
+            if (!improved) break;
+        }
+        int bm = 0;
+        (void)score(bo, &bm);
+        {   // every group must own at least one block row (each wave group runs the same number of barriers either way,
+            // but an idle group would only burn occupancy)
+            std::vector<int> used(np, 0);
+            for (int g : bo) used[g] = 1;
+            if (std::find(used.begin(), used.end(), 0) != used.end()) continue;
+        }
+        if (bm <= cap) { best_np = np; best_own = bo; }
+    }
+    if (!best_np) return "more messages per thread than the register budget allows even with the widest workgroup";
+    p.np = best_np; p.own = best_own;
+    // waves per SIMD the register allocator is asked for: messages + round-0 LLRs + row temporaries
+    int msgs = 0;
+    { std::vector<int> m(p.np, 0); for (int br = 0; br < p.nbr; br++) m[p.own[br]] += p.deg[br]; msgs = *std::max_element(m.begin(), m.end()); }
+    const int norig = (p.nbc + p.np - 1) / p.np + 2;
+    const int est = msgs + norig + (variant == LDPC_TANH ? 3 * p.dmax + 24 : p.dmax + 28);
+    int w = est <= 64 ? 8 : est <= 80 ? 6 : est <= 96 ? 5 : est <= 128 ? 4 : est <= 168 ? 3 : 2;
+    const int threads = p.np * p.v;
+    const int wg_per_cu = (int)std::max<size_t>(1, (160 * 1024) / lds);
+    const int w_lds = std::max(1, std::min(wg_per_cu, 2048 / threads) * threads / 64 / 4);
+    p.waves_per_eu = std::max(1, std::min(w, w_lds));
+    return nullptr;
+}
+
+std::string list_of(const std::vector<int> &v) {
+    std::string s;
+    for (size_t i = 0; i < v.size(); i++) { if (i) s += ", "; s += std::to_string(v[i]); }
+    return s;
+}
+}  // namespace
+
+const char *jit_split_why_not(const ldpc_code &c, int variant, int dtype) {
+    if (dtype != LDPC_F32) return "run-time specialised kernels exist for f32 only";
+    if (variant != LDPC_MINSUM && variant != LDPC_TANH) return "unknown variant";
+    if (variant == LDPC_MINSUM && c.min_row_deg < 2) return "min-sum needs check rows of weight >= 2";
+    const char *e = getenv("LDPC_JIT");
+    if (e && !strcmp(e, "0")) return "disabled (LDPC_JIT=0)";
+    PlanChoice p;
+    return choose_plan(c, variant, p);
+}
+
+std::string jit_split_source(const ldpc_code &c, int variant, int dtype, JitKernel *g) {
+    PlanChoice p;
+    if (dtype != LDPC_F32 || choose_plan(c, variant, p)) return std::string();
+    std::ostringstream s;
+    s << "// generated by libldpc_hip (jit.cc) for a " << p.nbr << " x " << p.nbc << " block quasi-cyclic H, circulant size " << p.sz << "\n"
+      << "#define SPLIT_RESULT_PACKED 0\n"
+      << "#include \"fused_split_body.h\"\n"
+      << "namespace ldpc {\n"
+      << "struct JPlan {\n"
+      << "    static constexpr int NBR = " << p.nbr << ", NBC = " << p.nbc << ", NEDGE = " << p.nedge << ", DMAX = " << p.dmax << ", NP = " << p.np << ";\n"
+      << "    static constexpr int deg_[NBR] = {" << list_of(p.deg) << "};\n"
+      << "    static constexpr int ebeg_[NBR + 1] = {" << list_of(p.ebeg) << "};\n"
+      << "    static constexpr int own_[NBR] = {" << list_of(p.own) << "};\n"
+      << "    static constexpr int deg(int br) { return deg_[br]; }\n"
+      << "    static constexpr int ebeg(int br) { return ebeg_[br]; }\n"
+      << "    static constexpr int owner_br(int br) { return own_[br]; }\n"
+      << "};\n"
+      << "struct JTab {\n"
+      << "    static constexpr int SZ = " << p.sz << ", NBR = " << p.nbr << ", NBC = " << p.nbc << ", NEDGE = " << p.nedge << ";\n"
+      << "    static constexpr uint16_t rot[NEDGE] = {" << list_of(p.rot) << "};\n"
+      << "    static constexpr uint16_t bc[NEDGE] = {" << list_of(p.bc) << "};\n"
+      << "};\n"
+      << "}  // namespace ldpc\n";
+    const std::string body = s.str();
+    char name[96];
+    snprintf(name, sizeof(name), "ldpc_jit_split_%s_sz%d_%s", variant == LDPC_MINSUM ? "minsum" : "tanh", p.sz, hash_hex(body).substr(0, 10).c_str());
+    std::ostringstream k;
+    k << body << "extern \"C\" __global__ __launch_bounds__(" << p.np * p.v << ") __attribute__((amdgpu_waves_per_eu(" << p.waves_per_eu << ", " << p.waves_per_eu << ")))\n"
+      << "void " << name << "(ldpc::FusedArgs A) {\n"
+      << "    ldpc::split_kernel_body<float, " << (variant == LDPC_MINSUM ? "LDPC_V_MINSUM" : "LDPC_V_TANH") << ", ldpc::JPlan, " << p.sz << ", ldpc::JTab>(A);\n"
+      << "}\n";
+    if (g) { g->threads = p.np * p.v; g->frames_per_wg = p.cpw; g->np = p.np; g->waves_per_eu = p.waves_per_eu; g->name = name; }
+    return k.str();
+}
+
+void jit_destroy(JitKernel *k) {
+    if (!k) return;
+    if (k->mod) { (void)hipSetDevice(k->device); (void)hipModuleUnload(k->mod); }
+    delete k;
+}
+
+JitKernel *jit_split_create(const ldpc_code &c, int variant, int dtype) {
+    const char *why = jit_split_why_not(c, variant, dtype);
+    if (why) { set_error(LDPC_EUNSUPPORTED, "%s", why); return nullptr; }
+    JitKernel *k = new (std::nothrow) JitKernel();
+    if (!k) { set_error(LDPC_ENOMEM, "out of host memory"); return nullptr; }
+    try {
+        const std::string src = jit_split_source(c, variant, dtype, k);
+        std::vector<char> co;
+        if (jit_compile_cached(src, k->name, co, &k->from_cache, &k->compile_seconds) != LDPC_OK) { delete k; return nullptr; }
+        (void)hipGetDevice(&k->device);
+        hipError_t e = hipModuleLoadData(&k->mod, co.data());
+        if (e == hipSuccess) e = hipModuleGetFunction(&k->fn, k->mod, k->name.c_str());
+        if (e != hipSuccess) {
+            set_error(LDPC_EHIP, "loading the run-time compiled kernel %s: %s", k->name.c_str(), hipGetErrorString(e));
+            jit_destroy(k);
+            return nullptr;
+        }
+        if (const char *v = getenv("LDPC_JIT_VERBOSE"); v && !strcmp(v, "1"))
+            fprintf(stderr, "[ldpc jit] %s: %d threads/workgroup, %d wave groups, %d waves/SIMD, %s (%.1f s)\n", k->name.c_str(), k->threads, k->np,
+                    k->waves_per_eu, k->from_cache ? "from cache" : "compiled", k->compile_seconds);
+        return k;
+    } catch (...) { delete k; set_error(LDPC_ENOMEM, "out of host memory"); return nullptr; }
+}
+
+}  // namespace ldpc

@@ -18,9 +18,22 @@
 //     applied where the double reference applies it (its product rounds to exactly +-1 <=> every factor
 //     has |t_j|/2 >= 19.0615, i.e. the true value is >= 37.43 anyway).
 #pragma once
+#if defined(__HIPCC_RTC__) || defined(LDPC_JIT)
+// run-time compilation (jit.cc: hiprtc, or `hipcc --genco -DLDPC_JIT`): device code only -- hiprtc has no host headers
+#define LDPC_DEVICE_ONLY 1
+#ifndef __HIPCC_RTC__
+#include <hip/hip_runtime.h>
+#endif
+#include <stdint.h>
+namespace ldpc { enum { LLR_F32 = 0, LLR_F64 = 1, LLR_F16 = 2 }; }
+#ifndef INFINITY
+#define INFINITY __builtin_inff()
+#endif
+#else
 #include <hip/hip_runtime.h>
 #include <hip/hip_fp16.h>
 #include "internal.h"
+#endif
 #include <type_traits>
 
 // Marks the enclosing basic block as a COLD side path of the iteration loop (syndrome-only last turn, convergence
@@ -48,6 +61,7 @@ template <> struct Store<double> {
     static __device__ __forceinline__ double ld(const double *p) { return *p; }
     static __device__ __forceinline__ void st(double *p, double v) { *p = v; }
 };
+#ifndef LDPC_DEVICE_ONLY
 template <> struct Store<__half> {
     using CT = float;
     static __device__ __forceinline__ float ld(const __half *p) { return __half2float(*p); }
@@ -57,6 +71,7 @@ template <> struct Store<__half> {
         *p = __float2half_rn(v);
     }
 };
+#endif
 
 template <typename CT> __device__ __forceinline__ bool hard(CT x) { return x > CT(0); }
 
@@ -64,14 +79,14 @@ template <typename CT> __device__ __forceinline__ bool hard(CT x) { return x > C
 // (LLR_F32 / LLR_F64 / LLR_F16: internal.h)
 template <typename CT> __device__ __forceinline__ CT load_llr(const void *base, size_t i, int fmt) {
     if (fmt == LLR_F64) return (CT) reinterpret_cast<const double *>(base)[i];
-    if (fmt == LLR_F16) return (CT) __half2float(reinterpret_cast<const __half *>(base)[i]);
+    if (fmt == LLR_F16) return (CT) (float) reinterpret_cast<const _Float16 *>(base)[i];
     return (CT) reinterpret_cast<const float *>(base)[i];
 }
 // compile-time format: lets a caller dispatch on the format ONCE around a batch of loads, so that the loads
 // of one thread issue back to back instead of each sitting behind its own three-way branch
 template <typename CT, int FMT> __device__ __forceinline__ CT load_llr_as(const void *base, size_t i) {
     if constexpr (FMT == LLR_F64) return (CT) reinterpret_cast<const double *>(base)[i];
-    else if constexpr (FMT == LLR_F16) return (CT) __half2float(reinterpret_cast<const __half *>(base)[i]);
+    else if constexpr (FMT == LLR_F16) return (CT) (float) reinterpret_cast<const _Float16 *>(base)[i];
     else return (CT) reinterpret_cast<const float *>(base)[i];
 }
 template <class F> __device__ __forceinline__ void with_llr_format(int fmt, F &&f) {
@@ -82,7 +97,7 @@ template <class F> __device__ __forceinline__ void with_llr_format(int fmt, F &&
 // value a float LLR has after being stored as fp16 (LDPC_F16 contexts): saturating round-to-nearest-even
 __device__ __forceinline__ float round_f16(float v) {
     v = fminf(fmaxf(v, -65504.f), 65504.f);
-    return __half2float(__float2half_rn(v));
+    return (float)(_Float16)v;   // IEEE binary16, round to nearest even (== __float2half_rn)
 }
 template <typename CT> __device__ __forceinline__ CT maybe_round_f16(CT v, int on) {
     if constexpr (sizeof(CT) == 4) return on ? round_f16(v) : v;

@@ -179,6 +179,21 @@ const char *ldpc_ctx_kernel_name(const ldpc_ctx *ctx);
  * decodes; 0/0 for the flood path, whose kernels are not frame-per-workgroup) */
 int ldpc_ctx_kernel_geometry(const ldpc_ctx *ctx, int *threads_per_workgroup, int *frames_per_workgroup);
 
+/* ---- run-time specialised kernels ------------------------------------------------------------------
+ * The fused kernels take the graph as compile-time constants.  For the shipped matrices those instances are built
+ * ahead of time; for any other single-circulant quasi-cyclic H (what the reference's QC decoders accept,
+ * Fast/Arraylet.hs:68-79) ldpc_ctx_create compiles one with hiprtc the first time and caches the code object on
+ * disk (LDPC_JIT_CACHE, default jit_cache/ next to the library).  These entry points let a host warm that cache
+ * ahead of time -- they need no GPU -- and look at what would be compiled.  LDPC_JIT=0 disables the mechanism
+ * (table-driven / generic kernels are used instead). */
+const char *ldpc_jit_cache_dir(void);
+/* the generated translation unit for (code, variant, dtype): copies up to cap-1 bytes, returns its full length,
+ * or a negative LDPC_E* (LDPC_EUNSUPPORTED with the reason when this code has no such kernel) */
+long ldpc_jit_source(const ldpc_code *code, int variant, int dtype, char *buf, size_t cap);
+/* compile into the cache (or find it there); kernel_name receives the symbol rocprofv3 will list */
+int ldpc_jit_prepare(const ldpc_code *code, int variant, int dtype, char *kernel_name, size_t cap, int *from_cache,
+                     double *seconds);
+
 /* ---- frame source and error tally for a BER / throughput harness -----------------------------------
  * The reference leaves message generation, BPSK + AWGN and BER statistics to the external tester
  * (ecc-manifold `eccMain`, main/Main.hs:41-48); a harness built on this library can keep frames

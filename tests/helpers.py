@@ -86,3 +86,93 @@ def lam_tolerance(g, ne_ref, lam_ref, rel=1e-5):
     col_unc = np.zeros(g.N)
     np.add.at(col_unc, g.col_idx, edge_unc)
     return rel * np.maximum(1.0, np.abs(lam_ref)) + col_unc, rel * np.maximum(1.0, np.abs(ne_ref)) + edge_unc
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Synthetic quasi-cyclic codes for the run-time specialised kernels (any single-circulant .q is a valid input of the
+# reference's QC decoders, Fast/Arraylet.hs:68-79).  Deterministic; frames are the all-zero codeword + noise.
+class SyntheticQC:
+    def __init__(self, name, sz, offsets, rate=None):
+        self.name, self.sz = name, int(sz)
+        self.offsets = np.asarray(offsets, np.int32)
+        R, Cb = self.offsets.shape
+        self.M, self.N = R * sz, Cb * sz
+        H = np.zeros((self.M, self.N), np.uint8)
+        r = np.arange(sz)
+        for br in range(R):
+            for bc in range(Cb):
+                if self.offsets[br, bc] >= 0:
+                    H[br * sz + r, bc * sz + (r + self.offsets[br, bc]) % sz] = 1     # QuasiCyclic.hs:19-25
+        self.H = H
+        self.graph = oracle.Graph.from_dense(H)
+        self.E = self.graph.E
+        self.k, self.n_tx = rate if rate else (self.N - self.M, self.N)
+        self.layer_ptr = np.arange(0, self.M + 1, sz, dtype=np.int32)                   # one block row per layer
+
+    def frames(self, F, ebn0_db, seed):
+        cws = np.zeros((F, self.N), np.uint8)
+        return cws, channel.frames(cws, ebn0_db, self.k, self.n_tx, self.N, seed)
+
+    def hip_code(self, E):
+        return E.Code.from_qc(self.sz, self.offsets)
+
+
+def _random_offsets(mask, sz, seed):
+    rng = np.random.default_rng(seed)
+    return np.where(mask, rng.integers(0, sz, mask.shape), -1).astype(np.int32)
+
+
+@functools.lru_cache(maxsize=None)
+def synthetic(name) -> SyntheticQC:
+    if name == "jpl4096-permuted":          # the headline code's block structure with other rotations
+        base = load("jpl.4096.4.5").offsets
+        return SyntheticQC(name, 128, _random_offsets(base >= 0, 128, 11), rate=(4096, 5120))
+    if name == "regular36-sz128":           # (3,6)-regular protograph, 6 x 12 blocks
+        rng = np.random.default_rng(12)
+        mask = np.zeros((6, 12), bool)
+        for bc in range(12):                # column weight 3, row weight 6
+            for j in range(3):
+                mask[(bc + 2 * j + (bc // 6)) % 6, bc] = True
+        assert (mask.sum(0) == 3).all() and (mask.sum(1) == 6).all()
+        return SyntheticQC(name, 128, _random_offsets(mask, 128, 13))
+    if name == "ira-12x24-sz64":            # rate-1/2 irregular repeat-accumulate shape (dual-diagonal parity part)
+        rng = np.random.default_rng(14)
+        mask = np.zeros((12, 24), bool)
+        for br in range(12):
+            mask[br, 12 + br] = True
+            if br:
+                mask[br, 12 + br - 1] = True
+        mask[0, 23] = True
+        for bc in range(12):
+            w = 6 if bc < 4 else 3
+            for br in rng.choice(12, w, replace=False):
+                mask[br, bc] = True
+        off = _random_offsets(mask, 64, 15)
+        for br in range(12):                # accumulator: rotation 0 on the two diagonals
+            off[br, 12 + br] = 0
+            if br:
+                off[br, 12 + br - 1] = 0
+        return SyntheticQC(name, 64, off)
+    if name == "small-2x4-sz32":            # two frames per wave (sz < 64), one wave group
+        return SyntheticQC(name, 32, np.array([[1, 7, 30, -1], [5, -1, 12, 3]], np.int32))
+    if name == "irregular-20x30-sz64":      # 20 x 30 blocks, block-row weights 3..10: needs three or more wave groups
+        rng = np.random.default_rng(16)
+        mask = np.zeros((20, 30), bool)
+        for br in range(20):
+            for bc in rng.choice(30, 3 + (br * 7) % 8, replace=False):
+                mask[br, bc] = True
+        for bc in range(30):
+            if not mask[:, bc].any():
+                mask[rng.integers(0, 20), bc] = True
+        return SyntheticQC(name, 64, _random_offsets(mask, 64, 17))
+    if name == "wide-4x40-sz256":           # circulant size 256: four waves per wave group
+        rng = np.random.default_rng(18)
+        mask = np.zeros((4, 40), bool)
+        for bc in range(40):
+            for br in rng.choice(4, 2 + (bc % 2), replace=False):
+                mask[br, bc] = True
+        return SyntheticQC(name, 256, _random_offsets(mask, 256, 19))
+    raise KeyError(name)
+
+
+SYNTHETIC_NAMES = ["jpl4096-permuted", "regular36-sz128", "ira-12x24-sz64", "small-2x4-sz32", "irregular-20x30-sz64", "wide-4x40-sz256"]

@@ -1,0 +1,106 @@
+"""Run-time specialised QC kernels (jit.cc): generalising the four-wave split kernel from the two shipped matrices to
+ANY single-circulant quasi-cyclic H (what the reference's QC decoders accept, Fast/Arraylet.hs:68-79).
+CPU: the generated translation unit and its compilation with hiprtc (no GPU needed; also warms the on-disk cache the
+GPU tests then hit).  GPU: the compiled kernels against the oracle."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+import ecc_ldpc_amd as E
+from oracle import oracle
+from tests.helpers import SYNTHETIC_NAMES, lam_tolerance, synthetic
+
+
+@pytest.mark.parametrize("name", SYNTHETIC_NAMES)
+def test_generated_plan_describes_the_code(name):
+    c = synthetic(name)
+    src = c.hip_code(E).jit_source("min")
+    g = lambda pat: [int(x) for x in re.search(pat + r"\[[^\]]*\] = \{([^}]*)\}", src).group(1).split(",")]
+    deg, ebeg, own, rot, bc = g("deg_"), g("ebeg_"), g("own_"), g("rot"), g("bc")
+    mask = c.offsets >= 0
+    assert deg == mask.sum(1).tolist() and ebeg == [0] + np.cumsum(mask.sum(1)).tolist()
+    assert rot == c.offsets[mask].tolist() and bc == np.nonzero(mask)[1].tolist()           # block-row-major, ascending column
+    np_ = int(re.search(r"NP = (\d+)", src).group(1))
+    threads = int(re.search(r"__launch_bounds__\((\d+)\)", src).group(1))
+    v = max(c.sz, 64)
+    assert threads == np_ * v <= 1024 and set(own) == set(range(np_))
+    per_group = [sum(d for d, o in zip(deg, own) if o == p) for p in range(np_)]
+    assert max(per_group) <= 80                                                                # register budget
+    if name == "irregular-20x30-sz64":
+        assert np_ >= 2
+    if name == "jpl4096-permuted":
+        assert np_ == 2 and per_group == [78, 78]
+
+
+def test_unsupported_shapes_say_why():
+    with pytest.raises(E.LdpcError) as e:
+        E.Code.from_qc(24, np.array([[1, 2], [3, 4]], np.int32)).jit_source("min")          # not a power of two
+    assert e.value.code == -5 and "power of two" in str(e.value)
+    with pytest.raises(E.LdpcError) as e:
+        E.Code.from_qc(64, np.array([[1, 2, -1], [3, 4, -1]], np.int32)).jit_source("min")   # empty block column
+    assert "empty block column" in str(e.value)
+    with pytest.raises(E.LdpcError):
+        synthetic("regular36-sz128").hip_code(E).jit_source("min", "f64")                     # f32 only
+
+
+@pytest.mark.parametrize("name", SYNTHETIC_NAMES)
+def test_hiprtc_compiles_without_a_gpu_and_caches(name):
+    code = synthetic(name).hip_code(E)
+    for variant in ("min", "tanh"):
+        kname, cached, sec = code.jit_prepare(variant)
+        assert kname.startswith("ldpc_jit_split_") and f"sz{synthetic(name).sz}" in kname
+        path = [f for f in os.listdir(E.lib().ldpc_jit_cache_dir().decode()) if f.startswith(kname)]
+        assert len(path) == 1 and path[0].endswith(".hsaco")
+        k2, cached2, _ = code.jit_prepare(variant)
+        assert k2 == kname and cached2
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", SYNTHETIC_NAMES)
+def test_jit_kernels_match_the_oracle(hip, name):
+    c = synthetic(name)
+    code = c.hip_code(hip)
+    F = 24 if c.N > 4000 else 64
+    llr = np.concatenate([c.frames(F // 2, db, 700 + i)[1] for i, db in enumerate((2.0, 4.0) if c.N > 1000 else (3.0, 6.0))])
+    for variant in ("min", "tanh"):
+        dec = hip.Decoder(code, variant, "f32", F)
+        assert dec.path == "fused" and dec.kernel_name.startswith("ldpc_jit_split_"), dec.kernel_name
+        bits, its, conv = dec.decode_batch(llr.astype(np.float32), 40)
+        ob, oi, oc = oracle.decode_batch(c.graph, variant, 40, llr, nthreads=8)
+        assert np.array_equal(bits, ob) and np.array_equal(conv, oc), (name, variant)
+        assert (its == oi).mean() >= 0.9
+        # same arithmetic in the same order as the flood path: identical, iteration counts included
+        fb, fi, fc = hip.Decoder(code, variant, "f32", F, path="flood").decode_batch(llr.astype(np.float32), 40)
+        assert np.array_equal(bits, fb) and np.array_equal(its, fi) and np.array_equal(conv, fc)
+        # ragged batch + single frame + max_iters beyond the packed-result limit of the built-in instances
+        b1, i1, c1 = dec.decode_batch(llr[:5].astype(np.float32), 600)
+        o1 = oracle.decode_batch(c.graph, variant, 600, llr[:5], nthreads=5)
+        assert np.array_equal(b1, o1[0]) and np.array_equal(c1, o1[2])
+        print(f"{name} {variant}: {dec.kernel_name} {int(conv.sum())}/{F} converged, iteration counts {100 * (its == oi).mean():.0f}% identical")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["jpl4096-permuted", "ira-12x24-sz64", "small-2x4-sz32"])
+def test_jit_kernels_teacher_forced(hip, name):
+    c = synthetic(name)
+    code = c.hip_code(hip)
+    _, llr = c.frames(4, 3.0, seed=801)
+    for variant in ("min", "tanh"):
+        dec = hip.Decoder(code, variant, "f32", 64)
+        states = []
+        for f in range(len(llr)):
+            o = oracle.decode(c.graph, variant, 12, llr[f], trace=True)
+            ne = np.zeros(c.E)
+            for n in range(o["iters"]):
+                states.append((llr[f], o["trace_lam"][n], ne, o["trace_ne"][n], o["trace_lam"][n + 1]))
+                ne = o["trace_ne"][n]
+        states = states[:64]
+        ne2, lam2, _ = dec.debug_step(np.stack([s[0] for s in states]), np.stack([s[1] for s in states]), np.stack([s[2] for s in states]))
+        worst = 0.0
+        for i, s in enumerate(states):
+            tol_lam, tol_ne = lam_tolerance(c.graph, s[3], s[4])
+            assert (np.abs(ne2[i] - s[3]) <= tol_ne).all() and (np.abs(lam2[i] - s[4]) <= tol_lam).all(), (name, variant, i)
+            worst = max(worst, (np.abs(lam2[i] - s[4]) / np.maximum(1, np.abs(s[4]))).max())
+        print(f"{name} {variant}: worst teacher-forced relative LLR error {worst:.2e} over {len(states)} turns")

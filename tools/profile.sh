@@ -9,7 +9,7 @@ set -o pipefail
 tag=$1; shift
 out=$PWD/gpurun_out/prof_$tag; mkdir -p $out
 export TMPDIR=/tmp
-args="--cpu-seconds 0 --steps 4 --warmup 2 $*"
+args="--cpu-seconds 0 --proof 0 --steps 4 --warmup 2 $*"
 echo "[profile] kernel trace" >&2
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt -o kt -- python3 bench.py $args > $out/${tag}_bench_under_rocprof.json 2> $out/kt.log || { tail -5 $out/kt.log; exit 1; }
 cp $(find $out/kt -name '*kernel_stats.csv' | head -1) $out/${tag}_kernel_stats.csv

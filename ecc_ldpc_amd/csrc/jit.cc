@@ -327,7 +327,9 @@ const char *choose_plan(const ldpc_code &c, int variant, PlanChoice &p) {
     int msgs = 0;
     { std::vector<int> m(p.np, 0); for (int br = 0; br < p.nbr; br++) m[p.own[br]] += p.deg[br]; msgs = *std::max_element(m.begin(), m.end()); }
     const int norig = (p.nbc + p.np - 1) / p.np + 2;
-    const int est = msgs + norig + (variant == LDPC_TANH ? 3 * p.dmax + 24 : p.dmax + 28);
+    // (calibrated on the shipped AR4JA instances: 78 messages + 24 LLRs run best at 4 waves/SIMD for min-sum -- 128 VGPRs,
+    //  ~30 spilled -- and at 3 for the tanh rule, which keeps ~3 transient registers per edge of a row)
+    const int est = msgs + norig + (variant == LDPC_TANH ? 3 * p.dmax + 10 : 24);
     int w = est <= 64 ? 8 : est <= 80 ? 6 : est <= 96 ? 5 : est <= 128 ? 4 : est <= 168 ? 3 : 2;
     const int threads = p.np * p.v;
     const int wg_per_cu = (int)std::max<size_t>(1, (160 * 1024) / lds);

@@ -1,7 +1,8 @@
 """GPU: the TABLE-DRIVEN instances of the fused QC kernels (fused_msg.hip `DynTab`, every circulant size the
-library compiles: 32, 64, 128) against the CPU oracle.  The shipped matrices normally run kernels with compile-time
-rotation tables; any other matrix with the AR4JA rate-4/5 block structure (the reference's QC decoders take any
-single-circulant .q: src/ECC/Code/LDPC/Fast/Arraylet.hs:68-79) reads its rotations from memory.  Covered here:
+library compiles: 32, 64, 128) against the CPU oracle.  The shipped matrices run kernels with compile-time
+rotation tables and any other QC matrix gets such a kernel from the run-time compiler (tests/test_jit.py); with
+that switched off (LDPC_JIT=0, or no hiprtc on the machine) a matrix with the AR4JA rate-4/5 block structure falls
+back to a two-wave kernel that reads its rotations from memory -- and f64 (parity mode) always does.  Covered here:
   * synthetic codes: the block structure of codes/jpl.1024.4.5 with RANDOM rotations, sz = 32 / 64 / 128,
     f32 (min-sum, tanh) and f64 (min-sum): hard bits, flags, per-turn LLRs (f32 <= 1e-5 teacher-forced, f64 bit-exact);
   * the shipped codes forced onto the table-driven kernel (LDPC_FUSED_TABLE=dyn): identical to their
@@ -38,7 +39,8 @@ def frames(g, sz, F, dbs, seed):
 
 
 @pytest.mark.parametrize("sz", [32, 64, 128])
-def test_synthetic_rotations_f32(hip, sz):
+def test_synthetic_rotations_f32(hip, sz, monkeypatch):
+    monkeypatch.setenv("LDPC_JIT", "0")     # the table-driven kernels are what runs when the run-time compiler is off / absent
     off, g = synthetic_ar4ja(sz, 1000 + sz)
     code = hip.Code.from_qc(sz, off)
     F = 48 if sz < 128 else 24
@@ -57,7 +59,8 @@ def test_synthetic_rotations_f32(hip, sz):
 
 
 @pytest.mark.parametrize("sz", [32, 64, 128])
-def test_synthetic_rotations_teacher_forced_and_f64(hip, sz):
+def test_synthetic_rotations_teacher_forced_and_f64(hip, sz, monkeypatch):
+    monkeypatch.setenv("LDPC_JIT", "0")
     off, g = synthetic_ar4ja(sz, 3000 + sz)
     code = hip.Code.from_qc(sz, off)
     llr = frames(g, sz, 6, (3.0, 4.0), 4000 + sz)
@@ -72,6 +75,7 @@ def test_synthetic_rotations_teacher_forced_and_f64(hip, sz):
     # f32: one teacher-forced turn from oracle states, both rules, <= 1e-5 (+ the oracle's own conditioning term for tanh)
     for variant in ("min", "tanh"):
         dec = hip.Decoder(code, variant, "f32", 64, path="fused")
+        assert "fused_msg_kernel" in dec.kernel_name
         states = []
         for f in range(len(llr)):
             o = oracle.decode(g, variant, 30, llr[f], trace=True)

@@ -52,7 +52,7 @@ def test_hiprtc_compiles_without_a_gpu_and_caches(name):
         kname, cached, sec = code.jit_prepare(variant)
         assert kname.startswith("ldpc_jit_split_") and f"sz{synthetic(name).sz}" in kname
         path = [f for f in os.listdir(E.lib().ldpc_jit_cache_dir().decode()) if f.startswith(kname)]
-        assert len(path) == 1 and path[0].endswith(".hsaco")
+        assert len(path) >= 1 and all(f.endswith(".hsaco") for f in path)   # (one per version of the device headers)
         k2, cached2, _ = code.jit_prepare(variant)
         assert k2 == kname and cached2
 

@@ -1,8 +1,8 @@
 // jit.cc -- run-time specialisation of the fused quasi-cyclic split kernel (see jit.h).
 //   source   : generated plan + rotation table + one extern "C" kernel around split_kernel_body (fused_split_body.h);
 //              the device headers are embedded in the library at build time (jit_embed.inc, build.py)
-//   compiler : hiprtc, dlopen'ed (so the library has no link-time dependency on it and binds to the copy that belongs
-//              to the HIP runtime already in the process); LDPC_JIT_COMPILER=hipcc runs `hipcc --genco` instead
+//   compiler : `hipcc --genco` in a child process when the tool chain is installed, else hiprtc in-process (dlopen'ed:
+//              no link-time dependency); LDPC_JIT_COMPILER=hipcc|hiprtc forces one.  See jit_compile_cached for why.
 //   cache    : <cache dir>/<hash of source + options>.hsaco, written atomically; LDPC_JIT_CACHE names the directory
 //              (default: jit_cache/ next to libldpc_hip.so if writable, else ~/.cache/ecc_ldpc_amd, else /tmp)
 #include "jit.h"
@@ -131,9 +131,11 @@ int compile_hiprtc(const std::string &source, std::vector<char> &co) {
     hiprtcProgram prog = nullptr;
     hiprtcResult rc = r.create(&prog, source.c_str(), "ldpc_jit.hip", (int)names.size(), texts.data(), names.data());
     if (rc != HIPRTC_SUCCESS) return set_error(LDPC_EHIP, "hiprtcCreateProgram: %s", r.err ? r.err(rc) : "error");
-    const char *opts[kNumOptions];
-    for (int i = 0; i < kNumOptions; i++) opts[i] = kOptions[i];
-    rc = r.compile(prog, kNumOptions, opts);
+    std::vector<const char *> opts(kOptions, kOptions + kNumOptions);
+    std::vector<std::string> extra;   // LDPC_JIT_EXTRA_OPTS: experiments (space separated; not part of the cache key)
+    if (const char *x = getenv("LDPC_JIT_EXTRA_OPTS")) { std::istringstream is(x); std::string t; while (is >> t) extra.push_back(t); }
+    for (auto &t : extra) opts.push_back(t.c_str());
+    rc = r.compile(prog, (int)opts.size(), opts.data());
     if (rc != HIPRTC_SUCCESS) {
         size_t n = 0;
         std::string log;
@@ -170,6 +172,21 @@ int compile_hipcc(const std::string &source, std::vector<char> &co) {
     if (!ok) return set_error(LDPC_EHIP, "hipcc --genco failed (%d): %s", rc, log.c_str());
     return LDPC_OK;
 }
+// `.vgpr_spill_count` of the (single) kernel in a code object, read from its msgpack metadata note; -1 if not found
+int spill_count(const std::vector<char> &co) {
+    static const char key[] = ".vgpr_spill_count";
+    const size_t kl = sizeof(key) - 1;
+    for (size_t i = 0; i + kl + 5 <= co.size(); i++) {
+        if (memcmp(&co[i], key, kl) != 0) continue;
+        const unsigned char *p = (const unsigned char *)&co[i + kl];
+        if (p[0] <= 0x7f) return p[0];
+        if (p[0] == 0xcc) return p[1];
+        if (p[0] == 0xcd) return (p[1] << 8) | p[2];
+        if (p[0] == 0xce) return (int)(((unsigned)p[1] << 24) | (p[2] << 16) | (p[3] << 8) | p[4]);
+        return -1;
+    }
+    return -1;
+}
 }  // namespace
 
 const char *jit_cache_dir() {
@@ -193,12 +210,24 @@ int jit_compile_cached(const std::string &source, const std::string &kernel_name
     }
     auto t0 = std::chrono::steady_clock::now();
     const char *which = getenv("LDPC_JIT_COMPILER");
-    int rc = (which && !strcmp(which, "hipcc")) ? compile_hipcc(source, co) : compile_hiprtc(source, co);
-    if (rc != LDPC_OK && !(which && !strcmp(which, "hiprtc")) && !(which && !strcmp(which, "hipcc"))) {
-        // hiprtc missing or failing: the tool chain, if there is one
-        std::string first = ldpc_last_error();
-        if (compile_hipcc(source, co) == LDPC_OK) rc = LDPC_OK;
-        else rc = set_error(LDPC_EHIP, "%s", first.c_str());
+    const bool only_hipcc = which && !strcmp(which, "hipcc"), only_hiprtc = which && !strcmp(which, "hiprtc");
+    // Two routes to the same code object.  The tool chain (`hipcc --genco`, a child process) comes first when it is
+    // installed: it is the compiler the built-in instances were built and tuned with, whereas the compiler behind
+    // hiprtc is whatever libamd_comgr the PROCESS has loaded -- inside Python that is the copy bundled with the torch
+    // wheel, an older LLVM than /opt/rocm's (measured on the jpl.4096-shaped kernel: 571 spilled VGPRs against 29,
+    // 4.8x slower).  Without a tool chain (run-time-only ROCm installs) hiprtc compiles in-process.
+    // LDPC_JIT_COMPILER=hipcc|hiprtc forces one route.
+    const char *hipcc_path = getenv("HIPCC") ? getenv("HIPCC") : "/opt/rocm/bin/hipcc";
+    const bool have_hipcc = access(hipcc_path, X_OK) == 0;
+    int rc;
+    if (only_hiprtc) rc = compile_hiprtc(source, co);
+    else if (only_hipcc) rc = compile_hipcc(source, co);
+    else {
+        rc = have_hipcc ? compile_hipcc(source, co) : compile_hiprtc(source, co);
+        if (rc != LDPC_OK && have_hipcc) {   // tool chain present but failing: the in-process compiler
+            std::string first = ldpc_last_error();
+            if (compile_hiprtc(source, co) != LDPC_OK) rc = set_error(LDPC_EHIP, "%s", first.c_str()); else rc = LDPC_OK;
+        }
     }
     if (seconds) *seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     if (rc != LDPC_OK) return rc;
@@ -414,8 +443,8 @@ JitKernel *jit_split_create(const ldpc_code &c, int variant, int dtype) {
             return nullptr;
         }
         if (const char *v = getenv("LDPC_JIT_VERBOSE"); v && !strcmp(v, "1"))
-            fprintf(stderr, "[ldpc jit] %s: %d threads/workgroup, %d wave groups, %d waves/SIMD, %s (%.1f s)\n", k->name.c_str(), k->threads, k->np,
-                    k->waves_per_eu, k->from_cache ? "from cache" : "compiled", k->compile_seconds);
+            fprintf(stderr, "[ldpc jit] %s: %d threads/workgroup, %d wave groups, %d waves/SIMD, %d spilled VGPRs, %s (%.1f s)\n", k->name.c_str(), k->threads,
+                    k->np, k->waves_per_eu, spill_count(co), k->from_cache ? "from cache" : "compiled", k->compile_seconds);
         return k;
     } catch (...) { delete k; set_error(LDPC_ENOMEM, "out of host memory"); return nullptr; }
 }

@@ -57,6 +57,32 @@ def test_hiprtc_compiles_without_a_gpu_and_caches(name):
         assert k2 == kname and cached2
 
 
+def test_both_compiler_routes_build_the_same_kernel(tmp_path, monkeypatch):
+    """hipcc --genco (a child process; default when the tool chain is installed) and hiprtc (in-process)"""
+    code = synthetic("small-2x4-sz32").hip_code(E)
+    names = {}
+    for route in ("hiprtc", "hipcc"):
+        monkeypatch.setenv("LDPC_JIT_COMPILER", route)
+        monkeypatch.setenv("LDPC_JIT_NOCACHE", "1")
+        names[route], cached, sec = code.jit_prepare("min")
+        assert not cached and sec > 0.5
+    assert names["hiprtc"] == names["hipcc"]
+
+
+@pytest.mark.gpu
+def test_a_hiprtc_compiled_kernel_runs_correctly(hip, tmp_path, monkeypatch):
+    """the in-process route end to end on the GPU (the other tests hit whatever the default route cached)"""
+    monkeypatch.setenv("LDPC_JIT_COMPILER", "hiprtc")
+    monkeypatch.setenv("LDPC_JIT_NOCACHE", "1")
+    c = synthetic("small-2x4-sz32")
+    _, llr = c.frames(32, 4.0, seed=5)
+    dec = hip.Decoder(c.hip_code(hip), "min", "f32", 32)
+    assert dec.kernel_name.startswith("ldpc_jit_split_")
+    bits, its, conv = dec.decode_batch(llr.astype(np.float32), 30)
+    ob, oi, oc = oracle.decode_batch(c.graph, "min", 30, llr, nthreads=4)
+    assert np.array_equal(bits, ob) and np.array_equal(conv, oc) and np.array_equal(its, oi)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", SYNTHETIC_NAMES)
 def test_jit_kernels_match_the_oracle(hip, name):

@@ -41,6 +41,7 @@ def main():
     ap.add_argument("--ebn0", type=float, default=2.0)
     ap.add_argument("--batch", type=int, default=65536, help="frames per GPU per step")
     ap.add_argument("--path", default="auto", choices=["auto", "flood", "fused"])
+    ap.add_argument("--schedule", default="flooding", choices=["flooding", "layered"], help="layered: extension (BASELINE configs[4])")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the cpu_baseline sample (0 = skip)")
     ap.add_argument("--seed", type=lambda s: int(s, 0), default=0x5EEDC0DE)
     ap.add_argument("--proof", type=int, default=1, help="0: skip the untimed proof-of-work sample (tools/profile.sh does, so that the "
@@ -77,7 +78,7 @@ def main():
     E.init(dev_index)
 
     suffix = "" if args.dtype == "f32" else "-" + args.dtype
-    name = f"ldpc/hip-{args.variant}{suffix}/{args.code}/{args.iters}"
+    name = f"ldpc/hip-{args.variant}{'-layered' if args.schedule == 'layered' else ''}{suffix}/{args.code}/{args.iters}"
     if args.rate not in ("", "none"):
         x, y = args.rate.split("/")
         name += f"/{x}/{y}"

@@ -17,10 +17,16 @@ OK, EINVAL, ENOMEM, EHIP, ENODEVICE, EUNSUPPORTED, EDEGREE, EFORMAT, ENOTFOUND =
 TANH, MINSUM = 0, 1
 F32, F64, F16 = 0, 1, 2
 PATH_AUTO, PATH_FLOOD, PATH_FUSED = 0, 1, 2
+SCHED_FLOODING, SCHED_LAYERED = 0, 1
+
+
+class CtxConfig(C.Structure):   # ldpc_ctx_config
+    _fields_ = [("struct_size", C.c_size_t), ("device", C.c_int), ("variant", C.c_int), ("dtype", C.c_int), ("max_batch", C.c_int),
+                ("path", C.c_int), ("schedule", C.c_int)]
 
 # every symbol include/ldpc_hip.h declares (tests/test_abi.py checks the library exports them all)
 ABI_SYMBOLS = [
-    "ldpc_init", "ldpc_shutdown", "ldpc_current_device", "ldpc_ctx_create_on", "ldpc_sim_create_on", "ldpc_last_error", "ldpc_last_error_code", "ldpc_abi_version", "ldpc_device_count",
+    "ldpc_init", "ldpc_shutdown", "ldpc_current_device", "ldpc_ctx_create_on", "ldpc_sim_create_on", "ldpc_ctx_create_cfg", "ldpc_ctx_schedule", "ldpc_code_set_layers", "ldpc_code_layers", "ldpc_last_error", "ldpc_last_error_code", "ldpc_abi_version", "ldpc_device_count",
     "ldpc_code_create_qc", "ldpc_code_create_csr", "ldpc_code_destroy", "ldpc_code_dims", "ldpc_code_csr",
     "ldpc_ctx_create", "ldpc_ctx_create_ex", "ldpc_ctx_destroy", "ldpc_ctx_path", "ldpc_ctx_synchronize",
     "ldpc_decode_one", "ldpc_decode_batch", "ldpc_decode_batch_f64", "ldpc_decode_batch_dev",
@@ -148,6 +154,11 @@ def lib():
     L.ldpc_ctx_create_ex.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int]
     L.ldpc_ctx_create_on.restype = vp
     L.ldpc_ctx_create_on.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
+    L.ldpc_ctx_create_cfg.restype = vp
+    L.ldpc_ctx_create_cfg.argtypes = [vp, C.POINTER(CtxConfig)]
+    L.ldpc_ctx_schedule.argtypes = [vp]
+    L.ldpc_code_set_layers.argtypes = [vp, C.c_int, i32p]
+    L.ldpc_code_layers.argtypes = [vp, ip, i32p]
     L.ldpc_sim_create_on.restype = vp
     L.ldpc_sim_create_on.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, u8p, C.c_int]
     L.ldpc_ctx_destroy.restype = None
@@ -261,6 +272,7 @@ def init(device: int = 0):
 _VARIANTS = {"tanh": TANH, "min": MINSUM, "minsum": MINSUM, "min-sum": MINSUM, TANH: TANH, MINSUM: MINSUM}
 _DTYPES = {"f32": F32, "f64": F64, "f16": F16, F32: F32, F64: F64, F16: F16}
 _PATHS = {"auto": PATH_AUTO, "flood": PATH_FLOOD, "fused": PATH_FUSED, 0: 0, 1: 1, 2: 2}
+_SCHEDULES = {"flooding": SCHED_FLOODING, "flood": SCHED_FLOODING, "layered": SCHED_LAYERED, 0: 0, 1: 1}
 
 
 class Code:
@@ -303,6 +315,17 @@ class Code:
         check(lib().ldpc_code_csr(self._h, ptr(rp, C.c_int32), ptr(ci, C.c_int32)))
         return rp, ci
 
+    def set_layers(self, layer_ptr):
+        lp = np.ascontiguousarray(layer_ptr, dtype=np.int32)
+        check(lib().ldpc_code_set_layers(self._h, len(lp) - 1, ptr(lp, C.c_int32)))
+
+    def layers(self):
+        n = C.c_int()
+        check(lib().ldpc_code_layers(self._h, C.byref(n), None))
+        lp = np.zeros(n.value + 1, np.int32)
+        check(lib().ldpc_code_layers(self._h, C.byref(n), ptr(lp, C.c_int32)))
+        return lp
+
     def jit_source(self, variant="min", dtype="f32") -> str:
         """the translation unit the run-time compiler would be given for this code (LdpcError -5 if there is none)"""
         n = lib().ldpc_jit_source(self._h, _VARIANTS[variant], _DTYPES[dtype], None, 0)
@@ -340,20 +363,23 @@ class Code:
 class Decoder:
     """One decoder replica (ldpc_ctx): the object behind the reference's per-frame closure."""
 
-    def __init__(self, code: Code, variant="min", dtype="f32", max_batch=64, path="auto", _handle=None, device=None):
+    def __init__(self, code: Code, variant="min", dtype="f32", max_batch=64, path="auto", _handle=None, device=None, schedule="flooding"):
         self.code = code
         self.max_batch = int(max_batch)
         self._owned = _handle is None
         if _handle is not None:
             self._h = _handle
-        elif device is None:
+        elif device is None and _SCHEDULES[schedule] == SCHED_FLOODING:
             self._h = lib().ldpc_ctx_create_ex(code._h, _VARIANTS[variant], _DTYPES[dtype], int(max_batch), _PATHS[path])
-        else:   # explicit device: replicas of one code on several GPUs of this process
-            self._h = lib().ldpc_ctx_create_on(code._h, int(device), _VARIANTS[variant], _DTYPES[dtype], int(max_batch), _PATHS[path])
+        else:   # explicit device (replicas of one code on several GPUs of this process) and/or the layered schedule
+            cfg = CtxConfig(C.sizeof(CtxConfig), -1 if device is None else int(device), _VARIANTS[variant], _DTYPES[dtype], int(max_batch),
+                            _PATHS[path], _SCHEDULES[schedule])
+            self._h = lib().ldpc_ctx_create_cfg(code._h, C.byref(cfg))
         if not self._h:
             raise LdpcError(lib().ldpc_last_error_code(), last_error())
         _register(self)
         self.path = {PATH_FLOOD: "flood", PATH_FUSED: "fused"}[lib().ldpc_ctx_path(self._h)]
+        self.schedule = {SCHED_FLOODING: "flooding", SCHED_LAYERED: "layered"}[lib().ldpc_ctx_schedule(self._h)]
 
     def decode_one(self, llr, max_iters):
         llr = np.ascontiguousarray(llr, np.float64)

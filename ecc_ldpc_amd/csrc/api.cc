@@ -1,6 +1,7 @@
 // api.cc -- the C ABI of include/ldpc_hip.h: graph objects, decoder replicas, host<->device plumbing.
 // No C++ exception leaves this file; every failure becomes an LDPC_E* code + thread-local message.
 #include <stdarg.h>
+#include <stddef.h>
 #include <stdio.h>
 #include <string.h>
 
@@ -46,7 +47,7 @@ using ldpc::set_error;
 
 struct ldpc_ctx {
     const ldpc_code *code = nullptr;
-    int variant = 0, dtype = 0, max_batch = 0, Bp = 0, path = LDPC_PATH_FLOOD, device = 0;
+    int variant = 0, dtype = 0, max_batch = 0, Bp = 0, path = LDPC_PATH_FLOOD, device = 0, schedule = LDPC_SCHED_FLOODING;
     hipStream_t stream = nullptr;
     ldpc::FloodState flood;
     ldpc::FusedState *fused = nullptr;
@@ -164,6 +165,10 @@ static int finish_code(ldpc_code *c) {
         c->max_col_deg = std::max(c->max_col_deg, c->col_ptr[j + 1]);
         c->col_ptr[j + 1] += c->col_ptr[j];
     }
+    // default layers: block rows of a QC code (column-disjoint: one circulant per block), single rows otherwise
+    c->layer_ptr.clear();
+    if (c->sz > 0) for (int br = 0; br <= c->block_rows; br++) c->layer_ptr.push_back(br * c->sz);
+    else for (int m = 0; m <= c->M; m++) c->layer_ptr.push_back(m);
     c->csc_edge.assign((size_t)c->E, 0);
     std::vector<int32_t> fill(c->col_ptr.begin(), c->col_ptr.end() - 1);
     for (int m = 0; m < c->M; m++)
@@ -260,6 +265,35 @@ int ldpc_code_dims(const ldpc_code *code, int *M, int *N, int *E) {
     return LDPC_OK;
 }
 
+int ldpc_code_set_layers(ldpc_code *code, int n_layers, const int32_t *layer_ptr) {
+    if (!code || n_layers <= 0 || !layer_ptr) return set_error(LDPC_EINVAL, "ldpc_code_set_layers: bad arguments");
+    {
+        std::lock_guard<std::mutex> lk(code->dev_mu);
+        if (!code->dev.empty()) return set_error(LDPC_EINVAL, "ldpc_code_set_layers: the code already has decoder contexts");
+    }
+    if (layer_ptr[0] != 0 || layer_ptr[n_layers] != code->M) return set_error(LDPC_EINVAL, "layers must cover rows 0..%d", code->M);
+    try {
+        std::vector<int32_t> seen((size_t)code->N, -1);
+        for (int l = 0; l < n_layers; l++) {
+            if (layer_ptr[l + 1] <= layer_ptr[l]) return set_error(LDPC_EINVAL, "layer %d is empty or out of order", l);
+            for (int m = layer_ptr[l]; m < layer_ptr[l + 1]; m++)
+                for (int q = code->row_ptr[m]; q < code->row_ptr[m + 1]; q++) {
+                    if (seen[code->col_idx[q]] == l) return set_error(LDPC_EINVAL, "rows of layer %d share column %d", l, code->col_idx[q]);
+                    seen[code->col_idx[q]] = l;
+                }
+        }
+        code->layer_ptr.assign(layer_ptr, layer_ptr + n_layers + 1);
+    } catch (...) { return set_error(LDPC_ENOMEM, "out of host memory"); }
+    return LDPC_OK;
+}
+
+int ldpc_code_layers(const ldpc_code *code, int *n_layers, int32_t *layer_ptr) {
+    if (!code) return set_error(LDPC_EINVAL, "null code");
+    if (n_layers) *n_layers = (int)code->layer_ptr.size() - 1;
+    if (layer_ptr) memcpy(layer_ptr, code->layer_ptr.data(), sizeof(int32_t) * code->layer_ptr.size());
+    return LDPC_OK;
+}
+
 int ldpc_code_csr(const ldpc_code *code, int32_t *row_ptr, int32_t *col_idx) {
     if (!code || !row_ptr || !col_idx) return set_error(LDPC_EINVAL, "null argument");
     memcpy(row_ptr, code->row_ptr.data(), sizeof(int32_t) * ((size_t)code->M + 1));
@@ -298,6 +332,7 @@ void ldpc_ctx_destroy(ldpc_ctx *ctx) {
     ldpc::flood_graph_release(ctx->flood);
     hipFree(ctx->flood.msg); hipFree(ctx->flood.scratch); hipFree(ctx->flood.lam); hipFree(ctx->flood.orig);
     hipFree(ctx->flood.dev.unsat); hipFree(ctx->flood.dev.iters); hipFree(ctx->flood.dev.conv); hipFree(ctx->flood.dev.done);
+    (void)hipFree(ctx->flood.d_layer_ptr);
     for (int i = 1; i < ldpc_ctx::kSlots; i++) if (ctx->pstream[i]) hipStreamSynchronize(ctx->pstream[i]);
     for (int i = 0; i < ldpc_ctx::kSlots; i++) { hipFree(ctx->d_in[i]); hipFree(ctx->d_bits[i]); hipFree(ctx->d_iters[i]); hipFree(ctx->d_conv[i]); hipFree(ctx->d_final[i]); }
     for (int i = 1; i < ldpc_ctx::kSlots; i++) if (ctx->pstream[i]) hipStreamDestroy(ctx->pstream[i]);
@@ -312,16 +347,24 @@ void ldpc_ctx_destroy(ldpc_ctx *ctx) {
 }
 
 ldpc_ctx *ldpc_ctx_create_ex(const ldpc_code *code, int variant, int dtype, int max_batch, int path) {
-    const int device = current_device();
-    if (device < 0) {
-        set_error(LDPC_ENODEVICE, "ldpc_init() has not succeeded: no GPU bound (there is no CPU fallback)");
-        return nullptr;
-    }
-    return ldpc_ctx_create_on(code, device, variant, dtype, max_batch, path);
+    return ldpc_ctx_create_on(code, -1, variant, dtype, max_batch, path);   // -1: the calling thread's device
 }
 
-ldpc_ctx *ldpc_ctx_create_on(const ldpc_code *code_c, int device, int variant, int dtype, int max_batch, int path) {
+ldpc_ctx *ldpc_ctx_create_on(const ldpc_code *code, int device, int variant, int dtype, int max_batch, int path) {
+    ldpc_ctx_config cfg{};
+    cfg.struct_size = sizeof(cfg); cfg.device = device; cfg.variant = variant; cfg.dtype = dtype; cfg.max_batch = max_batch; cfg.path = path;
+    cfg.schedule = LDPC_SCHED_FLOODING;
+    return ldpc_ctx_create_cfg(code, &cfg);
+}
+
+int ldpc_ctx_schedule(const ldpc_ctx *ctx) { return ctx ? ctx->schedule : set_error(LDPC_EINVAL, "null ctx"); }
+
+ldpc_ctx *ldpc_ctx_create_cfg(const ldpc_code *code_c, const ldpc_ctx_config *cfg) {
+    if (!cfg || cfg->struct_size < offsetof(ldpc_ctx_config, schedule)) { set_error(LDPC_EINVAL, "ldpc_ctx_create_cfg: bad config"); return nullptr; }
     ldpc_code *code = const_cast<ldpc_code *>(code_c);
+    const int variant = cfg->variant, dtype = cfg->dtype, max_batch = cfg->max_batch, path = cfg->path;
+    const int schedule = cfg->struct_size >= sizeof(ldpc_ctx_config) ? cfg->schedule : LDPC_SCHED_FLOODING;
+    if (schedule != LDPC_SCHED_FLOODING && schedule != LDPC_SCHED_LAYERED) { set_error(LDPC_EINVAL, "unknown schedule %d", schedule); return nullptr; }
     if (!code || max_batch <= 0 || (variant != LDPC_TANH && variant != LDPC_MINSUM) ||
         (dtype != LDPC_F32 && dtype != LDPC_F64 && dtype != LDPC_F16) ||
         (path != LDPC_PATH_AUTO && path != LDPC_PATH_FLOOD && path != LDPC_PATH_FUSED)) {
@@ -332,21 +375,29 @@ ldpc_ctx *ldpc_ctx_create_on(const ldpc_code *code_c, int device, int variant, i
         set_error(LDPC_EDEGREE, "min-sum on a check row of degree 1 (the reference's foldr1 min' fails on [], Min.hs:79)");
         return nullptr;
     }
+    int device = cfg->device;
+    if (device < 0) device = current_device();
+    if (device < 0) { set_error(LDPC_ENODEVICE, "ldpc_init() has not succeeded: no GPU bound (there is no CPU fallback)"); return nullptr; }
     if (check_device(device) != LDPC_OK) return nullptr;
     HIPCHK_NULL(hipSetDevice(device));
     ldpc_code_dev tabs;
     if (code_upload(code, device, &tabs) != LDPC_OK) return nullptr;
 
-    const bool fused_ok = ldpc::fused_supported(*code, variant, dtype);
+    if (schedule == LDPC_SCHED_LAYERED) {
+        if (dtype == LDPC_F16) { set_error(LDPC_EUNSUPPORTED, "the layered schedule exists for f32 and f64"); return nullptr; }
+        if (code->max_row_deg > 32) { set_error(LDPC_EUNSUPPORTED, "layered schedule: check rows above weight 32 (this code has %d)", code->max_row_deg); return nullptr; }
+    }
+    const bool fused_ok = schedule == LDPC_SCHED_FLOODING && ldpc::fused_supported(*code, variant, dtype);
     if (path == LDPC_PATH_FUSED && !fused_ok) {
+        if (schedule == LDPC_SCHED_LAYERED) { set_error(LDPC_EUNSUPPORTED, "no on-chip kernel for the layered schedule (state lives in HBM: LDPC_PATH_FLOOD)"); return nullptr; }
         set_error(LDPC_EUNSUPPORTED, "no fused kernel for this code/variant/dtype (%s)", ldpc::fused_why_not(*code, variant, dtype));
         return nullptr;
     }
     ldpc_ctx *ctx = new (std::nothrow) ldpc_ctx();
     if (!ctx) { set_error(LDPC_ENOMEM, "out of host memory"); return nullptr; }
-    ctx->code = code; ctx->variant = variant; ctx->dtype = dtype; ctx->max_batch = max_batch; ctx->device = device;
+    ctx->code = code; ctx->variant = variant; ctx->dtype = dtype; ctx->max_batch = max_batch; ctx->device = device; ctx->schedule = schedule;
     ctx->Bp = (max_batch + 63) / 64 * 64;
-    ctx->path = (path == LDPC_PATH_AUTO) ? (ldpc::fused_preferred(*code, variant, dtype) ? LDPC_PATH_FUSED : LDPC_PATH_FLOOD) : path;
+    ctx->path = (path == LDPC_PATH_AUTO) ? ((fused_ok && ldpc::fused_preferred(*code, variant, dtype)) ? LDPC_PATH_FUSED : LDPC_PATH_FLOOD) : path;
 
 #define CTX_HIP(x)                                                       \
     do {                                                                 \
@@ -388,6 +439,13 @@ ldpc_ctx *ldpc_ctx_create_on(const ldpc_code *code_c, int device, int variant, i
         CTX_HIP(hipMalloc((void **)&d.iters, sizeof(int32_t) * Bp));
         CTX_HIP(hipMalloc((void **)&d.conv, Bp));
         CTX_HIP(hipMalloc((void **)&d.done, Bp));
+        if (schedule == LDPC_SCHED_LAYERED) {
+            ctx->flood.layered = true;
+            ctx->flood.n_layers = (int)code->layer_ptr.size() - 1;
+            ctx->flood.max_row_deg = code->max_row_deg;
+            CTX_HIP(hipMalloc((void **)&ctx->flood.d_layer_ptr, sizeof(int32_t) * code->layer_ptr.size()));
+            CTX_HIP(hipMemcpy(ctx->flood.d_layer_ptr, code->layer_ptr.data(), sizeof(int32_t) * code->layer_ptr.size(), hipMemcpyHostToDevice));
+        }
     } else {
         ctx->fused = ldpc::fused_create(*code, variant, dtype, max_batch);
         if (!ctx->fused) { ldpc_ctx_destroy(ctx); return nullptr; }
@@ -695,7 +753,7 @@ int ldpc_ctx_kernel_time(ldpc_ctx *ctx, int *launches, double *total_ms) {
 const char *ldpc_ctx_kernel_name(const ldpc_ctx *ctx) {
     if (!ctx) return "";
     if (ctx->path == LDPC_PATH_FUSED && ctx->fused) return ldpc::fused_kernel_name(*ctx->fused);
-    return "flood_cn_kernel";
+    return ctx->schedule == LDPC_SCHED_LAYERED ? "layered_kernel" : "flood_cn_kernel";
 }
 
 int ldpc_ctx_kernel_geometry(const ldpc_ctx *ctx, int *threads_per_workgroup, int *frames_per_workgroup) {

@@ -423,6 +423,191 @@ __global__ void syndrome_flags_kernel(FloodDev d, uint8_t *out, int batch, int s
     if (b < batch) out[b] = d.unsat[b] != stamp ? 1 : 0;
 }
 
+// ==================================================================== row-layered schedule (extension)
+// BASELINE.json configs[4]: "layered min-sum + early termination" on codes whose frame does not fit on-chip (a
+// DVB-S2-class n = 64 800 code keeps 253 KB of LLRs alone).  No counterpart in the reference; the specification is
+// oracle_decode_layered (oracle/ldpc_oracle.c) and the arithmetic per row is the flooding rule's.
+//
+// Same batch-major layout as above (lane = codeword, scalar graph indices), but ONE persistent workgroup of LW waves
+// owns a 64-frame slab for the whole decode: layers run one after the other, the rows of a layer (column-disjoint by
+// construction: a block row of a single-circulant QC code) are dealt round-robin to the waves, a workgroup barrier
+// separates the layers.  No launch per turn, no grid-wide synchronisation: slabs are independent.  Stopping rule of
+// the specification, per frame: before the first sweep, syndrome(hard lam) == 0; after a sweep, "no check it saw was
+// odd and no hard decision changed".  Finished frames freeze (their lanes stop storing); a workgroup leaves when its
+// 64 frames are finished or out of sweeps.
+// HBM traffic per frame and sweep: every edge reads and writes its lam cell and its message: 4E * sizeof(ST).
+struct LayerDev {
+    int n_layers;
+    const int32_t *layer_ptr;   // [n_layers + 1] row ranges
+};
+struct LayerArgs {
+    int max_iters, step_mode;
+    double *trace;              // may be null: [batch][max_iters + 1][N], lam after sweep n at row n
+    int batch;
+};
+constexpr int kLayerWaves = 16;
+
+template <typename ST, int VARIANT, int DEG, bool SYNDROME_ONLY>
+__device__ __forceinline__ void layer_row_regs(const FloodDev &d, ST *__restrict__ msg, ST *__restrict__ lam, int ebeg, size_t b,
+                                               bool active, bool &odd, bool &flip) {
+    using CT = typename Store<ST>::CT;
+    int col[DEG];
+#pragma unroll
+    for (int k = 0; k < DEG; k++) col[k] = d.col_idx[ebeg + k];
+    CT l[DEG], t[DEG];
+#pragma unroll
+    for (int k = 0; k < DEG; k++) l[k] = Store<ST>::ld(lam + (size_t)col[k] * d.Bp + b);
+    if constexpr (!SYNDROME_ONLY) {
+#pragma unroll
+        for (int k = 0; k < DEG; k++) t[k] = Store<ST>::ld(msg + (size_t)(ebeg + k) * d.Bp + b);
+    }
+    bool par = false;
+#pragma unroll
+    for (int k = 0; k < DEG; k++) par ^= hard(l[k]);
+    odd |= par && active;
+    if constexpr (SYNDROME_ONLY) return;
+    CT nm[DEG];
+#pragma unroll
+    for (int k = 0; k < DEG; k++) { t[k] = l[k] - t[k]; nm[k] = t[k]; }
+    cn_update<CT, VARIANT, DEG>(nm);
+#pragma unroll
+    for (int k = 0; k < DEG; k++) {
+        const CT nw = t[k] + nm[k];
+        flip |= active && (hard(nw) != hard(l[k]));
+        if (active) {
+            Store<ST>::st(lam + (size_t)col[k] * d.Bp + b, nw);
+            Store<ST>::st(msg + (size_t)(ebeg + k) * d.Bp + b, nm[k]);
+        }
+    }
+}
+
+template <typename ST, int VARIANT, int DMAX, bool SYNDROME_ONLY>
+__device__ __forceinline__ void layer_row_padded(const FloodDev &d, ST *__restrict__ msg, ST *__restrict__ lam, int ebeg, int deg,
+                                                 size_t b, bool active, bool &odd, bool &flip) {
+    using CT = typename Store<ST>::CT;
+    int col[DMAX];
+#pragma unroll
+    for (int k = 0; k < DMAX; k++) col[k] = (k < deg) ? d.col_idx[ebeg + k] : 0;
+    CT l[DMAX], t[DMAX];
+#pragma unroll
+    for (int k = 0; k < DMAX; k++) l[k] = (k < deg) ? Store<ST>::ld(lam + (size_t)col[k] * d.Bp + b) : CT(0);
+    if constexpr (!SYNDROME_ONLY) {
+#pragma unroll
+        for (int k = 0; k < DMAX; k++) t[k] = (k < deg) ? Store<ST>::ld(msg + (size_t)(ebeg + k) * d.Bp + b) : CT(0);
+    }
+    bool par = false;
+#pragma unroll
+    for (int k = 0; k < DMAX; k++) par ^= (k < deg) && hard(l[k]);
+    odd |= par && active;
+    if constexpr (SYNDROME_ONLY) return;
+    CT nm[DMAX];
+#pragma unroll
+    for (int k = 0; k < DMAX; k++) { t[k] = (k < deg) ? l[k] - t[k] : CT(INFINITY); nm[k] = t[k]; }
+    cn_update_padded<CT, VARIANT, DMAX>(nm, deg);
+#pragma unroll
+    for (int k = 0; k < DMAX; k++) {
+        if (k < deg) {
+            const CT nw = t[k] + nm[k];
+            flip |= active && (hard(nw) != hard(l[k]));
+            if (active) {
+                Store<ST>::st(lam + (size_t)col[k] * d.Bp + b, nw);
+                Store<ST>::st(msg + (size_t)(ebeg + k) * d.Bp + b, nm[k]);
+            }
+        }
+    }
+}
+
+// DCLASS: the widest row the instance holds in registers (8, 20 or 32): the code's maximum row weight picks it, so a
+// code of light rows is not compiled against the register count of 32-edge rows
+template <typename ST, int VARIANT, int DCLASS, bool SO>
+__device__ __forceinline__ void layer_row(const FloodDev &d, ST *msg, ST *lam, int row, size_t b, bool active, bool &odd, bool &flip) {
+    const int ebeg = d.row_ptr[row];
+    const int deg = d.row_ptr[row + 1] - ebeg;
+    switch (deg) {
+        case 0: return;
+        case 1:
+            if constexpr (VARIANT == LDPC_V_TANH) layer_row_regs<ST, VARIANT, 1, SO>(d, msg, lam, ebeg, b, active, odd, flip);
+            else layer_row_regs<ST, LDPC_V_TANH, 1, true>(d, msg, lam, ebeg, b, active, odd, flip);   // min-sum on weight 1: rejected at creation
+            return;
+        case 2: layer_row_regs<ST, VARIANT, 2, SO>(d, msg, lam, ebeg, b, active, odd, flip); return;
+        case 3: layer_row_regs<ST, VARIANT, 3, SO>(d, msg, lam, ebeg, b, active, odd, flip); return;
+        case 4: layer_row_regs<ST, VARIANT, 4, SO>(d, msg, lam, ebeg, b, active, odd, flip); return;
+        case 5: layer_row_regs<ST, VARIANT, 5, SO>(d, msg, lam, ebeg, b, active, odd, flip); return;
+        case 6: layer_row_regs<ST, VARIANT, 6, SO>(d, msg, lam, ebeg, b, active, odd, flip); return;
+        case 7: layer_row_regs<ST, VARIANT, 7, SO>(d, msg, lam, ebeg, b, active, odd, flip); return;
+        case 8: layer_row_regs<ST, VARIANT, 8, SO>(d, msg, lam, ebeg, b, active, odd, flip); return;
+        default: break;
+    }
+    if constexpr (DCLASS >= 20) {
+        if (deg == 18) { layer_row_regs<ST, VARIANT, 18, SO>(d, msg, lam, ebeg, b, active, odd, flip); return; }
+        if (deg <= 12) { layer_row_padded<ST, VARIANT, 12, SO>(d, msg, lam, ebeg, deg, b, active, odd, flip); return; }
+        if (deg <= 16) { layer_row_padded<ST, VARIANT, 16, SO>(d, msg, lam, ebeg, deg, b, active, odd, flip); return; }
+        if (deg <= 20) { layer_row_padded<ST, VARIANT, 20, SO>(d, msg, lam, ebeg, deg, b, active, odd, flip); return; }
+    }
+    if constexpr (DCLASS >= 32) {
+        if (deg <= 24) { layer_row_padded<ST, VARIANT, 24, SO>(d, msg, lam, ebeg, deg, b, active, odd, flip); return; }
+        if (deg <= 32) { layer_row_padded<ST, VARIANT, 32, SO>(d, msg, lam, ebeg, deg, b, active, odd, flip); return; }
+    }
+}
+
+template <typename ST, int VARIANT, int DCLASS>
+__global__ __launch_bounds__(kWave *kLayerWaves) void layered_kernel(FloodDev d, LayerDev L, ST *msg, ST *lam, LayerArgs A) {
+    using CT = typename Store<ST>::CT;
+    __shared__ uint32_t flags[kLayerWaves][kWave];   // bit 0: odd, bit 1: flip -- per wave, per frame of the slab
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const size_t b = (size_t)blockIdx.x * kWave + lane;
+    bool done = d.done[b] != 0;        // padding frames are born finished (flood_reset_kernel)
+    bool conv = false;
+    int iters = 0;
+    // OR of a per-lane flag pair over the waves of the workgroup (every wave holds the same 64 frames)
+    auto combine = [&](bool odd, bool flip) -> uint32_t {
+        flags[wave][lane] = (odd ? 1u : 0u) | (flip ? 2u : 0u);
+        __syncthreads();
+        uint32_t f = 0;
+#pragma unroll
+        for (int w = 0; w < kLayerWaves; w++) f |= flags[w][lane];
+        __syncthreads();               // the flags are rewritten by the next combine
+        return f;
+    };
+    auto store_trace = [&](int n, bool open) {
+        if (!A.trace) return;
+        if (open && b < (size_t)A.batch)
+            for (int c = wave; c < d.N; c += kLayerWaves)
+                A.trace[((size_t)b * (A.max_iters + 1) + n) * d.N + c] = (double)Store<ST>::ld(lam + (size_t)c * d.Bp + b);
+    };
+    if (!A.step_mode) {
+        store_trace(0, !done);
+        bool odd = false, flip = false;
+        for (int r = wave; r < d.M; r += kLayerWaves) layer_row<ST, VARIANT, DCLASS, true>(d, msg, lam, r, b, !done, odd, flip);
+        const uint32_t f = combine(odd, false);
+        if (!done && !(f & 1u)) { done = true; conv = true; iters = 0; }
+    }
+    for (int n = 1; n <= A.max_iters; n++) {
+        if (__all(done)) break;        // same decision in every wave: `done` derives from the shared flags
+        const bool open = !done;
+        bool odd = false, flip = false;
+        for (int l = 0; l < L.n_layers; l++) {
+            const int r0 = L.layer_ptr[l], r1 = L.layer_ptr[l + 1];
+            for (int r = r0 + wave; r < r1; r += kLayerWaves) layer_row<ST, VARIANT, DCLASS, false>(d, msg, lam, r, b, open, odd, flip);
+            __syncthreads();           // the next layer reads what this one wrote (workgroup-scope release/acquire)
+        }
+        const uint32_t f = combine(odd, flip);
+        store_trace(n, open);
+        if (open) {
+            iters = n;
+            if (!A.step_mode && f == 0u) { done = true; conv = true; }
+        }
+        if (A.step_mode) break;
+    }
+    if (wave == 0 && b < (size_t)d.Bp) {
+        d.iters[b] = conv ? iters : A.max_iters;
+        d.conv[b] = conv ? 1 : 0;
+        d.done[b] = 1;
+        if (A.step_mode) d.unsat[b] = 0;
+    }
+}
+
 // ------------------------------------------------------------------ host-side launch sequences
 #define HIPCHK(x)                                                             \
     do {                                                                      \
@@ -537,6 +722,66 @@ static int step_impl(FloodState &s, hipStream_t st, int batch, const double *d_o
     return LDPC_OK;
 }
 
+template <typename ST, int VARIANT>
+static int layered_launch(FloodState &s, hipStream_t st, const LayerArgs &a) {
+    FloodDev d = s.dev;
+    LayerDev L{s.n_layers, s.d_layer_ptr};
+    const dim3 grid(d.Bp / kWave), block(kWave * kLayerWaves);
+    if (s.timer && !a.step_mode) s.timer->begin(st);
+    if (s.max_row_deg <= 8) hipLaunchKernelGGL((layered_kernel<ST, VARIANT, 8>), grid, block, 0, st, d, L, (ST *)s.msg, (ST *)s.lam, a);
+    else if (s.max_row_deg <= 20) hipLaunchKernelGGL((layered_kernel<ST, VARIANT, 20>), grid, block, 0, st, d, L, (ST *)s.msg, (ST *)s.lam, a);
+    else hipLaunchKernelGGL((layered_kernel<ST, VARIANT, 32>), grid, block, 0, st, d, L, (ST *)s.msg, (ST *)s.lam, a);
+    if (s.timer && !a.step_mode) s.timer->end(st);
+    HIPCHK(hipGetLastError());
+    return LDPC_OK;
+}
+
+template <typename ST, int VARIANT>
+static int layered_decode_impl(FloodState &s, hipStream_t st, int max_iters, int batch, const void *d_llr, int llr_fmt, uint8_t *d_bits,
+                               double *d_final, double *d_trace) {
+    FloodDev d = s.dev;
+    hipLaunchKernelGGL(flood_reset_kernel, dim3((d.Bp + 255) / 256), dim3(256), 0, st, d, batch);
+    HIPCHK(hipMemsetAsync(s.msg, 0, (size_t)d.E * d.Bp * sizeof(ST), st));
+    const dim3 tgrid((d.N + 63) / 64, (d.Bp + 63) / 64);
+    if (llr_fmt == LLR_F64)
+        hipLaunchKernelGGL((load_llr_kernel<double, ST>), tgrid, dim3(256), 0, st, (const double *)d_llr, (ST *)s.orig, (ST *)s.lam, batch, d.N, d.Bp);
+    else if (llr_fmt == LLR_F16)
+        hipLaunchKernelGGL((load_llr_kernel<__half, ST>), tgrid, dim3(256), 0, st, (const __half *)d_llr, (ST *)s.orig, (ST *)s.lam, batch, d.N, d.Bp);
+    else
+        hipLaunchKernelGGL((load_llr_kernel<float, ST>), tgrid, dim3(256), 0, st, (const float *)d_llr, (ST *)s.orig, (ST *)s.lam, batch, d.N, d.Bp);
+    LayerArgs a{max_iters, 0, d_trace, batch};
+    int rc = layered_launch<ST, VARIANT>(s, st, a);
+    if (rc != LDPC_OK) return rc;
+    hipLaunchKernelGGL((store_bits_kernel<ST>), tgrid, dim3(256), 0, st, d, (const ST *)s.orig, (const ST *)s.lam, d_bits, d_final, batch);
+    HIPCHK(hipGetLastError());
+    return LDPC_OK;
+}
+
+// teacher-forced SWEEP: from (lam, msg) one full sweep over the layers -> (msg', lam'); d_syn = syndrome of hard(lam) is zero
+template <typename ST, int VARIANT>
+static int layered_step_impl(FloodState &s, hipStream_t st, int batch, const double *d_orig, const double *d_lam, const double *d_ne,
+                             double *d_ne_out, double *d_lam_out, uint8_t *d_syn) {
+    FloodDev d = s.dev;
+    ST *msg = (ST *)s.msg, *scr = (ST *)s.scratch, *lam = (ST *)s.lam, *orig = (ST *)s.orig;
+    hipLaunchKernelGGL(flood_reset_kernel, dim3((d.Bp + 255) / 256), dim3(256), 0, st, d, batch);
+    auto blocks = [&](size_t n) { return dim3((unsigned)((n + 255) / 256)); };
+    hipLaunchKernelGGL((upload_rows_kernel<ST>), blocks((size_t)d.N * d.Bp), dim3(256), 0, st, d_orig, orig, batch, d.N, d.Bp);
+    hipLaunchKernelGGL((upload_rows_kernel<ST>), blocks((size_t)d.N * d.Bp), dim3(256), 0, st, d_lam, lam, batch, d.N, d.Bp);
+    hipLaunchKernelGGL((upload_rows_kernel<ST>), blocks((size_t)d.E * d.Bp), dim3(256), 0, st, d_ne, msg, batch, d.E, d.Bp);
+    // syndrome of the given lam: the flooding check-node kernel in syndrome-only mode (stamp 1)
+    const int slabs = d.Bp / kWave, row_groups = (d.M + kCnWaves - 1) / kCnWaves;
+    hipLaunchKernelGGL((flood_cn_kernel<ST, VARIANT, false>), dim3(slabs * row_groups), dim3(kWave * kCnWaves), 0, st, d, msg, scr, lam, 1, 1, 1);
+    if (s.has_wide_rows) hipLaunchKernelGGL((flood_cn_kernel<ST, VARIANT, true>), dim3(slabs * row_groups), dim3(kWave * kCnWaves), 0, st, d, msg, scr, lam, 1, 1, 1);
+    hipLaunchKernelGGL(syndrome_flags_kernel, dim3((batch + 255) / 256), dim3(256), 0, st, d, d_syn, batch, 1);
+    LayerArgs a{1, 1, nullptr, batch};
+    int rc = layered_launch<ST, VARIANT>(s, st, a);
+    if (rc != LDPC_OK) return rc;
+    hipLaunchKernelGGL((download_rows_kernel<ST>), blocks((size_t)d.E * d.Bp), dim3(256), 0, st, msg, d_ne_out, batch, d.E, d.Bp);
+    hipLaunchKernelGGL((download_rows_kernel<ST>), blocks((size_t)d.N * d.Bp), dim3(256), 0, st, lam, d_lam_out, batch, d.N, d.Bp);
+    HIPCHK(hipGetLastError());
+    return LDPC_OK;
+}
+
 #define DISPATCH(FN, ...)                                                                   \
     switch (s.dtype) {                                                                      \
         case LDPC_F32: return s.variant == LDPC_MINSUM ? FN<float, LDPC_V_MINSUM>(__VA_ARGS__) : FN<float, LDPC_V_TANH>(__VA_ARGS__);   \
@@ -545,12 +790,21 @@ static int step_impl(FloodState &s, hipStream_t st, int batch, const double *d_o
         default: return set_error(LDPC_EINVAL, "bad dtype %d", s.dtype);                    \
     }
 
+#define DISPATCH_NO_F16(FN, ...)                                                            \
+    switch (s.dtype) {                                                                      \
+        case LDPC_F32: return s.variant == LDPC_MINSUM ? FN<float, LDPC_V_MINSUM>(__VA_ARGS__) : FN<float, LDPC_V_TANH>(__VA_ARGS__);   \
+        case LDPC_F64: return s.variant == LDPC_MINSUM ? FN<double, LDPC_V_MINSUM>(__VA_ARGS__) : FN<double, LDPC_V_TANH>(__VA_ARGS__); \
+        default: return set_error(LDPC_EUNSUPPORTED, "the layered schedule exists for f32 and f64");                                    \
+    }
+
 int flood_decode(FloodState &s, hipStream_t st, int max_iters, int batch, const void *d_llr, int llr_fmt,
                  uint8_t *d_bits, double *d_final, double *d_trace) {
+    if (s.layered) { DISPATCH_NO_F16(layered_decode_impl, s, st, max_iters, batch, d_llr, llr_fmt, d_bits, d_final, d_trace) }
     DISPATCH(decode_impl, s, st, max_iters, batch, d_llr, llr_fmt, d_bits, d_final, d_trace)
 }
 int flood_step(FloodState &s, hipStream_t st, int batch, const double *d_orig, const double *d_lam,
                const double *d_ne, double *d_ne_out, double *d_lam_out, uint8_t *d_syn) {
+    if (s.layered) { DISPATCH_NO_F16(layered_step_impl, s, st, batch, d_orig, d_lam, d_ne, d_ne_out, d_lam_out, d_syn) }
     DISPATCH(step_impl, s, st, batch, d_orig, d_lam, d_ne, d_ne_out, d_lam_out, d_syn)
 }
 

@@ -4,8 +4,9 @@
 //   * the plug-in record `mkLDPC` builds (src/ECC/Code/LDPC/Utils.hs:35-75): name, encode, decode,
 //     message_length, codeword_length, with the same code-name grammar (Utils.hs:82-88,100-108):
 //       ldpc/<decoder>/<matrix>/<max-rounds>[/<x>/<y>]      rate = x % y
-//     decoders registered here: hip-tanh, hip-minsum, with an optional dtype suffix -f32 (default),
-//     -f64, -f16 (new tokens next to the reference's registry, main/Main.hs:34-36).
+//     decoders registered here: hip-tanh, hip-minsum, optionally -layered (row-layered schedule, an extension),
+//     then an optional dtype suffix -f32 (default), -f64, -f16 (new tokens next to the reference's registry,
+//     main/Main.hs:34-36).
 // GHC is not available in this image, so this layer is C++ behind the same C ABI; INTEGRATION.md
 // has the Haskell module that calls the ABI from the reference itself.
 #include <stdio.h>
@@ -391,10 +392,11 @@ ldpc_ecc *ldpc_ecc_create(const char *codes_dir, const char *code_name, int max_
         if (ends("-f64")) { dtype = LDPC_F64; dec.resize(dec.size() - 4); }
         else if (ends("-f16")) { dtype = LDPC_F16; dec.resize(dec.size() - 4); }
         else if (ends("-f32")) { dec.resize(dec.size() - 4); }
-        int variant;
+        int variant, schedule = LDPC_SCHED_FLOODING;
+        if (ends("-layered")) { schedule = LDPC_SCHED_LAYERED; dec.resize(dec.size() - 8); }   // extension: row-layered schedule
         if (dec == "hip-tanh") variant = LDPC_TANH;
         else if (dec == "hip-minsum") variant = LDPC_MINSUM;
-        else { set_error(LDPC_ENOTFOUND, "decoder '%s' is not provided by libldpc_hip (hip-tanh, hip-minsum)", xs[1].c_str()); return nullptr; }
+        else { set_error(LDPC_ENOTFOUND, "decoder '%s' is not provided by libldpc_hip (hip-tanh, hip-minsum [-layered][-f32|-f64|-f16])", xs[1].c_str()); return nullptr; }
 
         // A matrix name that is a plain FILE under codes_dir is a stand-alone parity-check matrix in
         // MacKay's alist order with no generator (codes/1920.1280.3.303; the reference cannot load it,
@@ -443,7 +445,10 @@ ldpc_ecc *ldpc_ecc_create(const char *codes_dir, const char *code_name, int max_
             const char *pe = getenv("LDPC_HIP_PATH");
             if (pe && !strcmp(pe, "flood")) path = LDPC_PATH_FLOOD;
             else if (pe && !strcmp(pe, "fused")) path = LDPC_PATH_FUSED;
-            e->ctx = ldpc_ctx_create_ex(e->code, variant, dtype, max_batch, path);
+            ldpc_ctx_config cfg{};
+            cfg.struct_size = sizeof(cfg); cfg.device = -1; cfg.variant = variant; cfg.dtype = dtype; cfg.max_batch = max_batch; cfg.path = path;
+            cfg.schedule = schedule;
+            e->ctx = ldpc_ctx_create_cfg(e->code, &cfg);
         }
         if (!e->ctx) goto fail;
         if (g) {

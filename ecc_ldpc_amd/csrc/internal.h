@@ -80,6 +80,10 @@ struct FloodState {
     KernelTimer *timer = nullptr;
     bool has_wide_rows = false;   // some check row has weight 9..32 (not 18): second CN kernel instance, flood.hip
     void *msg = nullptr, *scratch = nullptr, *lam = nullptr, *orig = nullptr;
+    // row-layered schedule (extension; flood.hip layered_kernel): layers as row ranges, device copy owned by the context
+    bool layered = false;
+    int n_layers = 0, max_row_deg = 0;
+    int32_t *d_layer_ptr = nullptr;
     // The turn loop (2 launches per turn, no host decision inside: finished frames are frozen on the device)
     // touches only this context's buffers, so it is captured once per max_iters into a hipGraph and
     // replayed: one graph launch instead of 2*max_iters + 2 kernel launches.  flood_graph_release() frees it.
@@ -107,6 +111,9 @@ struct ldpc_code {
     // quasi-cyclic description when created through ldpc_code_create_qc (sz = 0 otherwise)
     int sz = 0, block_rows = 0, block_cols = 0;
     std::vector<int32_t> offsets;
+    // layers of the row-layered schedule: row ranges [layer_ptr[l], layer_ptr[l+1]) whose rows share no column.
+    // Default: the block rows of a QC code; every row its own layer otherwise (ldpc_code_set_layers replaces it).
+    std::vector<int32_t> layer_ptr;
     // device copies, one set per HIP device (created by the first context on that device): a code may be shared by
     // replicas on several GPUs of one process (Utils.hs:53 replicateM maxThreadCount)
     std::mutex dev_mu;

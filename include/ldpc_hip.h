@@ -59,6 +59,13 @@ typedef enum { LDPC_TANH = 0, LDPC_MINSUM = 1 } ldpc_variant;
  *      emulation in oracle/emulate_f16.py, whereas for F32/F64 they agree bit for bit. */
 typedef enum { LDPC_F32 = 0, LDPC_F64 = 1, LDPC_F16 = 2 } ldpc_dtype;
 /* which kernel family a context uses */
+/* message-passing schedule.  FLOODING: the reference's (Orig.hs:81-98: all checks, then all variables).
+ * LAYERED (extension, no reference counterpart): checks layer by layer, each seeing the LLRs the layers before it
+ * updated in the same sweep -- about half the sweeps to converge; stopping rule: before the first sweep the
+ * syndrome of the channel decisions, after a sweep "no check it saw was odd and no hard decision changed"
+ * (specification: oracle/ldpc_oracle.c oracle_decode_layered); a frame out of sweeps returns the channel decisions,
+ * as Orig.hs:70 does.  `iters` counts sweeps. */
+typedef enum { LDPC_SCHED_FLOODING = 0, LDPC_SCHED_LAYERED = 1 } ldpc_schedule;
 typedef enum {
     LDPC_PATH_AUTO = 0,  /* fused on-chip kernel when the code/variant/dtype has one, else flood */
     LDPC_PATH_FLOOD = 1, /* generic two-kernels-per-iteration path, state in HBM, any H          */
@@ -97,6 +104,14 @@ int ldpc_code_dims(const ldpc_code *code, int *M, int *N, int *E);
  * row-major, ascending column inside a row == the order of Orig.hs:86-91.  Arrays caller-owned. */
 int ldpc_code_csr(const ldpc_code *code, int32_t *row_ptr /*M+1*/, int32_t *col_idx /*E*/);
 
+/* ---- layers (row-layered schedule, an EXTENSION: BASELINE.json configs[4]; the reference has flooding only) -------
+ * A layer is a range of consecutive rows that share no column.  Default: the block rows of a quasi-cyclic code (one
+ * circulant per block => column-disjoint), every row its own layer for a CSR code.  ldpc_code_set_layers replaces
+ * the partition (layer_ptr[0] = 0 < ... < layer_ptr[n_layers] = M; LDPC_EINVAL if two rows of a layer share a column
+ * or a context already exists on the code). */
+int ldpc_code_set_layers(ldpc_code *code, int n_layers, const int32_t *layer_ptr);
+int ldpc_code_layers(const ldpc_code *code, int *n_layers, int32_t *layer_ptr /* may be NULL; n_layers+1 entries */);
+
 /* ---- decoder replica -------------------------------------------------------------------------
  * replaces one `decoder vars h` call (Utils.hs:53 replicateM maxThreadCount; Arraylet2.hs:88-144:
  * getFun x9, mallocArray of mLet/newMLet/lam/orig_lam/done, Stream.create).  Owns its device
@@ -106,6 +121,14 @@ ldpc_ctx *ldpc_ctx_create_ex(const ldpc_code *code, int variant, int dtype, int 
 /* the same on an explicitly named device (no ldpc_init needed on this thread; a code may have replicas on several
  * devices, its graph tables are uploaded once per device) */
 ldpc_ctx *ldpc_ctx_create_on(const ldpc_code *code, int device, int variant, int dtype, int max_batch, int path);
+/* everything above, plus what was added later, in one extensible structure: set struct_size = sizeof(ldpc_ctx_config)
+ * and zero the rest before filling in; device = -1 means the calling thread's device */
+typedef struct {
+    size_t struct_size;
+    int device, variant, dtype, max_batch, path, schedule;
+} ldpc_ctx_config;
+ldpc_ctx *ldpc_ctx_create_cfg(const ldpc_code *code, const ldpc_ctx_config *cfg);
+int ldpc_ctx_schedule(const ldpc_ctx *ctx);
 void ldpc_ctx_destroy(ldpc_ctx *ctx);
 /* LDPC_PATH_FLOOD or LDPC_PATH_FUSED: what the context resolved to */
 int ldpc_ctx_path(const ldpc_ctx *ctx);
@@ -249,7 +272,7 @@ ldpc_code *ldpc_code_from_matrix(const ldpc_matrix *m);
  * C mirror of what mkLDPC returns (src/ECC/Code/LDPC/Utils.hs:35-75): ECC{name, encode, decode,
  * message_length, codeword_length}, selected by the reference's code-name grammar
  *   ldpc/<decoder>/<matrix-name>/<max-rounds>[/<x>/<y>]        (Utils.hs:82-88,100-108; rate x%y)
- * with <decoder> in {hip-tanh, hip-minsum}[-f32|-f64|-f16].  NULL + LDPC_ENOTFOUND for any other
+ * with <decoder> in {hip-tanh, hip-minsum}[-layered][-f32|-f64|-f16].  NULL + LDPC_ENOTFOUND for any other
  * name (the factory's `_ -> return []`). One decoder replica is created (maxThreadCount = 1, like
  * the CUDA plug-ins, GPU/CUDA/Arraylet2.hs:61). */
 typedef struct ldpc_ecc ldpc_ecc;

@@ -309,6 +309,62 @@ int oracle_decode(int M, int N, const int32_t *row_ptr, const int32_t *col_idx, 
  *                                                           saw was satisfied => hard lam is a codeword)
  * trace_lam: NULL or (max_iters+1) x N: lam after sweep n at row n (row 0 = orig).
  * ---------------------------------------------------------------------------------------- */
+/* one sweep over all rows in ascending order (layers are contiguous ascending row ranges whose rows are column-disjoint,
+ * so this IS the layer-by-layer order); lam and msg are updated in place */
+static int layered_sweep(int M, const int32_t *row_ptr, const int32_t *col_idx, int variant, double *lam, double *msg,
+                         int *odd_out, int *flip_out) {
+    double t[4096], x[4096];
+    int odd = 0, flip = 0;
+    for (int m = 0; m < M; m++) {
+        const int b = row_ptr[m], d = row_ptr[m + 1] - b;
+        if (d > 4096) return ORACLE_EARG;
+        int par = 0;
+        for (int k = 0; k < d; k++) {
+            const double l = lam[col_idx[b + k]];
+            par ^= hard(l);
+            t[k] = l - msg[b + k];
+        }
+        odd |= par;
+        if (variant == ORACLE_TANH) {
+            for (int k = 0; k < d; k++) x[k] = tanh(-(t[k] / 2.0));
+            for (int k = 0; k < d; k++) {
+                double prod = 1.0;
+                for (int j = 0; j < d; j++) if (j != k) prod = prod * x[j];
+                msg[b + k] = -2.0 * atanh_clamped(prod);
+            }
+        } else {
+            if (d == 1) return ORACLE_EDEGREE;
+            for (int k = 0; k < d; k++) x[k] = -t[k];
+            for (int k = 0; k < d; k++) {
+                int have = 0; double acc = 0.0;
+                for (int j = d - 1; j >= 0; j--) if (j != k) { acc = have ? min_prime(x[j], acc) : x[j]; have = 1; }
+                msg[b + k] = (-3.0 / 4.0) * acc;
+            }
+        }
+        for (int k = 0; k < d; k++) {
+            const int c = col_idx[b + k];
+            const double nw = t[k] + msg[b + k];
+            flip |= hard(nw) != hard(lam[c]);
+            lam[c] = nw;
+        }
+    }
+    *odd_out = odd; *flip_out = flip;
+    return ORACLE_OK;
+}
+
+/* teacher-forced sweep: (lam, msg) -> (lam', msg') */
+int oracle_layered_step(int M, int N, const int32_t *row_ptr, const int32_t *col_idx, int variant, const double *lam,
+                        const double *msg, double *lam_out, double *msg_out, int *odd, int *flip) {
+    if (M <= 0 || N <= 0 || !row_ptr || !col_idx || !lam || !msg || !lam_out || !msg_out) return ORACLE_EARG;
+    memcpy(lam_out, lam, sizeof(double) * (size_t)N);
+    memcpy(msg_out, msg, sizeof(double) * (size_t)row_ptr[M]);
+    int o = 0, f = 0;
+    int rc = layered_sweep(M, row_ptr, col_idx, variant, lam_out, msg_out, &o, &f);
+    if (odd) *odd = o;
+    if (flip) *flip = f;
+    return rc;
+}
+
 int oracle_decode_layered(int M, int N, const int32_t *row_ptr, const int32_t *col_idx, int n_layers,
                           const int32_t *layer_ptr, int variant, int max_iters, const double *orig_lam, uint8_t *bits,
                           int *iters_out, int *converged_out, double *final_lam, double *trace_lam) {
@@ -332,7 +388,6 @@ int oracle_decode_layered(int M, int N, const int32_t *row_ptr, const int32_t *c
             }
     }
     free(seen);
-    double t[4096], x[4096];
     int n = 0, conv = 0;
     const double *result = orig_lam;
     if (rc == ORACLE_OK) {
@@ -342,39 +397,7 @@ int oracle_decode_layered(int M, int N, const int32_t *row_ptr, const int32_t *c
         else for (;;) {
             if (n >= max_iters) { conv = 0; result = orig_lam; break; }
             int odd = 0, flip = 0;
-            for (int m = 0; m < M && rc == ORACLE_OK; m++) {   /* layers are contiguous row ranges in ascending order */
-                const int b = row_ptr[m], d = row_ptr[m + 1] - b;
-                if (d > 4096) { rc = ORACLE_EARG; break; }
-                int par = 0;
-                for (int k = 0; k < d; k++) {
-                    const double l = lam[col_idx[b + k]];
-                    par ^= hard(l);
-                    t[k] = l - msg[b + k];
-                }
-                odd |= par;
-                if (variant == ORACLE_TANH) {
-                    for (int k = 0; k < d; k++) x[k] = tanh(-(t[k] / 2.0));
-                    for (int k = 0; k < d; k++) {
-                        double prod = 1.0;
-                        for (int j = 0; j < d; j++) if (j != k) prod = prod * x[j];
-                        msg[b + k] = -2.0 * atanh_clamped(prod);
-                    }
-                } else {
-                    if (d == 1) { rc = ORACLE_EDEGREE; break; }
-                    for (int k = 0; k < d; k++) x[k] = -t[k];
-                    for (int k = 0; k < d; k++) {
-                        int have = 0; double acc = 0.0;
-                        for (int j = d - 1; j >= 0; j--) if (j != k) { acc = have ? min_prime(x[j], acc) : x[j]; have = 1; }
-                        msg[b + k] = (-3.0 / 4.0) * acc;
-                    }
-                }
-                for (int k = 0; k < d; k++) {
-                    const int c = col_idx[b + k];
-                    const double nw = t[k] + msg[b + k];
-                    flip |= hard(nw) != hard(lam[c]);
-                    lam[c] = nw;
-                }
-            }
+            rc = layered_sweep(M, row_ptr, col_idx, variant, lam, msg, &odd, &flip);
             if (rc != ORACLE_OK) break;
             n++;
             if (trace_lam) memcpy(trace_lam + (size_t)n * N, lam, sizeof(double) * (size_t)N);

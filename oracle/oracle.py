@@ -34,6 +34,7 @@ def lib():
         L.oracle_step.argtypes = [C.c_int, C.c_int, i32p, i32p, C.c_int, f64p, f64p, f64p, f64p, f64p, ip]
         L.oracle_decode_batch.argtypes = [C.c_int, C.c_int, i32p, i32p, C.c_int, C.c_int, C.c_int, f64p, u8p, i32p, u8p, C.c_int]
         L.oracle_decode_layered.argtypes = [C.c_int, C.c_int, i32p, i32p, C.c_int, i32p, C.c_int, C.c_int, f64p, u8p, ip, ip, f64p, f64p]
+        L.oracle_layered_step.argtypes = [C.c_int, C.c_int, i32p, i32p, C.c_int, f64p, f64p, f64p, f64p, ip, ip]
         L.oracle_encode_dense.argtypes = [C.c_int, C.c_int, u8p, u8p, u8p]
         L.oracle_encode_qc.argtypes = [C.c_int, C.c_int, C.c_int, u8p, u8p, u8p]
         _lib = L
@@ -108,6 +109,19 @@ def decode_layered(g: Graph, layer_ptr, variant, max_iters, llr, trace=False):
     if trace:
         out["trace_lam"] = tl[: it.value + 1]
     return out
+
+
+def layered_step(g: Graph, variant, lam, msg):
+    """one teacher-forced sweep of the layered schedule -> (msg', lam', odd, flip)"""
+    lam = np.ascontiguousarray(lam, np.float64)
+    msg = np.ascontiguousarray(msg, np.float64)
+    lam2, msg2 = np.zeros(g.N, np.float64), np.zeros(g.E, np.float64)
+    odd, flip = C.c_int(0), C.c_int(0)
+    rc = lib().oracle_layered_step(g.M, g.N, _p(g.row_ptr, C.c_int32), _p(g.col_idx, C.c_int32), _variant(variant), _p(lam, C.c_double),
+                                   _p(msg, C.c_double), _p(lam2, C.c_double), _p(msg2, C.c_double), C.byref(odd), C.byref(flip))
+    if rc != 0:
+        raise RuntimeError(f"oracle_layered_step rc={rc}")
+    return msg2, lam2, bool(odd.value), bool(flip.value)
 
 
 def decode_dense(H, variant, max_iters, llr, trace=False):

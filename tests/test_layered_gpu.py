@@ -1,0 +1,116 @@
+"""GPU: the row-layered schedule (BASELINE.json configs[4]; an extension -- the reference has flooding only) against its
+specification, oracle_decode_layered.  Same bars as the flooding paths: f64 min-sum reproduces the oracle's trajectory
+bit for bit, f64 tanh to the device libm's last ulps, f32 gives identical hard bits / flags and per-sweep LLRs within
+1e-5 (teacher-forced)."""
+import numpy as np
+import pytest
+
+from oracle import oracle
+from tests.helpers import CODES, lam_tolerance, load, synthetic
+
+pytestmark = pytest.mark.gpu
+
+
+def _layers(c):
+    return c.layer_ptr if hasattr(c, "layer_ptr") else (np.arange(0, c.M + 1, c.sz) if getattr(c, "sz", 0) else np.arange(c.M + 1))
+
+
+def _get(name):
+    return load(name) if name in ("moon.7.13", "jpl.1024.4.5", "jpl.4096.4.5", "1920.1280.3.303") else synthetic(name)
+
+
+@pytest.mark.parametrize("name,db", [("moon.7.13", 3.0), ("jpl.1024.4.5", 3.0), ("jpl.4096.4.5", 3.2), ("ira-12x24-sz64", 2.0)])
+@pytest.mark.parametrize("variant", ["min", "tanh"])
+def test_f64_trajectory(hip, name, db, variant):
+    c = _get(name)
+    lp = _layers(c)
+    _, llr = c.frames(6, db, seed=900)
+    dec = hip.Decoder(c.hip_code(hip), variant, "f64", len(llr), schedule="layered")
+    assert dec.schedule == "layered" and dec.path == "flood" and np.array_equal(dec.code.layers(), lp)
+    bits, its, conv, trace = dec.decode_trace(llr, 25)
+    for f in range(len(llr)):
+        o = oracle.decode_layered(c.graph, lp, variant, 25, llr[f], trace=True)
+        assert its[f] == o["iters"] and bool(conv[f]) == o["converged"], (name, variant, f, its[f], o["iters"])
+        assert np.array_equal(bits[f], o["bits"])
+        if variant == "min":
+            assert np.array_equal(trace[f, : o["iters"] + 1], o["trace_lam"])
+        else:
+            rel = np.abs(trace[f, : o["iters"] + 1] - o["trace_lam"]) / np.maximum(1, np.abs(o["trace_lam"]))
+            assert rel.max() <= 1e-9, rel.max()
+
+
+@pytest.mark.parametrize("name,dbs", [("jpl.1024.4.5", (2.5, 3.5)), ("jpl.4096.4.5", (2.8, 3.6)), ("regular36-sz128", (2.0, 3.0)), ("1920.1280.3.303", (1.5, 2.5))])
+def test_f32_free_running_and_teacher_forced(hip, name, dbs):
+    c = _get(name)
+    lp = _layers(c)
+    F = 24 if c.N > 4000 else 48
+    llr = np.concatenate([c.frames(F // 2, db, 910 + i)[1] for i, db in enumerate(dbs)])
+    for variant in ("min", "tanh"):
+        dec = hip.Decoder(c.hip_code(hip), variant, "f32", F, schedule="layered")
+        bits, its, conv = dec.decode_batch(llr.astype(np.float32), 40)
+        ref = [oracle.decode_layered(c.graph, lp, variant, 40, l) for l in llr]
+        ob = np.stack([o["bits"] for o in ref]); oi = np.array([o["iters"] for o in ref]); oc = np.array([o["converged"] for o in ref])
+        assert np.array_equal(bits, ob) and np.array_equal(conv.astype(bool), oc), (name, variant)
+        assert (its == oi).mean() >= 0.9
+        # one sweep from oracle states
+        states = []
+        for f in range(4):
+            lam, msg = llr[f].copy(), np.zeros(c.E)
+            for n in range(min(ref[f]["iters"], 6)):
+                m2, l2, _, _ = oracle.layered_step(c.graph, variant, lam, msg)
+                states.append((llr[f], lam, msg, m2, l2))
+                lam, msg = l2, m2
+        states = states[:F]
+        if states:
+            ne2, lam2, _ = dec.debug_step(np.stack([s[0] for s in states]), np.stack([s[1] for s in states]), np.stack([s[2] for s in states]))
+            worst = 0.0
+            for i, s in enumerate(states):
+                tol_lam, tol_ne = lam_tolerance(c.graph, s[3], s[4])
+                assert (np.abs(ne2[i] - s[3]) <= tol_ne).all() and (np.abs(lam2[i] - s[4]) <= tol_lam).all(), (name, variant, i)
+                worst = max(worst, (np.abs(lam2[i] - s[4]) / np.maximum(1, np.abs(s[4]))).max())
+            print(f"{name} layered {variant} f32: {int(conv.sum())}/{F} converged, sweeps {100 * (its == oi).mean():.0f}% identical, "
+                  f"worst teacher-forced relative LLR error {worst:.2e} over {len(states)} sweeps")
+
+
+def test_layered_needs_fewer_sweeps_and_same_answers(hip):
+    c = load("jpl.4096.4.5")
+    _, llr = c.frames(256, 3.4, seed=77)
+    code = c.hip_code(hip)
+    fl = hip.Decoder(code, "min", "f32", 256)
+    la = hip.Decoder(code, "min", "f32", 256, schedule="layered")
+    fb, fi, fc = fl.decode_batch(llr.astype(np.float32), 50)
+    lb, li, lc = la.decode_batch(llr.astype(np.float32), 50)
+    both = (fc == 1) & (lc == 1)
+    assert both.sum() > 200 and lc.sum() >= fc.sum()
+    assert np.array_equal(fb[both], lb[both])                 # both found the (same) codeword
+    assert li[both].mean() < 0.7 * fi[both].mean()
+    print(f"jpl.4096 3.4 dB: flooding {fi[both].mean():.1f} turns, layered {li[both].mean():.1f} sweeps; converged {int(fc.sum())} vs {int(lc.sum())} of 256")
+
+
+def test_edge_cases_and_custom_layers(hip):
+    c = load("jpl.1024.4.5")
+    cws, llr = c.frames(70, 4.0, seed=5)                   # ragged batch: 70 frames in two 64-frame slabs
+    code_csr = c.hip_code(hip, prefer_qc=False)
+    assert len(code_csr.layers()) == c.M + 1                # CSR default: every row its own layer
+    code_csr.set_layers(np.arange(0, c.M + 1, c.sz))        # the block rows, by hand
+    with pytest.raises(hip.LdpcError):
+        c.hip_code(hip, prefer_qc=False).set_layers(np.arange(0, c.M + 1, 2 * c.sz))   # two block rows share columns
+    dec = hip.Decoder(code_csr, "min", "f32", 70, schedule="layered")
+    z = llr.copy(); z[0] = (2.0 * cws[0] - 1.0) * 8.0; z[1] = 0.0
+    bits, its, conv = dec.decode_batch(z.astype(np.float32), 30)
+    lp = np.arange(0, c.M + 1, c.sz)
+    for f in range(70):
+        o = oracle.decode_layered(c.graph, lp, "min", 30, z[f])
+        assert np.array_equal(bits[f], o["bits"]) and bool(conv[f]) == o["converged"]
+    assert its[0] == 0 and its[1] == 0 and not bits[1].any()
+    with pytest.raises(hip.LdpcError):                      # contexts exist now: the partition is frozen
+        code_csr.set_layers(np.arange(c.M + 1))
+    b0, i0, c0 = dec.decode_batch(llr[:3].astype(np.float32), 0)     # no sweeps allowed: channel decisions
+    assert np.array_equal(b0, (llr[:3] > 0).astype(np.uint8)) and not c0.any()
+    with pytest.raises(hip.LdpcError) as e:
+        hip.Decoder(c.hip_code(hip), "min", "f16", 8, schedule="layered")
+    assert e.value.code == -5
+    ecc = hip.ECC(CODES, "ldpc/hip-minsum-layered/jpl.1024.4.5/50/4/5", max_batch=4)
+    assert ecc.decoder.schedule == "layered"
+    out, ok = ecc.decode(llr[5][:1280])
+    assert ok and np.array_equal(out, oracle.decode_layered(c.graph, lp, "min", 50, llr[5])["bits"][:1024])

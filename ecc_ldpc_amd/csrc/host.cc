@@ -402,10 +402,18 @@ ldpc_ecc *ldpc_ecc_create(const char *codes_dir, const char *code_name, int max_
         // MacKay's alist order with no generator (codes/1920.1280.3.303; the reference cannot load it,
         // SURVEY.md section 0 note ii): message length = cols - rows (H full rank), frames are the
         // all-zero codeword.  Otherwise the reference's <matrix>/G + <matrix>/H pair.
-        const bool standalone = file_exists(std::string(codes_dir) + "/" + xs[2]);
+        bool standalone = file_exists(std::string(codes_dir) + "/" + xs[2]);
+        bool have_g = false;
+        for (const char *suf : {"q", "alist", "m"}) have_g = have_g || file_exists(std::string(codes_dir) + "/" + xs[2] + "/G." + suf);
         if (standalone) {
             h = ldpc_matrix_load_mackay((std::string(codes_dir) + "/" + xs[2]).c_str());
             if (!h) return nullptr;
+        } else if (!have_g) {
+            // a matrix directory that ships H only (codes/dvbs2like.64800.1.2: a dense generator would be 131 MB):
+            // same convention as the stand-alone file -- k = cols - rows, all-zero codewords, no encoder
+            h = ldpc_matrix_load(codes_dir, (xs[2] + "/H").c_str());
+            if (!h) return nullptr;
+            standalone = true;
         } else {
             g = ldpc_matrix_load(codes_dir, (xs[2] + "/G").c_str());  // Utils.hs:36
             if (!g) return nullptr;

@@ -117,3 +117,37 @@ def test_edge_cases_and_custom_layers(hip):
     assert ecc.decoder.schedule == "layered"
     out, ok = ecc.decode(llr[5][:1280])
     assert ok and np.array_equal(out, oracle.decode_layered(c.graph, lp, "min", 50, llr[5])["bits"][:1024])
+
+
+def test_dvbs2_shaped_long_code(hip):
+    """BASELINE.json configs[4]: n = 64 800, period 360 (a SYNTHETIC matrix with the DVB-S2 rate-1/2 shape: the ETSI
+    tables are not available; tools/gen_dvbs2_like.py).  A frame's LLRs alone are 253 KB -- beyond every on-chip
+    kernel -- so both schedules run from HBM.  Parity against the oracle on a few frames, f64 bit-exact."""
+    from oracle import formats
+    import os
+    sz, rows = formats.read_qc(open(os.path.join(CODES, "dvbs2like.64800.1.2", "H.q")).read())
+    off = formats.qc_offsets(sz, rows)
+    assert sz == 360 and off.shape == (90, 180)
+    ecc = hip.ECC(CODES, "ldpc/hip-minsum-layered/dvbs2like.64800.1.2/50", max_batch=64)
+    assert (ecc.message_length, ecc.codeword_length, ecc.unpunctured_length) == (32400, 64800, 64800)
+    assert ecc.decoder.schedule == "layered" and ecc.decoder.path == "flood"
+    rp, ci = ecc.code.csr()
+    g = oracle.Graph(rp, ci, ecc.code.N)
+    lp = ecc.code.layers()
+    assert len(lp) == 91 and lp[1] == 360
+    from oracle import channel
+    llr = channel.frames(np.zeros((6, g.N), np.uint8), 1.6, 32400, 64800, g.N, seed=3)
+    bits, its, conv = ecc.decoder.decode_batch(llr.astype(np.float32), 50)
+    ref = [oracle.decode_layered(g, lp, "min", 50, l) for l in llr]
+    assert all(np.array_equal(bits[f], ref[f]["bits"]) and bool(conv[f]) == ref[f]["converged"] for f in range(6))
+    d64 = hip.Decoder(ecc.code, "min", "f64", 2, schedule="layered")
+    b2, i2, c2, lam = d64.decode_batch(llr[:2], 50, want_lam=True)
+    for f in range(2):
+        assert i2[f] == ref[f]["iters"] and np.array_equal(lam[f], ref[f]["lam"])
+    # flooding on the same code for comparison (flood path): also the oracle's answer, in more turns
+    fl = hip.Decoder(ecc.code, "min", "f32", 6)
+    assert fl.path == "flood"
+    fb, fi, fc = fl.decode_batch(llr.astype(np.float32), 50)
+    ob, oi, oc = oracle.decode_batch(g, "min", 50, llr, nthreads=6)
+    assert np.array_equal(fb, ob) and np.array_equal(fc, oc)
+    print(f"dvbs2like 1.6 dB: layered {its.tolist()} sweeps, flooding {fi.tolist()} turns")

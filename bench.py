@@ -162,7 +162,7 @@ def main():
             "value": round(value, 2), "unit": "Mbit/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": f"{args.code} rate {args.rate} ({k},{n_tx}) {args.variant} flooding BP, {args.iters} iters, "
+            "config": {"workload": f"{args.code} rate {args.rate} ({k},{n_tx}) {args.variant} {args.schedule} BP, {args.iters} iters, "
                                    f"Eb/N0={args.ebn0} dB, {B} frames/GPU/step", "code_name": ecc.name, "path": dec.path,
                        "batch_per_gpu": B, "parallelism": f"frames sharded over {world} GPU(s), tallies all-reduced"},
             **({"rehearsal": "ranks share GPUs over gloo; not a measurement"} if rehearse else {}),
@@ -183,6 +183,40 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def proof_of_work_layered(args, E, ecc, dec, sim, llr_t, msg_t, bits, iters_t, conv_t, sp, f16, n):
+    """The layered schedule has one implementation, so the check is by invariant, with a DIFFERENT kernel as the judge:
+    every frame reported converged must be a codeword -- its hard bits, fed back as LLRs to a flooding-path context with
+    0 turns allowed, must come back 'syndrome zero' from flood_cn_kernel -- a frame reported failed must carry the
+    channel's hard decisions (the reference's rule, Orig.hs:70), and decoding must remove bit errors."""
+    import torch
+    k = ecc.message_length
+    out = {"sample_frames": n, "checked_against": "syndrome kernel of the flooding path on the decoder's output; channel decisions for failed frames", "points": []}
+    chk = E.Decoder(ecc.code, "min", "f32", n, path="flood")
+    cb = torch.empty_like(bits[:n])
+    ci = torch.empty_like(iters_t[:n])
+    cc = torch.empty_like(conv_t[:n])
+    for db in (args.ebn0, args.ebn0 + 1.6):
+        sim.generate(args.seed, 1 << 40, n, db, llr_t.data_ptr(), msg_t.data_ptr(), sp, llr_f16=f16)
+        dec.decode_batch_dev(llr_t.data_ptr(), bits.data_ptr(), n, args.iters, iters_t.data_ptr(), conv_t.data_ptr(), sp, llr_f16=f16)
+        torch.cuda.synchronize()
+        as_llr = (bits[:n].to(torch.float32) * 2.0 - 1.0).contiguous()
+        chk.decode_batch_dev(as_llr.data_ptr(), cb.data_ptr(), n, 0, ci.data_ptr(), cc.data_ptr(), sp)
+        torch.cuda.synchronize()
+        conv = conv_t[:n].bool()
+        hard_in = (llr_t[:n].float() > 0).to(torch.uint8)
+        raw = (hard_in[:, :k] != msg_t[:n]).sum().item()
+        dec_err = (bits[:n, :k] != msg_t[:n]).sum().item()
+        it = iters_t[:n].cpu().numpy()
+        out["points"].append({
+            "ebn0_db": db, "converged_frames_are_codewords": bool(cc.bool()[conv].all().item()),
+            "failed_frames_return_channel_decisions": bool((bits[:n][~conv] == hard_in[~conv]).all().item()),
+            "converged_frac": round(float(conv.float().mean().item()), 4), "mean_sweeps": round(float(it.mean()), 2),
+            "distinct_sweep_counts": int(len(set(it.tolist()))), "channel_bit_errors": int(raw), "decoded_bit_errors": int(dec_err)})
+    chk.close()
+    out["ok"] = all(p["converged_frames_are_codewords"] and p["failed_frames_return_channel_decisions"] for p in out["points"])
+    return out
 
 
 PROFILE_TAGS = {   # committed rocprofv3 PMC passes of these workloads at 65 536 frames per launch (tools/profile.sh)
@@ -242,6 +276,16 @@ def rooflines(args, dec, B, Eg, N, n_tx, k, s_bytes, launches, kernel_ms, turns_
            "algorithmic_bytes_timed": model_bytes, "mean_iters_timed": round(turns_timed / frames_timed, 3)}
     hbm["frac"] = round(hbm["achieved"] / HBM_PEAK_GBS, 4)
     traffic, tsrc = committed_traffic(args, dec, B)
+    if dec.path != "fused" and dec.schedule == "layered":
+        # layered schedule from HBM: ONE launch is the whole decode of the batch; per sweep every edge reads and writes its
+        # lam cell and its message (4E*s), plus the syndrome pass before the first sweep (E*s); priced with the sweeps run
+        bytes_timed = turns_timed * 4 * Eg * s_bytes + frames_timed * Eg * s_bytes
+        ach = bytes_timed / (kernel_ms * 1e-3) / 1e9 if kernel_ms else 0.0
+        r = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
+             "traffic": None, "kernel": dec.kernel_name, "launches": launches, "avg_launch_ms": round(avg_ms, 4),
+             "algorithmic_bytes_timed": bytes_timed, "frame_sweeps_timed": turns_timed,
+             "bytes_model": "sum_frames(sweeps_f)*4E*s + frames*E*s (one persistent launch decodes the batch; lam and messages live in HBM)"}
+        return r, None
     if dec.path != "fused":
         # flood path: state in HBM, two kernels per turn; the timed kernel is the check-node kernel and every launch of
         # it streams (2E+N)*s bytes per frame of the batch
@@ -290,6 +334,8 @@ def proof_of_work(args, E, ecc, dec, sim, llr_t, msg_t, bits, iters_t, conv_t, s
     import torch
     n = min(1024, llr_t.shape[0])
     k = ecc.message_length
+    if dec.schedule == "layered":
+        return proof_of_work_layered(args, E, ecc, dec, sim, llr_t, msg_t, bits, iters_t, conv_t, sp, f16, n)
     flood_dtype = "f32" if args.dtype == "f16" else args.dtype     # fused-F16(llr) == F32 decoder on the fp16-rounded LLRs
     variant = "min" if args.variant == "minsum" else "tanh"
     out = {"sample_frames": n, "checked_against": "flood path (ldpc_ctx_create_ex path=LDPC_PATH_FLOOD)", "points": []}
@@ -357,7 +403,10 @@ def cpu_baseline(args, ecc, llr_dev, gpu_value):
     while n + chunk <= llr_dev.shape[0] and dt < args.cpu_seconds:
         x = llr_dev[n:n + chunk].cpu().numpy().astype(np.float64)
         t0 = time.perf_counter()
-        oracle.decode_batch(g, variant, args.iters, x, nthreads=cores)
+        if args.schedule == "layered":
+            oracle.decode_layered_batch(g, code.layers(), variant, args.iters, x, nthreads=cores)
+        else:
+            oracle.decode_batch(g, variant, args.iters, x, nthreads=cores)
         dt += time.perf_counter() - t0
         n += chunk
     v = n * ecc.message_length / dt / 1e6

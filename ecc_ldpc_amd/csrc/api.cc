@@ -12,6 +12,7 @@
 #include "internal.h"
 #include "fused.h"
 #include "jit.h"
+#include "layered_qc.h"
 #include "sim.h"
 
 namespace ldpc {
@@ -51,6 +52,7 @@ struct ldpc_ctx {
     hipStream_t stream = nullptr;
     ldpc::FloodState flood;
     ldpc::FusedState *fused = nullptr;
+    ldpc::LayeredQcState *lqc = nullptr;   // layered schedule on a QC code: frame-per-workgroup kernel, state in HBM (layered_qc.hip)
     // staging of the host-pointer entry points, allocated on first use.  kSlots slots, each with its own stream
     // running H2D -> decode -> D2H for one chunk, so that the copies of one chunk overlap the decode of another
     // (fused paths are stateless on the device; the flood path keeps per-context BP state and uses slot 0 with
@@ -341,6 +343,7 @@ void ldpc_ctx_destroy(ldpc_ctx *ctx) {
     (void)hipFree(ctx->d_small_out); (void)hipFree(ctx->d_small_in);
     (void)hipFree(ctx->d_zc_iters); (void)hipFree(ctx->d_zc_conv);
     if (ctx->fused) ldpc::fused_destroy(ctx->fused);
+    ldpc::layered_qc_destroy(ctx->lqc);
     ctx->timer.destroy();
     if (ctx->stream) hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -420,7 +423,12 @@ ldpc_ctx *ldpc_ctx_create_cfg(const ldpc_code *code_c, const ldpc_ctx_config *cf
     ctx->flood.variant = variant; ctx->flood.dtype = dtype; ctx->flood.timer = &ctx->timer;
     // (the staging buffers of the host-pointer entry points are allocated on first use: a context driven
     //  through ldpc_decode_batch_dev with 65 536 frames would otherwise park 3 GB of HBM)
-    if (ctx->path == LDPC_PATH_FLOOD) {
+    if (ctx->path == LDPC_PATH_FLOOD && schedule == LDPC_SCHED_LAYERED && ldpc::layered_qc_why_not(*code, variant, dtype) == nullptr) {
+        // QC code: one workgroup per frame (a frame stops when ITS rule fires); any other H: the batch-major kernel below
+        ctx->lqc = ldpc::layered_qc_create(*code, variant, dtype, max_batch);
+        if (!ctx->lqc) { ldpc_ctx_destroy(ctx); return nullptr; }
+        ldpc::layered_qc_set_timer(ctx->lqc, &ctx->timer);
+    } else if (ctx->path == LDPC_PATH_FLOOD) {
         CTX_HIP(hipMalloc(&ctx->flood.msg, std::max<size_t>((size_t)code->E, 1) * Bp * es));
         // scratch is only touched by rows whose degree has no register kernel
         bool need_scratch = false;
@@ -489,6 +497,7 @@ static int decode_dev(ldpc_ctx *ctx, hipStream_t st, int max_iters, int batch, c
     if (batch == 0) return LDPC_OK;
     if (ctx->path == LDPC_PATH_FUSED)
         return ldpc::fused_decode(*ctx->fused, st, max_iters, batch, d_llr, fmt, d_bits, d_iters, d_conv, d_final, d_trace);
+    if (ctx->lqc) return ldpc::layered_qc_decode(*ctx->lqc, st, max_iters, batch, d_llr, fmt, d_bits, d_iters, d_conv, d_final, d_trace);
     int rc = ldpc::flood_decode(ctx->flood, st, max_iters, batch, d_llr, fmt, d_bits, d_final, d_trace);
     if (rc != LDPC_OK) return rc;
     if (d_iters) HIPCHK(hipMemcpyAsync(d_iters, ctx->flood.dev.iters, sizeof(int32_t) * (size_t)batch, hipMemcpyDeviceToDevice, st));
@@ -720,6 +729,8 @@ int ldpc_debug_step(ldpc_ctx *ctx, int batch, const double *orig, const double *
     if (ce != hipSuccess) rc = set_error(LDPC_EHIP, "debug_step upload: %s", hipGetErrorString(ce));
     else if (ctx->path == LDPC_PATH_FUSED)
         rc = ldpc::fused_step(*ctx->fused, st, batch, d_orig, d_lam, d_ne, d_ne_out, d_lam_out, d_syn);
+    else if (ctx->lqc)
+        rc = ldpc::layered_qc_step(*ctx->lqc, st, batch, d_orig, d_lam, d_ne, d_ne_out, d_lam_out, d_syn);
     else
         rc = ldpc::flood_step(ctx->flood, st, batch, d_orig, d_lam, d_ne, d_ne_out, d_lam_out, d_syn);
     if (rc == LDPC_OK) {
@@ -753,6 +764,7 @@ int ldpc_ctx_kernel_time(ldpc_ctx *ctx, int *launches, double *total_ms) {
 const char *ldpc_ctx_kernel_name(const ldpc_ctx *ctx) {
     if (!ctx) return "";
     if (ctx->path == LDPC_PATH_FUSED && ctx->fused) return ldpc::fused_kernel_name(*ctx->fused);
+    if (ctx->lqc) return ldpc::layered_qc_launch_info(*ctx->lqc).name;
     return ctx->schedule == LDPC_SCHED_LAYERED ? "layered_kernel" : "flood_cn_kernel";
 }
 
@@ -760,6 +772,7 @@ int ldpc_ctx_kernel_geometry(const ldpc_ctx *ctx, int *threads_per_workgroup, in
     if (!ctx) return set_error(LDPC_EINVAL, "null ctx");
     int t = 0, f = 0;
     if (ctx->path == LDPC_PATH_FUSED && ctx->fused) { const ldpc::LaunchInfo &li = ldpc::fused_launch_info(*ctx->fused); t = li.threads; f = li.frames_per_wg; }
+    if (ctx->lqc) { const ldpc::LaunchInfo &li = ldpc::layered_qc_launch_info(*ctx->lqc); t = li.threads; f = li.frames_per_wg; }
     if (threads_per_workgroup) *threads_per_workgroup = t;
     if (frames_per_workgroup) *frames_per_workgroup = f;
     return LDPC_OK;

@@ -445,7 +445,10 @@ struct LayerArgs {
     double *trace;              // may be null: [batch][max_iters + 1][N], lam after sweep n at row n
     int batch;
 };
-constexpr int kLayerWaves = 16;
+// waves per slab: 16 when there are few slabs (a small batch must still fill the chip), 8 when there are many (more
+// independent workgroups per CU hide more memory latency: 74 VGPRs -> 24 waves per CU = three 8-wave workgroups, but
+// only one 16-wave workgroup)
+constexpr int kLayerWavesMax = 16;
 
 template <typename ST, int VARIANT, int DEG, bool SYNDROME_ONLY>
 __device__ __forceinline__ void layer_row_regs(const FloodDev &d, ST *__restrict__ msg, ST *__restrict__ lam, int ebeg, size_t b,
@@ -477,6 +480,41 @@ __device__ __forceinline__ void layer_row_regs(const FloodDev &d, ST *__restrict
         if (active) {
             Store<ST>::st(lam + (size_t)col[k] * d.Bp + b, nw);
             Store<ST>::st(msg + (size_t)(ebeg + k) * d.Bp + b, nm[k]);
+        }
+    }
+}
+
+// two rows of one layer (same weight, disjoint columns): every load of both rows is issued before either is used
+template <typename ST, int VARIANT, int DEG>
+__device__ __forceinline__ void layer_row_pair(const FloodDev &d, ST *__restrict__ msg, ST *__restrict__ lam, int ea, int eb, size_t b,
+                                               bool active, bool &odd, bool &flip) {
+    using CT = typename Store<ST>::CT;
+    int ca[DEG], cb[DEG];
+#pragma unroll
+    for (int k = 0; k < DEG; k++) { ca[k] = d.col_idx[ea + k]; cb[k] = d.col_idx[eb + k]; }
+    CT la[DEG], lb[DEG], ta[DEG], tb[DEG];
+#pragma unroll
+    for (int k = 0; k < DEG; k++) { la[k] = Store<ST>::ld(lam + (size_t)ca[k] * d.Bp + b); lb[k] = Store<ST>::ld(lam + (size_t)cb[k] * d.Bp + b); }
+#pragma unroll
+    for (int k = 0; k < DEG; k++) { ta[k] = Store<ST>::ld(msg + (size_t)(ea + k) * d.Bp + b); tb[k] = Store<ST>::ld(msg + (size_t)(eb + k) * d.Bp + b); }
+    bool pa = false, pb = false;
+#pragma unroll
+    for (int k = 0; k < DEG; k++) { pa ^= hard(la[k]); pb ^= hard(lb[k]); }
+    odd |= (pa || pb) && active;
+    CT na[DEG], nb[DEG];
+#pragma unroll
+    for (int k = 0; k < DEG; k++) { ta[k] = la[k] - ta[k]; na[k] = ta[k]; tb[k] = lb[k] - tb[k]; nb[k] = tb[k]; }
+    cn_update<CT, VARIANT, DEG>(na);
+    cn_update<CT, VARIANT, DEG>(nb);
+#pragma unroll
+    for (int k = 0; k < DEG; k++) {
+        const CT wa = ta[k] + na[k], wb = tb[k] + nb[k];
+        flip |= active && ((hard(wa) != hard(la[k])) || (hard(wb) != hard(lb[k])));
+        if (active) {
+            Store<ST>::st(lam + (size_t)ca[k] * d.Bp + b, wa);
+            Store<ST>::st(msg + (size_t)(ea + k) * d.Bp + b, na[k]);
+            Store<ST>::st(lam + (size_t)cb[k] * d.Bp + b, wb);
+            Store<ST>::st(msg + (size_t)(eb + k) * d.Bp + b, nb[k]);
         }
     }
 }
@@ -550,7 +588,7 @@ __device__ __forceinline__ void layer_row(const FloodDev &d, ST *msg, ST *lam, i
     }
 }
 
-template <typename ST, int VARIANT, int DCLASS>
+template <typename ST, int VARIANT, int DCLASS, int kLayerWaves>
 __global__ __launch_bounds__(kWave *kLayerWaves) void layered_kernel(FloodDev d, LayerDev L, ST *msg, ST *lam, LayerArgs A) {
     using CT = typename Store<ST>::CT;
     __shared__ uint32_t flags[kLayerWaves][kWave];   // bit 0: odd, bit 1: flip -- per wave, per frame of the slab
@@ -590,7 +628,30 @@ __global__ __launch_bounds__(kWave *kLayerWaves) void layered_kernel(FloodDev d,
         bool odd = false, flip = false;
         for (int l = 0; l < L.n_layers; l++) {
             const int r0 = L.layer_ptr[l], r1 = L.layer_ptr[l + 1];
-            for (int r = r0 + wave; r < r1; r += kLayerWaves) layer_row<ST, VARIANT, DCLASS, false>(d, msg, lam, r, b, open, odd, flip);
+            int r = r0 + wave;
+            if constexpr (DCLASS <= 8) {
+                // two rows of the layer at a time when they have the same weight (always, for a QC block row): both rows'
+                // loads are in flight together
+                for (; r + kLayerWaves < r1; r += 2 * kLayerWaves) {
+                    const int ra = r, rb = r + kLayerWaves;
+                    const int ea = d.row_ptr[ra], da = d.row_ptr[ra + 1] - ea, eb = d.row_ptr[rb], db = d.row_ptr[rb + 1] - eb;
+                    if (da == db && da >= 2 && da <= 8) {
+                        switch (da) {
+                            case 2: layer_row_pair<ST, VARIANT, 2>(d, msg, lam, ea, eb, b, open, odd, flip); break;
+                            case 3: layer_row_pair<ST, VARIANT, 3>(d, msg, lam, ea, eb, b, open, odd, flip); break;
+                            case 4: layer_row_pair<ST, VARIANT, 4>(d, msg, lam, ea, eb, b, open, odd, flip); break;
+                            case 5: layer_row_pair<ST, VARIANT, 5>(d, msg, lam, ea, eb, b, open, odd, flip); break;
+                            case 6: layer_row_pair<ST, VARIANT, 6>(d, msg, lam, ea, eb, b, open, odd, flip); break;
+                            case 7: layer_row_pair<ST, VARIANT, 7>(d, msg, lam, ea, eb, b, open, odd, flip); break;
+                            default: layer_row_pair<ST, VARIANT, 8>(d, msg, lam, ea, eb, b, open, odd, flip); break;
+                        }
+                    } else {
+                        layer_row<ST, VARIANT, DCLASS, false>(d, msg, lam, ra, b, open, odd, flip);
+                        layer_row<ST, VARIANT, DCLASS, false>(d, msg, lam, rb, b, open, odd, flip);
+                    }
+                }
+            }
+            for (; r < r1; r += kLayerWaves) layer_row<ST, VARIANT, DCLASS, false>(d, msg, lam, r, b, open, odd, flip);
             __syncthreads();           // the next layer reads what this one wrote (workgroup-scope release/acquire)
         }
         const uint32_t f = combine(odd, flip);
@@ -727,11 +788,21 @@ template <typename ST, int VARIANT>
 static int layered_launch(FloodState &s, hipStream_t st, const LayerArgs &a) {
     FloodDev d = s.dev;
     LayerDev L{s.n_layers, s.d_layer_ptr};
-    const dim3 grid(d.Bp / kWave), block(kWave * kLayerWaves);
+    const int slabs = d.Bp / kWave;
+    // LDPC_LAYER_WAVES=8|16 overrides (A/B measurements)
+    static const int forced = [] { const char *e = getenv("LDPC_LAYER_WAVES"); return e ? atoi(e) : 0; }();
+    const bool narrow = forced ? forced == 8 : slabs >= 512;
+    const dim3 grid(slabs), block(kWave * (narrow ? 8 : kLayerWavesMax));
     if (s.timer && !a.step_mode) s.timer->begin(st);
-    if (s.max_row_deg <= 8) hipLaunchKernelGGL((layered_kernel<ST, VARIANT, 8>), grid, block, 0, st, d, L, (ST *)s.msg, (ST *)s.lam, a);
-    else if (s.max_row_deg <= 20) hipLaunchKernelGGL((layered_kernel<ST, VARIANT, 20>), grid, block, 0, st, d, L, (ST *)s.msg, (ST *)s.lam, a);
-    else hipLaunchKernelGGL((layered_kernel<ST, VARIANT, 32>), grid, block, 0, st, d, L, (ST *)s.msg, (ST *)s.lam, a);
+#define LAUNCH_LAYERED(DC)                                                                                                                       \
+    do {                                                                                                                                         \
+        if (narrow) hipLaunchKernelGGL((layered_kernel<ST, VARIANT, DC, 8>), grid, block, 0, st, d, L, (ST *)s.msg, (ST *)s.lam, a);             \
+        else hipLaunchKernelGGL((layered_kernel<ST, VARIANT, DC, kLayerWavesMax>), grid, block, 0, st, d, L, (ST *)s.msg, (ST *)s.lam, a);       \
+    } while (0)
+    if (s.max_row_deg <= 8) LAUNCH_LAYERED(8);
+    else if (s.max_row_deg <= 20) LAUNCH_LAYERED(20);
+    else LAUNCH_LAYERED(32);
+#undef LAUNCH_LAYERED
     if (s.timer && !a.step_mode) s.timer->end(st);
     HIPCHK(hipGetLastError());
     return LDPC_OK;

@@ -1,0 +1,326 @@
+// layered_qc.hip -- row-layered schedule for quasi-cyclic codes of ANY size, state in HBM, one workgroup per FRAME.
+//
+// BASELINE.json configs[4]: "DVB-S2 n = 64 800 long code, layered min-sum + early termination".  A frame of that
+// size keeps 253 KB of LLRs and 886 KB of messages -- nothing of it fits on-chip -- and early termination makes frames
+// of one batch finish at very different sweeps.  The batch-major layered kernel in flood.hip (lane = codeword, any H)
+// keeps a 64-frame slab going until its SLOWEST frame is done while the finished lanes still occupy their share of
+// every cache line: measured on the DVB-S2-shaped code at 2 dB, 17 sweeps are needed on average but ~50 are streamed.
+// Here the mapping is the on-chip kernels' (lane = row of the circulant, a layer = a block row, a workgroup = one
+// frame) with the state left in HBM:
+//   lam [frame][N]                 a-posteriori LLRs
+//   msg [frame][edge block][sz]    check->variable messages, row of the circulant fastest
+// so a wave reads 64 consecutive lam cells of a block column (rotated: one wrap) and 64 consecutive messages: every
+// access is coalesced, every graph index is wave-uniform (scalar loads of {block-column base, rotation}), and a frame
+// leaves the machine the moment ITS stopping rule fires.  Circulant sizes need not be powers of two (DVB-S2: 360);
+// lanes beyond sz idle.  Latency is hidden by frames, not by waves per frame: ~40 VGPRs -> 8 waves per SIMD -> five
+// 6-wave frames per CU.
+// Algorithmic HBM bytes per frame: sweeps * 4E * s (every edge reads and writes its lam cell and its message; the
+// first sweep reads no messages) + the LLRs in, lam initialised, the bits out.
+// Specification and arithmetic: oracle_decode_layered (oracle/ldpc_oracle.c); check rules of ldpc_math.h.
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <vector>
+
+#include "layered_qc.h"
+#include "ldpc_math.h"
+
+namespace ldpc {
+
+// the graph tables are read through the CONSTANT address space: the kernel never writes them, and only then may the
+// compiler use scalar loads although the kernel also stores to global memory (as in the fused kernels, fused_common.h)
+typedef const __attribute__((address_space(4))) int32_t *cidx_t;
+struct QcLayerDev {
+    int sz, nbr, nbc, N, E;         // E = (number of circulants) * sz
+    const int32_t *tab;             // per circulant, block-row-major: {block column * sz, rotation} (two words)
+    const int32_t *lbeg;            // [nbr + 1] first circulant of each block row
+};
+
+struct QcLayerArgs {
+    const void *llr; int llr_fmt;   // [batch][N]
+    uint8_t *bits; int32_t *iters; uint8_t *conv;
+    double *final_lam, *trace;      // may be null
+    int batch, max_iters, step_mode;
+    const double *st_lam, *st_ne_in; double *st_ne_out, *st_lam_out; uint8_t *st_syn;   // teacher-forced sweep (CSR edge order)
+};
+
+template <typename CT, int VARIANT, int DEG, int MODE /* 0: sweep, 1: first sweep (messages are zero), 2: syndrome only */>
+__device__ __forceinline__ void qc_row(const QcLayerDev &g, CT *__restrict__ lam, CT *__restrict__ msg, int e0, int r, bool live, bool &odd, bool &flip) {
+    int idx[DEG];
+    CT l[DEG], t[DEG];
+#pragma unroll
+    for (int k = 0; k < DEG; k++) {
+        const int cb = ((cidx_t)g.tab)[2 * (e0 + k)], rot = ((cidx_t)g.tab)[2 * (e0 + k) + 1];   // wave-uniform -> scalar loads
+        int c = r + rot;
+        c -= (c >= g.sz) ? g.sz : 0;
+        idx[k] = cb + c;
+    }
+#pragma unroll
+    for (int k = 0; k < DEG; k++) l[k] = live ? lam[idx[k]] : CT(0);
+    if constexpr (MODE == 0) {
+#pragma unroll
+        for (int k = 0; k < DEG; k++) t[k] = live ? msg[(size_t)(e0 + k) * g.sz + r] : CT(0);
+    }
+    bool par = false;
+#pragma unroll
+    for (int k = 0; k < DEG; k++) par ^= hard(l[k]);
+    odd |= par && live;
+    if constexpr (MODE == 2) return;
+    CT nm[DEG];
+#pragma unroll
+    for (int k = 0; k < DEG; k++) { t[k] = (MODE == 0) ? l[k] - t[k] : l[k] - CT(0); nm[k] = t[k]; }
+    cn_update<CT, VARIANT, DEG>(nm);
+#pragma unroll
+    for (int k = 0; k < DEG; k++) {
+        const CT nw = t[k] + nm[k];
+        flip |= live && (hard(nw) != hard(l[k]));
+        if (live) { lam[idx[k]] = nw; msg[(size_t)(e0 + k) * g.sz + r] = nm[k]; }
+    }
+}
+
+template <typename CT, int VARIANT, int DMAX, int MODE>
+__device__ __forceinline__ void qc_row_padded(const QcLayerDev &g, CT *__restrict__ lam, CT *__restrict__ msg, int e0, int deg, int r, bool live,
+                                              bool &odd, bool &flip) {
+    int idx[DMAX];
+    CT l[DMAX], t[DMAX];
+#pragma unroll
+    for (int k = 0; k < DMAX; k++) {
+        const int kk = k < deg ? k : 0;
+        const int cb = ((cidx_t)g.tab)[2 * (e0 + kk)], rot = ((cidx_t)g.tab)[2 * (e0 + kk) + 1];
+        int c = r + rot;
+        c -= (c >= g.sz) ? g.sz : 0;
+        idx[k] = cb + c;
+    }
+#pragma unroll
+    for (int k = 0; k < DMAX; k++) l[k] = (live && k < deg) ? lam[idx[k]] : CT(0);
+    if constexpr (MODE == 0) {
+#pragma unroll
+        for (int k = 0; k < DMAX; k++) t[k] = (live && k < deg) ? msg[(size_t)(e0 + k) * g.sz + r] : CT(0);
+    }
+    bool par = false;
+#pragma unroll
+    for (int k = 0; k < DMAX; k++) par ^= (k < deg) && hard(l[k]);
+    odd |= par && live;
+    if constexpr (MODE == 2) return;
+    CT nm[DMAX];
+#pragma unroll
+    for (int k = 0; k < DMAX; k++) { t[k] = (k < deg) ? ((MODE == 0) ? l[k] - t[k] : l[k] - CT(0)) : CT(INFINITY); nm[k] = t[k]; }
+    cn_update_padded<CT, VARIANT, DMAX>(nm, deg);
+#pragma unroll
+    for (int k = 0; k < DMAX; k++) {
+        if (k < deg) {
+            const CT nw = t[k] + nm[k];
+            flip |= live && (hard(nw) != hard(l[k]));
+            if (live) { lam[idx[k]] = nw; msg[(size_t)(e0 + k) * g.sz + r] = nm[k]; }
+        }
+    }
+}
+
+template <typename CT, int VARIANT, int DCLASS, int MODE>
+__device__ __forceinline__ void qc_layer(const QcLayerDev &g, CT *lam, CT *msg, int layer, int r, bool live, bool &odd, bool &flip) {
+    const int e0 = ((cidx_t)g.lbeg)[layer], deg = ((cidx_t)g.lbeg)[layer + 1] - e0;
+    switch (deg) {
+        case 0: return;
+        case 1:
+            if constexpr (VARIANT == LDPC_V_TANH) qc_row<CT, VARIANT, 1, MODE>(g, lam, msg, e0, r, live, odd, flip);
+            else qc_row<CT, VARIANT, 2, 2>(g, lam, msg, e0, r, live, odd, flip);    // (min-sum on weight 1 is rejected at creation; never reached)
+            return;
+        case 2: qc_row<CT, VARIANT, 2, MODE>(g, lam, msg, e0, r, live, odd, flip); return;
+        case 3: qc_row<CT, VARIANT, 3, MODE>(g, lam, msg, e0, r, live, odd, flip); return;
+        case 4: qc_row<CT, VARIANT, 4, MODE>(g, lam, msg, e0, r, live, odd, flip); return;
+        case 5: qc_row<CT, VARIANT, 5, MODE>(g, lam, msg, e0, r, live, odd, flip); return;
+        case 6: qc_row<CT, VARIANT, 6, MODE>(g, lam, msg, e0, r, live, odd, flip); return;
+        case 7: qc_row<CT, VARIANT, 7, MODE>(g, lam, msg, e0, r, live, odd, flip); return;
+        case 8: qc_row<CT, VARIANT, 8, MODE>(g, lam, msg, e0, r, live, odd, flip); return;
+        default: break;
+    }
+    if constexpr (DCLASS >= 20) {
+        if (deg == 18) { qc_row<CT, VARIANT, 18, MODE>(g, lam, msg, e0, r, live, odd, flip); return; }
+        if (deg <= 12) { qc_row_padded<CT, VARIANT, 12, MODE>(g, lam, msg, e0, deg, r, live, odd, flip); return; }
+        if (deg <= 16) { qc_row_padded<CT, VARIANT, 16, MODE>(g, lam, msg, e0, deg, r, live, odd, flip); return; }
+        if (deg <= 20) { qc_row_padded<CT, VARIANT, 20, MODE>(g, lam, msg, e0, deg, r, live, odd, flip); return; }
+    }
+    if constexpr (DCLASS >= 32) {
+        if (deg <= 24) { qc_row_padded<CT, VARIANT, 24, MODE>(g, lam, msg, e0, deg, r, live, odd, flip); return; }
+        if (deg <= 32) { qc_row_padded<CT, VARIANT, 32, MODE>(g, lam, msg, e0, deg, r, live, odd, flip); return; }
+    }
+}
+
+// block = ceil(sz / 64) waves; thread r = row r of every circulant (threads >= sz idle); grid = frames
+template <typename CT, int VARIANT, int DCLASS>
+__global__ __launch_bounds__(1024) void layered_qc_kernel(QcLayerDev g, CT *lam_all, CT *msg_all, QcLayerArgs A) {
+    const int r = threadIdx.x;
+    const bool live = r < g.sz;
+    const size_t frame = blockIdx.x;
+    CT *lam = lam_all + frame * (size_t)g.N;
+    CT *msg = msg_all + frame * (size_t)g.E;
+    const size_t fN = frame * (size_t)g.N;
+    // ---- lam <- channel LLRs (or the given state)
+    if (A.step_mode) {
+        for (int i = r; i < g.N; i += blockDim.x) lam[i] = (CT)A.st_lam[fN + i];
+        for (int l = 0; l < g.nbr; l++) {       // messages arrive in CSR edge order: row-major, ascending column
+            const int e0 = g.lbeg[l], deg = g.lbeg[l + 1] - e0;
+            if (live)
+                for (int k = 0; k < deg; k++) msg[(size_t)(e0 + k) * g.sz + r] = (CT)A.st_ne_in[frame * (size_t)g.E + (size_t)e0 * g.sz + (size_t)r * deg + k];
+        }
+    } else {
+        for (int i = r; i < g.N; i += blockDim.x) lam[i] = load_llr<CT>(A.llr, fN + i, A.llr_fmt);
+    }
+    __syncthreads();
+    bool conv = false;
+    int n = 0;
+    {   // syndrome of the hard decisions before the first sweep
+        bool odd = false, flip = false;
+        for (int l = 0; l < g.nbr; l++) qc_layer<CT, VARIANT, DCLASS, 2>(g, lam, msg, l, r, live, odd, flip);
+        const int any = __syncthreads_or(odd ? 1 : 0);
+        if (A.step_mode) { if (r == 0) A.st_syn[frame] = any ? 0 : 1; }
+        else conv = !any;
+    }
+    if (A.trace && !A.step_mode)
+        for (int i = r; i < g.N; i += blockDim.x) A.trace[(frame * (A.max_iters + 1)) * (size_t)g.N + i] = (double)lam[i];
+    if (!conv) {
+        for (n = 1; n <= A.max_iters; n++) {
+            bool odd = false, flip = false;
+            if (n == 1 && !A.step_mode) {
+                for (int l = 0; l < g.nbr; l++) { qc_layer<CT, VARIANT, DCLASS, 1>(g, lam, msg, l, r, live, odd, flip); __syncthreads(); }
+            } else {
+                for (int l = 0; l < g.nbr; l++) { qc_layer<CT, VARIANT, DCLASS, 0>(g, lam, msg, l, r, live, odd, flip); __syncthreads(); }
+            }
+            const int any = __syncthreads_or((odd || flip) ? 1 : 0);
+            if (A.trace && !A.step_mode) {
+                for (int i = r; i < g.N; i += blockDim.x) A.trace[(frame * (A.max_iters + 1) + n) * (size_t)g.N + i] = (double)lam[i];
+                __syncthreads();
+            }
+            if (A.step_mode) break;
+            if (!any) { conv = true; break; }
+        }
+        if (n > A.max_iters) n = A.max_iters;
+    }
+    if (A.step_mode) {
+        for (int i = r; i < g.N; i += blockDim.x) A.st_lam_out[fN + i] = (double)lam[i];
+        for (int l = 0; l < g.nbr; l++) {
+            const int e0 = g.lbeg[l], deg = g.lbeg[l + 1] - e0;
+            if (live)
+                for (int k = 0; k < deg; k++) A.st_ne_out[frame * (size_t)g.E + (size_t)e0 * g.sz + (size_t)r * deg + k] = (double)msg[(size_t)(e0 + k) * g.sz + r];
+        }
+        return;
+    }
+    // ---- result: hard(lam) of a frame that stopped by the rule, the channel's decisions otherwise (as Orig.hs:69-70)
+    for (int i = r; i < g.N; i += blockDim.x) {
+        const CT v = conv ? lam[i] : load_llr<CT>(A.llr, fN + i, A.llr_fmt);
+        A.bits[fN + i] = v > CT(0) ? 1 : 0;
+        if (A.final_lam) A.final_lam[fN + i] = (double)v;
+    }
+    if (r == 0) {
+        if (A.iters) A.iters[frame] = conv ? n : A.max_iters;
+        if (A.conv) A.conv[frame] = conv ? 1 : 0;
+    }
+}
+
+// ------------------------------------------------------------------ host side
+struct LayeredQcState {
+    int variant = 0, dtype = 0, max_batch = 0, max_row_deg = 0, threads = 0;
+    QcLayerDev g{};
+    int32_t *d_tab = nullptr;
+    int32_t *d_lbeg = nullptr;
+    void *lam = nullptr, *msg = nullptr;
+    KernelTimer *timer = nullptr;
+    LaunchInfo info;
+};
+
+const char *layered_qc_why_not(const ldpc_code &c, int variant, int dtype) {
+    if (c.sz <= 0) return "code was not created from a quasi-cyclic description";
+    if (c.sz > 1024) return "circulant size above 1024";
+    if (dtype != LDPC_F32 && dtype != LDPC_F64) return "the layered schedule exists for f32 and f64";
+    if (c.max_row_deg > 32) return "check rows above weight 32";
+    if ((int)c.layer_ptr.size() != c.block_rows + 1) return "layers were replaced: not the block rows";
+    for (int br = 0; br <= c.block_rows; br++) if (c.layer_ptr[br] != br * c.sz) return "layers were replaced: not the block rows";
+    const char *e = getenv("LDPC_LAYERED_QC");
+    if (e && !strcmp(e, "0")) return "disabled (LDPC_LAYERED_QC=0)";
+    return nullptr;
+}
+
+void layered_qc_destroy(LayeredQcState *s) {
+    if (!s) return;
+    (void)hipFree(s->d_tab); (void)hipFree(s->d_lbeg); (void)hipFree(s->lam); (void)hipFree(s->msg);
+    delete s;
+}
+
+LayeredQcState *layered_qc_create(const ldpc_code &c, int variant, int dtype, int max_batch) {
+    const char *why = layered_qc_why_not(c, variant, dtype);
+    if (why) { set_error(LDPC_EUNSUPPORTED, "%s", why); return nullptr; }
+    LayeredQcState *s = new (std::nothrow) LayeredQcState();
+    if (!s) { set_error(LDPC_ENOMEM, "out of host memory"); return nullptr; }
+    try {
+        s->variant = variant; s->dtype = dtype; s->max_batch = max_batch; s->max_row_deg = c.max_row_deg;
+        std::vector<int32_t> tab;
+        std::vector<int32_t> lbeg(1, 0);
+        for (int br = 0; br < c.block_rows; br++) {
+            for (int bc = 0; bc < c.block_cols; bc++) {
+                const int off = c.offsets[(size_t)br * c.block_cols + bc];
+                if (off >= 0) { tab.push_back(bc * c.sz); tab.push_back(off); }
+            }
+            lbeg.push_back((int32_t)(tab.size() / 2));
+        }
+        s->g.sz = c.sz; s->g.nbr = c.block_rows; s->g.nbc = c.block_cols; s->g.N = c.N; s->g.E = c.E;
+        s->threads = (c.sz + 63) / 64 * 64;
+        const size_t es = dtype == LDPC_F64 ? 8 : 4;
+        hipError_t e = hipMalloc((void **)&s->d_tab, sizeof(int32_t) * std::max<size_t>(tab.size(), 2));
+        if (e == hipSuccess) e = hipMalloc((void **)&s->d_lbeg, sizeof(int32_t) * lbeg.size());
+        if (e == hipSuccess) e = hipMalloc(&s->lam, (size_t)max_batch * c.N * es);
+        if (e == hipSuccess) e = hipMalloc(&s->msg, (size_t)max_batch * std::max(c.E, 1) * es);
+        if (e == hipSuccess && !tab.empty()) e = hipMemcpy(s->d_tab, tab.data(), sizeof(int32_t) * tab.size(), hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(s->d_lbeg, lbeg.data(), sizeof(int32_t) * lbeg.size(), hipMemcpyHostToDevice);
+        if (e != hipSuccess) {
+            set_error(e == hipErrorOutOfMemory ? LDPC_ENOMEM : LDPC_EHIP, "layered_qc_create (%d frames x %zu bytes of state): %s", max_batch,
+                      ((size_t)c.N + c.E) * es, hipGetErrorString(e));
+            layered_qc_destroy(s);
+            return nullptr;
+        }
+        s->g.tab = s->d_tab; s->g.lbeg = s->d_lbeg;
+        snprintf(s->info.name, sizeof(s->info.name), "ldpc::layered_qc_kernel<%s, %d, %d>", dtype == LDPC_F64 ? "double" : "float",
+                 variant == LDPC_MINSUM ? LDPC_V_MINSUM : LDPC_V_TANH, c.max_row_deg <= 8 ? 8 : (c.max_row_deg <= 20 ? 20 : 32));
+        s->info.threads = s->threads; s->info.frames_per_wg = 1;
+        return s;
+    } catch (...) { layered_qc_destroy(s); set_error(LDPC_ENOMEM, "out of host memory"); return nullptr; }
+}
+
+void layered_qc_set_timer(LayeredQcState *s, KernelTimer *t) { if (s) s->timer = t; }
+const LaunchInfo &layered_qc_launch_info(const LayeredQcState &s) { return s.info; }
+
+template <typename CT, int VARIANT>
+static int launch(LayeredQcState &s, hipStream_t st, QcLayerArgs &a) {
+    const dim3 grid(a.batch), block(s.threads);
+    if (s.timer && !a.step_mode) s.timer->begin(st);
+    if (s.max_row_deg <= 8) hipLaunchKernelGGL((layered_qc_kernel<CT, VARIANT, 8>), grid, block, 0, st, s.g, (CT *)s.lam, (CT *)s.msg, a);
+    else if (s.max_row_deg <= 20) hipLaunchKernelGGL((layered_qc_kernel<CT, VARIANT, 20>), grid, block, 0, st, s.g, (CT *)s.lam, (CT *)s.msg, a);
+    else hipLaunchKernelGGL((layered_qc_kernel<CT, VARIANT, 32>), grid, block, 0, st, s.g, (CT *)s.lam, (CT *)s.msg, a);
+    if (s.timer && !a.step_mode) s.timer->end(st);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return set_error(LDPC_EHIP, "layered_qc launch: %s", hipGetErrorString(e));
+    return LDPC_OK;
+}
+
+static int run(LayeredQcState &s, hipStream_t st, QcLayerArgs &a) {
+    if (s.dtype == LDPC_F64) return s.variant == LDPC_MINSUM ? launch<double, LDPC_V_MINSUM>(s, st, a) : launch<double, LDPC_V_TANH>(s, st, a);
+    return s.variant == LDPC_MINSUM ? launch<float, LDPC_V_MINSUM>(s, st, a) : launch<float, LDPC_V_TANH>(s, st, a);
+}
+
+int layered_qc_decode(LayeredQcState &s, hipStream_t st, int max_iters, int batch, const void *d_llr, int llr_fmt, uint8_t *d_bits, int32_t *d_iters,
+                      uint8_t *d_conv, double *d_final, double *d_trace) {
+    QcLayerArgs a{};
+    a.llr = d_llr; a.llr_fmt = llr_fmt; a.bits = d_bits; a.iters = d_iters; a.conv = d_conv; a.final_lam = d_final; a.trace = d_trace;
+    a.batch = batch; a.max_iters = max_iters;
+    return run(s, st, a);
+}
+
+int layered_qc_step(LayeredQcState &s, hipStream_t st, int batch, const double *d_orig, const double *d_lam, const double *d_ne, double *d_ne_out,
+                    double *d_lam_out, uint8_t *d_syn) {
+    QcLayerArgs a{};
+    a.llr = d_orig; a.llr_fmt = LLR_F64; a.batch = batch; a.max_iters = 1; a.step_mode = 1;
+    a.st_lam = d_lam; a.st_ne_in = d_ne; a.st_ne_out = d_ne_out; a.st_lam_out = d_lam_out; a.st_syn = d_syn;
+    return run(s, st, a);
+}
+
+}  // namespace ldpc

@@ -415,6 +415,43 @@ int oracle_decode_layered(int M, int N, const int32_t *row_ptr, const int32_t *c
     return rc;
 }
 
+/* batch driver of the layered extension (bench.py cpu_baseline leg for --schedule layered) */
+typedef struct {
+    int M, N; const int32_t *row_ptr, *col_idx; int n_layers; const int32_t *layer_ptr; int variant, max_iters;
+    const double *llr; uint8_t *bits; int32_t *iters; uint8_t *conv; int f0, f1, rc;
+} ljob_t;
+static void *ljob_run(void *p) {
+    ljob_t *j = p;
+    for (int f = j->f0; f < j->f1; f++) {
+        int it = 0, cv = 0;
+        int rc = oracle_decode_layered(j->M, j->N, j->row_ptr, j->col_idx, j->n_layers, j->layer_ptr, j->variant, j->max_iters,
+                                       j->llr + (size_t)f * j->N, j->bits + (size_t)f * j->N, &it, &cv, NULL, NULL);
+        if (rc != ORACLE_OK) { j->rc = rc; break; }
+        if (j->iters) j->iters[f] = it;
+        if (j->conv) j->conv[f] = (uint8_t)cv;
+    }
+    return NULL;
+}
+int oracle_decode_layered_batch(int M, int N, const int32_t *row_ptr, const int32_t *col_idx, int n_layers, const int32_t *layer_ptr,
+                                int variant, int max_iters, int frames, const double *llr, uint8_t *bits, int32_t *iters,
+                                uint8_t *converged, int nthreads) {
+    if (frames < 0 || nthreads < 1 || !llr || !bits) return ORACLE_EARG;
+    if (nthreads > frames) nthreads = frames > 0 ? frames : 1;
+    ljob_t *jobs = calloc((size_t)nthreads, sizeof(ljob_t));
+    pthread_t *th = calloc((size_t)nthreads, sizeof(pthread_t));
+    int rc = ORACLE_OK;
+    for (int t = 0; t < nthreads; t++) {
+        jobs[t] = (ljob_t){M, N, row_ptr, col_idx, n_layers, layer_ptr, variant, max_iters, llr, bits, iters, converged,
+                           (int)((long long)frames * t / nthreads), (int)((long long)frames * (t + 1) / nthreads), ORACLE_OK};
+        if (t > 0) pthread_create(&th[t], NULL, ljob_run, &jobs[t]);
+    }
+    ljob_run(&jobs[0]);
+    for (int t = 1; t < nthreads; t++) pthread_join(th[t], NULL);
+    for (int t = 0; t < nthreads; t++) if (jobs[t].rc != ORACLE_OK) rc = jobs[t].rc;
+    free(jobs); free(th);
+    return rc;
+}
+
 /* Teacher-forcing helper: one update from a given (lam, ne) state; also reports the syndrome of lam. */
 int oracle_step(int M, int N, const int32_t *row_ptr, const int32_t *col_idx, int variant,
                 const double *orig_lam, const double *lam, const double *ne, double *ne_out,

@@ -34,6 +34,7 @@ def lib():
         L.oracle_step.argtypes = [C.c_int, C.c_int, i32p, i32p, C.c_int, f64p, f64p, f64p, f64p, f64p, ip]
         L.oracle_decode_batch.argtypes = [C.c_int, C.c_int, i32p, i32p, C.c_int, C.c_int, C.c_int, f64p, u8p, i32p, u8p, C.c_int]
         L.oracle_decode_layered.argtypes = [C.c_int, C.c_int, i32p, i32p, C.c_int, i32p, C.c_int, C.c_int, f64p, u8p, ip, ip, f64p, f64p]
+        L.oracle_decode_layered_batch.argtypes = [C.c_int, C.c_int, i32p, i32p, C.c_int, i32p, C.c_int, C.c_int, C.c_int, f64p, u8p, i32p, u8p, C.c_int]
         L.oracle_layered_step.argtypes = [C.c_int, C.c_int, i32p, i32p, C.c_int, f64p, f64p, f64p, f64p, ip, ip]
         L.oracle_encode_dense.argtypes = [C.c_int, C.c_int, u8p, u8p, u8p]
         L.oracle_encode_qc.argtypes = [C.c_int, C.c_int, C.c_int, u8p, u8p, u8p]
@@ -109,6 +110,21 @@ def decode_layered(g: Graph, layer_ptr, variant, max_iters, llr, trace=False):
     if trace:
         out["trace_lam"] = tl[: it.value + 1]
     return out
+
+
+def decode_layered_batch(g: Graph, layer_ptr, variant, max_iters, llr, nthreads=1):
+    llr = np.ascontiguousarray(llr, dtype=np.float64)
+    lp = np.ascontiguousarray(layer_ptr, dtype=np.int32)
+    F = llr.shape[0]
+    bits = np.zeros((F, g.N), np.uint8)
+    iters = np.zeros(F, np.int32)
+    conv = np.zeros(F, np.uint8)
+    rc = lib().oracle_decode_layered_batch(g.M, g.N, _p(g.row_ptr, C.c_int32), _p(g.col_idx, C.c_int32), len(lp) - 1, _p(lp, C.c_int32),
+                                           _variant(variant), int(max_iters), F, _p(llr, C.c_double), _p(bits, C.c_uint8),
+                                           _p(iters, C.c_int32), _p(conv, C.c_uint8), int(nthreads))
+    if rc != 0:
+        raise RuntimeError(f"oracle_decode_layered_batch rc={rc}")
+    return bits, iters, conv
 
 
 def layered_step(g: Graph, variant, lam, msg):

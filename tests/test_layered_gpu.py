@@ -27,6 +27,8 @@ def test_f64_trajectory(hip, name, db, variant):
     _, llr = c.frames(6, db, seed=900)
     dec = hip.Decoder(c.hip_code(hip), variant, "f64", len(llr), schedule="layered")
     assert dec.schedule == "layered" and dec.path == "flood" and np.array_equal(dec.code.layers(), lp)
+    # QC codes: one workgroup per frame (layered_qc.hip); any other H: the batch-major kernel (flood.hip)
+    assert ("layered_qc_kernel" in dec.kernel_name) == (name != "moon.7.13"), dec.kernel_name
     bits, its, conv, trace = dec.decode_trace(llr, 25)
     for f in range(len(llr)):
         o = oracle.decode_layered(c.graph, lp, variant, 25, llr[f], trace=True)
@@ -73,6 +75,29 @@ def test_f32_free_running_and_teacher_forced(hip, name, dbs):
                 worst = max(worst, (np.abs(lam2[i] - s[4]) / np.maximum(1, np.abs(s[4]))).max())
             print(f"{name} layered {variant} f32: {int(conv.sum())}/{F} converged, sweeps {100 * (its == oi).mean():.0f}% identical, "
                   f"worst teacher-forced relative LLR error {worst:.2e} over {len(states)} sweeps")
+
+
+@pytest.mark.parametrize("name", ["jpl.1024.4.5", "ira-12x24-sz64"])
+def test_both_layered_kernels_agree_on_qc_codes(hip, name, monkeypatch):
+    """the frame-per-workgroup QC kernel and the batch-major any-H kernel implement one specification: identical f32
+    results (bits, sweeps, flags), f64 trajectories identical bit for bit"""
+    c = _get(name)
+    _, llr = c.frames(70, 3.0, seed=123)
+    code = c.hip_code(hip)
+    for variant in ("min", "tanh"):
+        qc = hip.Decoder(code, variant, "f32", 70, schedule="layered")
+        monkeypatch.setenv("LDPC_LAYERED_QC", "0")
+        bm = hip.Decoder(code, variant, "f32", 70, schedule="layered")
+        bm64 = hip.Decoder(code, variant, "f64", 4, schedule="layered")
+        monkeypatch.delenv("LDPC_LAYERED_QC")
+        assert "layered_qc_kernel" in qc.kernel_name and bm.kernel_name == "layered_kernel"
+        a = qc.decode_batch(llr.astype(np.float32), 40)
+        b = bm.decode_batch(llr.astype(np.float32), 40)
+        assert all(np.array_equal(x, y) for x, y in zip(a, b)), (name, variant)
+        qc64 = hip.Decoder(code, variant, "f64", 4, schedule="layered")
+        ta = qc64.decode_trace(llr[:4], 20)
+        tb = bm64.decode_trace(llr[:4], 20)
+        assert all(np.array_equal(x, y) for x, y in zip(ta, tb))
 
 
 def test_layered_needs_fewer_sweeps_and_same_answers(hip):

@@ -26,7 +26,9 @@ class CtxConfig(C.Structure):   # ldpc_ctx_config
 
 # every symbol include/ldpc_hip.h declares (tests/test_abi.py checks the library exports them all)
 ABI_SYMBOLS = [
-    "ldpc_init", "ldpc_shutdown", "ldpc_current_device", "ldpc_ctx_create_on", "ldpc_sim_create_on", "ldpc_ctx_create_cfg", "ldpc_ctx_schedule", "ldpc_code_set_layers", "ldpc_code_layers", "ldpc_last_error", "ldpc_last_error_code", "ldpc_abi_version", "ldpc_device_count",
+    "ldpc_init", "ldpc_shutdown", "ldpc_current_device", "ldpc_ctx_create_on", "ldpc_sim_create_on", "ldpc_ctx_create_cfg", "ldpc_ctx_schedule", "ldpc_ctx_code", "ldpc_ctx_max_batch", "ldpc_ctx_device",
+    "ldpc_batcher_create", "ldpc_batcher_destroy", "ldpc_batcher_decode_one", "ldpc_batcher_stats",
+    "ldpc_ecc_create_replicas", "ldpc_ecc_replicas", "ldpc_ecc_ctx_at", "ldpc_ecc_sim_at", "ldpc_ecc_decode_on", "ldpc_ecc_set_coalescing", "ldpc_ecc_coalescing_stats", "ldpc_code_set_layers", "ldpc_code_layers", "ldpc_last_error", "ldpc_last_error_code", "ldpc_abi_version", "ldpc_device_count",
     "ldpc_code_create_qc", "ldpc_code_create_csr", "ldpc_code_destroy", "ldpc_code_dims", "ldpc_code_csr",
     "ldpc_ctx_create", "ldpc_ctx_create_ex", "ldpc_ctx_destroy", "ldpc_ctx_path", "ldpc_ctx_synchronize",
     "ldpc_decode_one", "ldpc_decode_batch", "ldpc_decode_batch_f64", "ldpc_decode_batch_dev",
@@ -207,6 +209,26 @@ def lib():
     L.ldpc_code_from_matrix.argtypes = [vp]
     L.ldpc_ecc_create.restype = vp
     L.ldpc_ecc_create.argtypes = [C.c_char_p, C.c_char_p, C.c_int]
+    L.ldpc_ecc_create_replicas.restype = vp
+    L.ldpc_ecc_create_replicas.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_int, ip]
+    L.ldpc_ecc_replicas.argtypes = [vp]
+    L.ldpc_ecc_ctx_at.restype = vp
+    L.ldpc_ecc_ctx_at.argtypes = [vp, C.c_int]
+    L.ldpc_ecc_sim_at.restype = vp
+    L.ldpc_ecc_sim_at.argtypes = [vp, C.c_int]
+    L.ldpc_ecc_decode_on.argtypes = [vp, C.c_int, f64p, u8p, ip]
+    L.ldpc_ecc_set_coalescing.argtypes = [vp, C.c_int, C.c_int]
+    L.ldpc_ecc_coalescing_stats.argtypes = [vp, C.POINTER(C.c_long), C.POINTER(C.c_long)]
+    L.ldpc_ctx_code.restype = vp
+    L.ldpc_ctx_code.argtypes = [vp]
+    L.ldpc_ctx_max_batch.argtypes = [vp]
+    L.ldpc_ctx_device.argtypes = [vp]
+    L.ldpc_batcher_create.restype = vp
+    L.ldpc_batcher_create.argtypes = [vp, C.c_int, C.c_int]
+    L.ldpc_batcher_destroy.restype = None
+    L.ldpc_batcher_destroy.argtypes = [vp]
+    L.ldpc_batcher_decode_one.argtypes = [vp, C.c_int, f64p, u8p, ip, ip]
+    L.ldpc_batcher_stats.argtypes = [vp, C.POINTER(C.c_long), C.POINTER(C.c_long)]
     L.ldpc_ecc_destroy.restype = None
     L.ldpc_ecc_destroy.argtypes = [vp]
     L.ldpc_ecc_name.restype = C.c_char_p
@@ -571,8 +593,15 @@ class ECC:
     """The plug-in record mkLDPC builds (src/ECC/Code/LDPC/Utils.hs:59-75), by code name:
     ECC(codes_dir, "ldpc/hip-minsum/jpl.4096.4.5/50/4/5")."""
 
-    def __init__(self, codes_dir, code_name, max_batch=64):
-        self._h = lib().ldpc_ecc_create(str(codes_dir).encode(), code_name.encode(), int(max_batch))
+    def __init__(self, codes_dir, code_name, max_batch=64, replicas=1, devices=None):
+        """replicas / devices: the reference's maxThreadCount decoder replicas in one process (Utils.hs:53), replica i on
+        HIP device devices[i] (None: the calling thread's device)"""
+        if devices is not None:
+            devs = (C.c_int * len(devices))(*[int(d) for d in devices])
+            replicas = len(devices)
+        else:
+            devs = None
+        self._h = lib().ldpc_ecc_create_replicas(str(codes_dir).encode(), code_name.encode(), int(max_batch), int(replicas), devs)
         if not self._h:
             raise LdpcError(lib().ldpc_last_error_code(), last_error())
         _register(self)
@@ -593,13 +622,38 @@ class ECC:
         check(lib().ldpc_ecc_encode(self._h, ptr(msg, C.c_uint8), ptr(cw, C.c_uint8)))
         return cw
 
-    def decode(self, llr):
+    def decode(self, llr, replica=None):
+        """the record's decode (Utils.hs:62-72); replica None = picked by the calling thread, as the reference does"""
         llr = np.ascontiguousarray(llr, np.float64)
         assert llr.shape == (self.codeword_length,)
         out = np.zeros(self.message_length, np.uint8)
         ok = C.c_int()
-        check(lib().ldpc_ecc_decode(self._h, ptr(llr, C.c_double), ptr(out, C.c_uint8), C.byref(ok)))
+        if replica is None:
+            check(lib().ldpc_ecc_decode(self._h, ptr(llr, C.c_double), ptr(out, C.c_uint8), C.byref(ok)))
+        else:
+            check(lib().ldpc_ecc_decode_on(self._h, int(replica), ptr(llr, C.c_double), ptr(out, C.c_uint8), C.byref(ok)))
         return out, bool(ok.value)
+
+    @property
+    def replicas(self):
+        return lib().ldpc_ecc_replicas(self._h)
+
+    def replica(self, i):
+        """-> (Decoder, Sim) views of replica i (owned by the record)"""
+        L = lib()
+        return (Decoder(self.code, max_batch=self.decoder.max_batch, _handle=L.ldpc_ecc_ctx_at(self._h, int(i))),
+                Sim(self.code, self.message_length, self.codeword_length, _handle=L.ldpc_ecc_sim_at(self._h, int(i))))
+
+    def coalescing_stats(self):
+        """-> (decode calls, launches) through the batchers so far"""
+        c, l = C.c_long(), C.c_long()
+        check(lib().ldpc_ecc_coalescing_stats(self._h, C.byref(c), C.byref(l)))
+        return c.value, l.value
+
+    def set_coalescing(self, max_frames, max_wait_us=200):
+        """concurrent decode() calls share launches (ldpc_batcher): up to max_frames per launch, a lone caller waits at
+        most max_wait_us for company; 0 switches it off"""
+        check(lib().ldpc_ecc_set_coalescing(self._h, int(max_frames), int(max_wait_us)))
 
     def close(self):
         if self._h:

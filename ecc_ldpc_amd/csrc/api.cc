@@ -360,6 +360,9 @@ ldpc_ctx *ldpc_ctx_create_on(const ldpc_code *code, int device, int variant, int
     return ldpc_ctx_create_cfg(code, &cfg);
 }
 
+const ldpc_code *ldpc_ctx_code(const ldpc_ctx *ctx) { return ctx ? ctx->code : nullptr; }
+int ldpc_ctx_max_batch(const ldpc_ctx *ctx) { return ctx ? ctx->max_batch : set_error(LDPC_EINVAL, "null ctx"); }
+int ldpc_ctx_device(const ldpc_ctx *ctx) { return ctx ? ctx->device : set_error(LDPC_EINVAL, "null ctx"); }
 int ldpc_ctx_schedule(const ldpc_ctx *ctx) { return ctx ? ctx->schedule : set_error(LDPC_EINVAL, "null ctx"); }
 
 ldpc_ctx *ldpc_ctx_create_cfg(const ldpc_code *code_c, const ldpc_ctx_config *cfg) {

@@ -15,7 +15,10 @@
 #include <sys/stat.h>
 
 #include <algorithm>
+#include <atomic>
 #include <fstream>
+#include <memory>
+#include <mutex>
 #include <new>
 #include <sstream>
 #include <string>
@@ -333,6 +336,16 @@ ldpc_code *ldpc_code_from_matrix(const ldpc_matrix *m) {
 }  // extern "C"
 
 // ------------------------------------------------------------------ the ECC record (mkLDPC)
+// one decoder replica of the record: what one `decoder0 h` call of mkLDPC returns (Utils.hs:53 replicateM maxThreadCount)
+struct ldpc_ecc_replica {
+    int device = -1;
+    ldpc_ctx *ctx = nullptr;
+    ldpc_sim *sim = nullptr;
+    ldpc_batcher *batcher = nullptr;   // set by ldpc_ecc_set_coalescing
+    std::mutex mu;                     // two caller threads may map to one replica (Utils.hs:63-69: tid `rem` maxThreadCount)
+    std::vector<double> llr_buf;
+    std::vector<uint8_t> bits_buf;
+};
 struct ldpc_ecc {
     std::string name;            // Utils.hs:60
     int message_length = 0;      // Utils.hs:73   m_length = rows G
@@ -340,12 +353,16 @@ struct ldpc_ecc {
     int unpunctured_length = 0;  // cols H
     int max_iters = 0, variant = 0, dtype = 0, rate_num = 0, rate_den = 0;
     ldpc_code *code = nullptr;
-    ldpc_ctx *ctx = nullptr;
-    ldpc_sim *sim = nullptr;
+    std::vector<std::unique_ptr<ldpc_ecc_replica>> reps;
     int parity_len = 0;
-    std::vector<double> llr_buf;
-    std::vector<uint8_t> bits_buf;
 };
+// the calling thread's ordinal (first use): stands in for the Haskell ThreadId of Utils.hs:64-65
+static int thread_ordinal() {
+    static std::atomic<int> next{0};
+    static thread_local int mine = -1;
+    if (mine < 0) mine = next.fetch_add(1);
+    return mine;
+}
 
 static std::vector<std::string> split_slash(const std::string &s) {
     std::vector<std::string> out;
@@ -366,16 +383,24 @@ extern "C" {
 
 void ldpc_ecc_destroy(ldpc_ecc *e) {
     if (!e) return;
-    if (e->sim) ldpc_sim_destroy(e->sim);
-    if (e->ctx) ldpc_ctx_destroy(e->ctx);
+    for (auto &r : e->reps) {
+        if (r->batcher) ldpc_batcher_destroy(r->batcher);
+        if (r->sim) ldpc_sim_destroy(r->sim);
+        if (r->ctx) ldpc_ctx_destroy(r->ctx);
+    }
     if (e->code) ldpc_code_destroy(e->code);
     delete e;
 }
 
+ldpc_ecc *ldpc_ecc_create(const char *codes_dir, const char *code_name, int max_batch) {
+    return ldpc_ecc_create_replicas(codes_dir, code_name, max_batch, 1, nullptr);
+}
+
 // Utils.hs:100-108 (the Code factory) + Utils.hs:35-75 (mkLDPC).  Returns NULL with
 // LDPC_ENOTFOUND when the name is not one of this library's decoders (the factory's `_ -> return []`).
-ldpc_ecc *ldpc_ecc_create(const char *codes_dir, const char *code_name, int max_batch) {
-    if (!codes_dir || !code_name || max_batch <= 0) { set_error(LDPC_EINVAL, "bad argument"); return nullptr; }
+// n_replicas decoder replicas (Utils.hs:53), replica i on devices[i] (NULL: all on the calling thread's device)
+ldpc_ecc *ldpc_ecc_create_replicas(const char *codes_dir, const char *code_name, int max_batch, int n_replicas, const int *devices) {
+    if (!codes_dir || !code_name || max_batch <= 0 || n_replicas <= 0 || n_replicas > 1024) { set_error(LDPC_EINVAL, "bad argument"); return nullptr; }
     ldpc_ecc *e = nullptr;
     ldpc_matrix *g = nullptr, *h = nullptr;
     try {
@@ -448,29 +473,34 @@ ldpc_ecc *ldpc_ecc_create(const char *codes_dir, const char *code_name, int max_
                   std::to_string(e->rate_den);  // Utils.hs:60
         e->code = ldpc_code_from_matrix(h);
         if (!e->code) goto fail;
-        {   // Utils.hs:53 (one replica).  LDPC_HIP_PATH=flood|fused overrides the automatic kernel choice.
+        {   // Utils.hs:53 replicateM maxThreadCount.  LDPC_HIP_PATH=flood|fused overrides the automatic kernel choice.
             int path = LDPC_PATH_AUTO;
             const char *pe = getenv("LDPC_HIP_PATH");
             if (pe && !strcmp(pe, "flood")) path = LDPC_PATH_FLOOD;
             else if (pe && !strcmp(pe, "fused")) path = LDPC_PATH_FUSED;
-            ldpc_ctx_config cfg{};
-            cfg.struct_size = sizeof(cfg); cfg.device = -1; cfg.variant = variant; cfg.dtype = dtype; cfg.max_batch = max_batch; cfg.path = path;
-            cfg.schedule = schedule;
-            e->ctx = ldpc_ctx_create_cfg(e->code, &cfg);
+            std::vector<uint8_t> gd;
+            if (g) {
+                gd.resize((size_t)g->rows * g->cols);
+                if (ldpc_matrix_dense(g, gd.data()) != LDPC_OK) goto fail;
+                e->parity_len = g->cols;
+            }
+            for (int i = 0; i < n_replicas; i++) {
+                std::unique_ptr<ldpc_ecc_replica> r(new ldpc_ecc_replica());
+                r->device = devices ? devices[i] : ldpc_current_device();
+                ldpc_ctx_config cfg{};
+                cfg.struct_size = sizeof(cfg); cfg.device = devices ? devices[i] : -1; cfg.variant = variant; cfg.dtype = dtype; cfg.max_batch = max_batch;
+                cfg.path = path; cfg.schedule = schedule;
+                r->ctx = ldpc_ctx_create_cfg(e->code, &cfg);
+                ldpc_ecc_replica *rp = r.get();
+                e->reps.push_back(std::move(r));      // owned by the record from here on (ldpc_ecc_destroy frees it)
+                if (!rp->ctx) goto fail;
+                rp->device = ldpc_ctx_device(rp->ctx);
+                rp->sim = ldpc_sim_create_on(e->code, rp->device, e->message_length, e->codeword_length, g ? g->cols : 0, g ? gd.data() : nullptr, max_batch);
+                if (!rp->sim) goto fail;
+                rp->llr_buf.assign((size_t)e->unpunctured_length, 0.0);
+                rp->bits_buf.assign((size_t)e->unpunctured_length, 0);
+            }
         }
-        if (!e->ctx) goto fail;
-        if (g) {
-            std::vector<uint8_t> gd((size_t)g->rows * g->cols);
-            if (ldpc_matrix_dense(g, gd.data()) != LDPC_OK) goto fail;
-            e->parity_len = g->cols;
-            e->sim = ldpc_sim_create(e->code, e->message_length, e->codeword_length, g->cols, gd.data(), max_batch);
-        } else {
-            e->parity_len = 0;
-            e->sim = ldpc_sim_create(e->code, e->message_length, e->codeword_length, 0, nullptr, max_batch);
-        }
-        if (!e->sim) goto fail;
-        e->llr_buf.assign((size_t)e->unpunctured_length, 0.0);
-        e->bits_buf.assign((size_t)e->unpunctured_length, 0);
         if (g) ldpc_matrix_destroy(g);
         ldpc_matrix_destroy(h);
         return e;
@@ -487,8 +517,36 @@ int ldpc_ecc_message_length(const ldpc_ecc *e) { return e ? e->message_length : 
 int ldpc_ecc_codeword_length(const ldpc_ecc *e) { return e ? e->codeword_length : set_error(LDPC_EINVAL, "null ecc"); }
 int ldpc_ecc_unpunctured_length(const ldpc_ecc *e) { return e ? e->unpunctured_length : set_error(LDPC_EINVAL, "null ecc"); }
 int ldpc_ecc_max_iters(const ldpc_ecc *e) { return e ? e->max_iters : set_error(LDPC_EINVAL, "null ecc"); }
-ldpc_ctx *ldpc_ecc_ctx(ldpc_ecc *e) { return e ? e->ctx : nullptr; }
-ldpc_sim *ldpc_ecc_sim(ldpc_ecc *e) { return e ? e->sim : nullptr; }
+ldpc_ctx *ldpc_ecc_ctx(ldpc_ecc *e) { return (e && !e->reps.empty()) ? e->reps[0]->ctx : nullptr; }
+ldpc_sim *ldpc_ecc_sim(ldpc_ecc *e) { return (e && !e->reps.empty()) ? e->reps[0]->sim : nullptr; }
+int ldpc_ecc_replicas(const ldpc_ecc *e) { return e ? (int)e->reps.size() : set_error(LDPC_EINVAL, "null ecc"); }
+ldpc_ctx *ldpc_ecc_ctx_at(ldpc_ecc *e, int i) { return (e && i >= 0 && i < (int)e->reps.size()) ? e->reps[i]->ctx : nullptr; }
+ldpc_sim *ldpc_ecc_sim_at(ldpc_ecc *e, int i) { return (e && i >= 0 && i < (int)e->reps.size()) ? e->reps[i]->sim : nullptr; }
+
+// Coalescing of the per-frame calls (batcher.cc): every replica gets a batcher; ldpc_ecc_decode then queues its frame
+// there and up to max_frames concurrent callers share one launch.
+int ldpc_ecc_coalescing_stats(ldpc_ecc *e, long *calls, long *launches) {
+    if (!e) return set_error(LDPC_EINVAL, "null ecc");
+    long c = 0, l = 0;
+    for (auto &r : e->reps)
+        if (r->batcher) { long cc = 0, ll = 0; (void)ldpc_batcher_stats(r->batcher, &cc, &ll); c += cc; l += ll; }
+    if (calls) *calls = c;
+    if (launches) *launches = l;
+    return LDPC_OK;
+}
+
+int ldpc_ecc_set_coalescing(ldpc_ecc *e, int max_frames, int max_wait_us) {
+    if (!e) return set_error(LDPC_EINVAL, "null ecc");
+    for (auto &r : e->reps) {
+        std::lock_guard<std::mutex> lk(r->mu);
+        if (r->batcher) { ldpc_batcher_destroy(r->batcher); r->batcher = nullptr; }
+        if (max_frames > 0) {
+            r->batcher = ldpc_batcher_create(r->ctx, max_frames, max_wait_us);
+            if (!r->batcher) return ldpc_last_error_code();
+        }
+    }
+    return LDPC_OK;
+}
 const ldpc_code *ldpc_ecc_code(const ldpc_ecc *e) { return e ? e->code : nullptr; }
 
 // Utils.hs:61  encode = \inp -> inp ++ take (c_length - m_length) (encoder' inp)
@@ -498,7 +556,7 @@ int ldpc_ecc_encode(const ldpc_ecc *e, const uint8_t *msg, uint8_t *codeword) {
         if (e->parity_len == 0 && e->codeword_length > e->message_length)
             return set_error(LDPC_EUNSUPPORTED, "this code was loaded without a generator matrix: no encoder");
         std::vector<uint8_t> par((size_t)e->parity_len + 1);
-        int rc = ldpc_sim_encode_host(e->sim, msg, par.data());
+        int rc = ldpc_sim_encode_host(e->reps[0]->sim, msg, par.data());
         if (rc != LDPC_OK) return rc;
         memcpy(codeword, msg, (size_t)e->message_length);
         memcpy(codeword + e->message_length, par.data(), (size_t)(e->codeword_length - e->message_length));
@@ -509,17 +567,35 @@ int ldpc_ecc_encode(const ldpc_ecc *e, const uint8_t *msg, uint8_t *codeword) {
 // Utils.hs:62-72  decode: unpuncture (take c_length ++ zeros), run the replica, take m_length bits;
 // `Nothing` (a failing replica) -> hard decisions of the input, flag False.
 int ldpc_ecc_decode(ldpc_ecc *e, const double *llr, uint8_t *msg_bits, int *ok) {
-    if (!e || !llr || !msg_bits) return set_error(LDPC_EINVAL, "null argument");
-    std::copy(llr, llr + e->codeword_length, e->llr_buf.begin());
-    std::fill(e->llr_buf.begin() + e->codeword_length, e->llr_buf.end(), 0.0);  // Utils.hs:55
-    int iters = 0, conv = 0;
-    int rc = ldpc_decode_one(e->ctx, e->max_iters, e->llr_buf.data(), e->bits_buf.data(), &iters, &conv);
+    if (!e || e->reps.empty()) return set_error(LDPC_EINVAL, "null argument");
+    // Utils.hs:63-69: the replica is picked by the calling thread (tid `rem` maxThreadCount)
+    return ldpc_ecc_decode_on(e, thread_ordinal() % (int)e->reps.size(), llr, msg_bits, ok);
+}
+
+int ldpc_ecc_decode_on(ldpc_ecc *e, int replica, const double *llr, uint8_t *msg_bits, int *ok) {
+    if (!e || !llr || !msg_bits || replica < 0 || replica >= (int)e->reps.size()) return set_error(LDPC_EINVAL, "bad argument");
+    ldpc_ecc_replica &r = *e->reps[replica];
+    int iters = 0, conv = 0, rc;
+    if (r.batcher) {   // coalesced: the frame is queued; up to max_frames callers share the launch (no replica lock held)
+        static thread_local std::vector<double> tl_llr;
+        static thread_local std::vector<uint8_t> tl_bits;
+        tl_llr.assign((size_t)e->unpunctured_length, 0.0);                       // Utils.hs:55 unpuncture: zeros appended
+        std::copy(llr, llr + e->codeword_length, tl_llr.begin());
+        tl_bits.resize((size_t)e->unpunctured_length);
+        rc = ldpc_batcher_decode_one(r.batcher, e->max_iters, tl_llr.data(), tl_bits.data(), &iters, &conv);
+        if (rc == LDPC_OK) memcpy(msg_bits, tl_bits.data(), (size_t)e->message_length);   // Utils.hs:72
+    } else {
+        std::lock_guard<std::mutex> lk(r.mu);
+        std::copy(llr, llr + e->codeword_length, r.llr_buf.begin());
+        std::fill(r.llr_buf.begin() + e->codeword_length, r.llr_buf.end(), 0.0);  // Utils.hs:55
+        rc = ldpc_decode_one(r.ctx, e->max_iters, r.llr_buf.data(), r.bits_buf.data(), &iters, &conv);
+        if (rc == LDPC_OK) memcpy(msg_bits, r.bits_buf.data(), (size_t)e->message_length);  // Utils.hs:72
+    }
     if (rc != LDPC_OK) {  // Utils.hs:71
         for (int i = 0; i < e->message_length; i++) msg_bits[i] = llr[i] > 0.0 ? 1 : 0;
         if (ok) *ok = 0;
         return LDPC_OK;
     }
-    memcpy(msg_bits, e->bits_buf.data(), (size_t)e->message_length);  // Utils.hs:72
     if (ok) *ok = 1;
     return LDPC_OK;
 }

@@ -129,6 +129,9 @@ typedef struct {
 } ldpc_ctx_config;
 ldpc_ctx *ldpc_ctx_create_cfg(const ldpc_code *code, const ldpc_ctx_config *cfg);
 int ldpc_ctx_schedule(const ldpc_ctx *ctx);
+const ldpc_code *ldpc_ctx_code(const ldpc_ctx *ctx);
+int ldpc_ctx_max_batch(const ldpc_ctx *ctx);
+int ldpc_ctx_device(const ldpc_ctx *ctx);
 void ldpc_ctx_destroy(ldpc_ctx *ctx);
 /* LDPC_PATH_FLOOD or LDPC_PATH_FUSED: what the context resolved to */
 int ldpc_ctx_path(const ldpc_ctx *ctx);
@@ -175,6 +178,19 @@ void *ldpc_host_alloc(size_t bytes);
 void ldpc_host_free(void *p);
 /* wait for everything enqueued on the context's stream */
 int ldpc_ctx_synchronize(ldpc_ctx *ctx);
+
+/* ---- coalescing of per-frame calls ----------------------------------------------------------------------
+ * The reference's harness calls the decoder once per frame from up to maxThreadCount threads (Utils.hs:53,63-69) and
+ * its CUDA plug-ins decode one codeword per launch sequence (Arraylet2.hs:151-273).  A batcher sits between such
+ * callers and ONE decoder replica: the first caller to arrive waits until max_frames requests are queued or
+ * max_wait_us have passed, decodes them with one launch and hands every caller its own result.  Thread-safe; each
+ * call blocks like ldpc_decode_one and returns exactly what ldpc_decode_one would.  The context must not be used
+ * directly while a batcher owns it; max_frames <= the context's max_batch. */
+typedef struct ldpc_batcher ldpc_batcher;
+ldpc_batcher *ldpc_batcher_create(ldpc_ctx *ctx, int max_frames, int max_wait_us);
+void ldpc_batcher_destroy(ldpc_batcher *b);
+int ldpc_batcher_decode_one(ldpc_batcher *b, int max_iters, const double *llr, uint8_t *bits, int *iters, int *converged);
+int ldpc_batcher_stats(ldpc_batcher *b, long *calls, long *launches);
 
 /* ---- verification entry points (used by tests/; not needed by a harness) ------------------------
  * One teacher-forced update on the device in the context's dtype: from the state (lam, ne) at
@@ -277,6 +293,18 @@ ldpc_code *ldpc_code_from_matrix(const ldpc_matrix *m);
  * the CUDA plug-ins, GPU/CUDA/Arraylet2.hs:61). */
 typedef struct ldpc_ecc ldpc_ecc;
 ldpc_ecc *ldpc_ecc_create(const char *codes_dir, const char *code_name, int max_batch);
+/* the reference's maxThreadCount (Utils.hs:53 replicateM maxThreadCount $ decoder0 h): n_replicas decoder replicas in
+ * ONE process, replica i on HIP device devices[i] (devices = NULL: all on the calling thread's device) -- one host
+ * process can drive every GPU of a node.  ldpc_ecc_decode picks the replica by calling thread, as Utils.hs:63-69
+ * does (thread ordinal mod n_replicas); ldpc_ecc_decode_on names it. */
+ldpc_ecc *ldpc_ecc_create_replicas(const char *codes_dir, const char *code_name, int max_batch, int n_replicas, const int *devices);
+int ldpc_ecc_replicas(const ldpc_ecc *ecc);
+ldpc_ctx *ldpc_ecc_ctx_at(ldpc_ecc *ecc, int replica);
+ldpc_sim *ldpc_ecc_sim_at(ldpc_ecc *ecc, int replica);
+int ldpc_ecc_decode_on(ldpc_ecc *ecc, int replica, const double *llr, uint8_t *msg_bits, int *ok);
+/* route ldpc_ecc_decode through a batcher per replica (see above): max_frames = 0 switches it off again */
+int ldpc_ecc_set_coalescing(ldpc_ecc *ecc, int max_frames, int max_wait_us);
+int ldpc_ecc_coalescing_stats(ldpc_ecc *ecc, long *calls, long *launches);   /* summed over the replicas */
 void ldpc_ecc_destroy(ldpc_ecc *ecc);
 const char *ldpc_ecc_name(const ldpc_ecc *ecc);            /* Utils.hs:60 */
 int ldpc_ecc_message_length(const ldpc_ecc *ecc);          /* Utils.hs:73 */

@@ -1,0 +1,123 @@
+"""GPU: what a multi-threaded host sees.  The reference makes maxThreadCount decoder replicas in ONE process and its
+harness calls the record's decode once per frame from several threads (src/ECC/Code/LDPC/Utils.hs:53,63-69):
+  * ldpc_ecc_create_replicas: several replicas behind one record, picked by calling thread; explicit devices;
+  * ldpc_ecc_set_coalescing / ldpc_batcher: concurrent per-frame calls share one launch -- same answers as one by one;
+  * objects on an explicitly named device from a thread that never called ldpc_init;
+  * the native multi-rank CLI: one thread per rank, frame ranges sharded, tallies summed (host) / all-reduced (RCCL)."""
+import subprocess
+import threading
+import time
+
+import numpy as np
+import pytest
+
+from oracle import oracle
+from tests.helpers import CODES, load
+
+pytestmark = pytest.mark.gpu
+NAME = "ldpc/hip-minsum/jpl.1024.4.5/50/4/5"
+
+
+def _run_threads(n, fn):
+    errs, th = [], []
+    def wrap(i):
+        try:
+            fn(i)
+        except Exception as e:      # noqa: BLE001
+            errs.append(e)
+    for i in range(n):
+        t = threading.Thread(target=wrap, args=(i,))
+        t.start(); th.append(t)
+    for t in th:
+        t.join()
+    assert not errs, errs[0]
+
+
+def test_replicas_are_picked_by_thread_and_agree(hip):
+    c = load("jpl.1024.4.5")
+    _, llr = c.frames(48, 3.4, seed=21)
+    want = [oracle.decode(c.graph, "min", 50, l)["bits"][:1024] for l in llr]
+    ecc = hip.ECC(CODES, NAME, max_batch=8, devices=[0, 0, 0])
+    assert ecc.replicas == 3
+    got = [None] * 48
+    def work(i):
+        for f in range(i, 48, 6):
+            got[f], ok = ecc.decode(llr[f][:1280])
+            assert ok
+    _run_threads(6, work)
+    assert all(np.array_equal(g, w) for g, w in zip(got, want))
+    out, ok = ecc.decode(llr[0][:1280], replica=2)
+    assert ok and np.array_equal(out, want[0])
+    dec2, sim2 = ecc.replica(2)
+    assert dec2.path == "fused"
+    ecc.close()
+
+
+def test_coalesced_calls_equal_one_by_one_and_share_launches(hip):
+    c = load("jpl.1024.4.5")
+    _, llr = c.frames(256, 3.2, seed=22)
+    ecc = hip.ECC(CODES, NAME, max_batch=64)
+    one_by_one = [ecc.decode(l[:1280])[0] for l in llr[:64]]
+    ecc.set_coalescing(32, 5000)
+    got = [None] * 256
+    def work(i):
+        for f in range(i, 256, 32):
+            got[f], ok = ecc.decode(llr[f][:1280])
+            assert ok
+    _run_threads(32, work)
+    calls, launches = ecc.coalescing_stats()
+    assert calls == 256 and launches <= 64, (calls, launches)        # 32 callers at a time: far fewer launches than frames
+    assert all(np.array_equal(got[f], one_by_one[f]) for f in range(64))
+    ref = oracle.decode_batch(c.graph, "min", 50, llr, nthreads=8)[0]
+    assert all(np.array_equal(got[f], ref[f][:1024]) for f in range(256))
+    # a lone caller is served after the wait budget, not never
+    t0 = time.time()
+    out, ok = ecc.decode(llr[3][:1280])
+    assert ok and np.array_equal(out, one_by_one[3]) and time.time() - t0 < 1.0
+    print(f"coalescing: {calls} calls in {launches} launches")
+    # harness-visible rate, frames decoded one per call from T threads (jpl.1024, 3.2 dB)
+    for T, coalesce in ((1, 0), (8, 0), (8, 8), (64, 64)):
+        ecc.set_coalescing(coalesce, 300)
+        per = 256 // T if T <= 8 else 4
+        def work2(i):
+            for f in range(per):
+                ecc.decode(llr[(i * per + f) % 256][:1280])
+        t0 = time.time()
+        _run_threads(T, work2)
+        dt = time.time() - t0
+        print(f"  {T:3d} threads, coalescing {coalesce:2d}: {T * per * 1024 / dt / 1e6:8.2f} Mbit/s harness-visible ({T * per / dt:7.0f} frames/s)")
+    ecc.close()
+
+
+def test_explicit_device_from_a_thread_without_init(hip):
+    c = load("jpl.1024.4.5")
+    _, llr = c.frames(4, 4.0, seed=23)
+    res = {}
+    def work(_):
+        assert hip.lib().ldpc_current_device() == 0          # never called ldpc_init here: the process default
+        code = c.hip_code(hip)
+        dec = hip.Decoder(code, "min", "f32", 4, device=0)   # ldpc_ctx_create_cfg with an explicit device
+        res["bits"] = dec.decode_batch(llr.astype(np.float32), 50)[0]
+        with pytest.raises(hip.LdpcError):
+            hip.Decoder(code, "min", "f32", 4, device=99)
+        dec.close(); code.close()
+    _run_threads(1, work)
+    assert np.array_equal(res["bits"], oracle.decode_batch(c.graph, "min", 50, llr, nthreads=4)[0])
+
+
+def test_native_cli_ranks(hip):
+    from ecc_ldpc_amd.build import CLI
+    args = ["3.2", NAME, "-m20000", "-b4096", "-c" + CODES]
+    def rows(extra):
+        p = subprocess.run([CLI] + args + extra, capture_output=True, text=True, timeout=300)
+        assert p.returncode == 0, p.stderr
+        return [l.split() for l in p.stdout.splitlines() if l.strip()]
+    one = rows(["-d0"])
+    two = rows(["-d0,0", "-thost"])            # two ranks (threads) sharing the GPU, tallies summed on the host
+    three = rows(["-d0,0,0", "-thost"])        # 20000 frames do not divide by 3: ragged shards
+    rccl = rows(["-d0", "-trccl"])             # the RCCL all-reduce with a single rank
+    for other in (two, three, rccl):
+        assert other[0][1:6] == one[0][1:6], (one, other)     # name, Eb/N0, frames, bit errors, BER: the same frames were decoded
+    assert "ranks," in " ".join(two[0]) and "rccl" not in " ".join(one[0])
+    p = subprocess.run([CLI] + args + ["-d0,0", "-trccl"], capture_output=True, text=True, timeout=60)
+    assert p.returncode == 2 and "distinct" in p.stderr

@@ -313,6 +313,9 @@ int ldpc_matrix_qc_offsets(const ldpc_matrix *m, int32_t *offsets) {
 
 // the parity-check graph of a loaded matrix: QC table when every block is a single circulant
 // (what the QuasiCyclic decoders take), generic CSR otherwise (what the Matrix Bool decoders take)
+// the expanded matrix as a generic CSR graph: what a `Matrix Bool` decoder of the reference is given (Orig.hs:30-31)
+static ldpc_code *code_from_dense(const ldpc_matrix *m);
+
 ldpc_code *ldpc_code_from_matrix(const ldpc_matrix *m) {
     if (!m) { set_error(LDPC_EINVAL, "null matrix"); return nullptr; }
     try {
@@ -320,6 +323,12 @@ ldpc_code *ldpc_code_from_matrix(const ldpc_matrix *m) {
             std::vector<int32_t> off(m->blocks.size());
             if (ldpc_matrix_qc_offsets(m, off.data()) == LDPC_OK) return ldpc_code_create_qc(m->sz, m->brows, m->bcols, off.data());
         }
+        return code_from_dense(m);
+    } catch (...) { set_error(LDPC_ENOMEM, "out of host memory"); return nullptr; }
+}
+
+static ldpc_code *code_from_dense(const ldpc_matrix *m) {
+    try {
         std::vector<uint8_t> d((size_t)m->rows * m->cols);
         if (ldpc_matrix_dense(m, d.data()) != LDPC_OK) return nullptr;
         std::vector<int32_t> rp((size_t)m->rows + 1, 0), ci;
@@ -418,6 +427,8 @@ ldpc_ecc *ldpc_ecc_create_replicas(const char *codes_dir, const char *code_name,
         else if (ends("-f16")) { dtype = LDPC_F16; dec.resize(dec.size() - 4); }
         else if (ends("-f32")) { dec.resize(dec.size() - 4); }
         int variant, schedule = LDPC_SCHED_FLOODING;
+        bool as_bool = false;   // "-bool": take H as a plain Boolean matrix (the Haskell binding's `Matrix Bool` flavour, haskell/.../HIP.hs)
+        if (ends("-bool")) { as_bool = true; dec.resize(dec.size() - 5); }
         if (ends("-layered")) { schedule = LDPC_SCHED_LAYERED; dec.resize(dec.size() - 8); }   // extension: row-layered schedule
         if (dec == "hip-tanh") variant = LDPC_TANH;
         else if (dec == "hip-minsum") variant = LDPC_MINSUM;
@@ -471,7 +482,7 @@ ldpc_ecc *ldpc_ecc_create_replicas(const char *codes_dir, const char *code_name,
         }
         e->name = "ldpc/" + xs[1] + "/" + xs[2] + "/" + std::to_string(e->max_iters) + "/" + std::to_string(e->rate_num) + "/" +
                   std::to_string(e->rate_den);  // Utils.hs:60
-        e->code = ldpc_code_from_matrix(h);
+        e->code = as_bool ? code_from_dense(h) : ldpc_code_from_matrix(h);
         if (!e->code) goto fail;
         {   // Utils.hs:53 replicateM maxThreadCount.  LDPC_HIP_PATH=flood|fused overrides the automatic kernel choice.
             int path = LDPC_PATH_AUTO;

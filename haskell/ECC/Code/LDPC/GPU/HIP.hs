@@ -2,12 +2,21 @@
 -- record, written against mkLDPC_CodeIO (src/ECC/Code/LDPC/Utils.hs:91-108) the way the CUDA plug-ins are
 -- (src/ECC/Code/LDPC/GPU/CUDA/Arraylet2.hs:60-61).  Delivered as source: GHC is not available in the build
 -- image, so this module has NOT been compiled.  See INTEGRATION.md for the cabal / Main.hs changes.
+--
+-- Codes exported (names resolve through the reference's grammar ldpc/<name>/<matrix>/<max-rounds>[/x/y]):
+--   hip-tanh, hip-minsum                    QuasiCyclic Integer H  (.q files; what Fast.Arraylet takes, Fast/Arraylet.hs:68-79)
+--   hip-tanh-bool, hip-minsum-bool          Matrix Bool H          (.alist / .m files; what Reference.Orig takes, Orig.hs:20-31)
+--   hip-minsum-layered                      QuasiCyclic, row-layered schedule (an extension of this library)
+-- Every code is built with maxThreadCount = hipThreads replicas (Utils.hs:53): replica i lives on GPU (i mod #GPUs), so
+-- one Haskell process drives every GPU of the node; and the replicas of one GPU share a coalescing batcher
+-- (ldpc_batcher_*): frames that several Haskell threads decode at the same moment go to the device in ONE launch.
 {-# LANGUAGE ForeignFunctionInterface #-}
-module ECC.Code.LDPC.GPU.HIP (codeTanh, codeMinSum) where
+module ECC.Code.LDPC.GPU.HIP (codeTanh, codeMinSum, codeTanhBool, codeMinSumBool, codeMinSumLayered, hipThreads) where
 
 import ECC.Code.LDPC.Utils            (mkLDPC_CodeIO)
 import ECC.Types
-import qualified ECC.Code.LDPC.Fast.Encoder as E
+import qualified ECC.Code.LDPC.Fast.Encoder   as E
+import qualified ECC.Code.LDPC.Reference.Orig as O
 import qualified Data.Matrix.QuasiCyclic as Q
 import qualified Data.Matrix as M
 import qualified Data.Vector.Unboxed as U
@@ -15,39 +24,64 @@ import qualified Data.Vector.Storable as S
 import qualified Data.Vector.Storable.Mutable as SM
 import Data.Bits (testBit, popCount, shiftR)
 import Data.Int  (Int32)
+import Data.IORef
 import Data.Word (Word8)
 import Foreign.C.Types
 import Foreign.C.String (CString, peekCString)
 import Foreign.Ptr
-import Foreign.Marshal.Alloc (alloca)
-import Foreign.Storable (peek)
+import Foreign.Marshal.Alloc (alloca, allocaBytes)
+import Foreign.Storable (peek, pokeByteOff)
 
 data LdpcCode
 data LdpcCtx
+data LdpcBatcher
 
--- blocking calls (they wait for the GPU): `safe`
-foreign import ccall safe   "ldpc_init"           c_init      :: CInt -> IO CInt
-foreign import ccall safe   "ldpc_shutdown"       c_shutdown  :: IO CInt
-foreign import ccall unsafe "ldpc_last_error"     c_lastError :: IO CString
-foreign import ccall safe   "ldpc_code_create_qc" c_codeQC    :: CInt -> CInt -> CInt -> Ptr Int32 -> IO (Ptr LdpcCode)
-foreign import ccall safe   "ldpc_ctx_create"     c_ctxCreate :: Ptr LdpcCode -> CInt -> CInt -> CInt -> IO (Ptr LdpcCtx)
-foreign import ccall safe   "ldpc_decode_one"     c_decodeOne :: Ptr LdpcCtx -> CInt -> Ptr Double -> Ptr Word8
-                                                              -> Ptr CInt -> Ptr CInt -> IO CInt
+-- blocking calls (they wait for the GPU): `safe`, so other Haskell threads keep running meanwhile
+foreign import ccall safe   "ldpc_init"               c_init       :: CInt -> IO CInt
+foreign import ccall safe   "ldpc_shutdown"           c_shutdown   :: IO CInt
+foreign import ccall unsafe "ldpc_device_count"       c_devCount   :: IO CInt
+foreign import ccall unsafe "ldpc_last_error"         c_lastError  :: IO CString
+foreign import ccall safe   "ldpc_code_create_qc"     c_codeQC     :: CInt -> CInt -> CInt -> Ptr Int32 -> IO (Ptr LdpcCode)
+foreign import ccall safe   "ldpc_code_create_csr"    c_codeCSR    :: CInt -> CInt -> Ptr Int32 -> Ptr Int32 -> IO (Ptr LdpcCode)
+foreign import ccall safe   "ldpc_ctx_create_cfg"     c_ctxCfg     :: Ptr LdpcCode -> Ptr () -> IO (Ptr LdpcCtx)
+foreign import ccall safe   "ldpc_batcher_create"     c_batcher    :: Ptr LdpcCtx -> CInt -> CInt -> IO (Ptr LdpcBatcher)
+foreign import ccall safe   "ldpc_batcher_decode_one" c_decodeOne  :: Ptr LdpcBatcher -> CInt -> Ptr Double -> Ptr Word8
+                                                                   -> Ptr CInt -> Ptr CInt -> IO CInt
 
-tanhRule, minSumRule, f32 :: CInt
-tanhRule = 0; minSumRule = 1; f32 = 0
+tanhRule, minSumRule, f32, flooding, layered, pathAuto :: CInt
+tanhRule = 0; minSumRule = 1; f32 = 0; flooding = 0; layered = 1; pathAuto = 0
 
--- same shape as CUDAArraylet2.code (GPU/CUDA/Arraylet2.hs:60-61): one replica, Fast.Encoder
-codeTanh, codeMinSum :: Code
-codeTanh   = mkLDPC_CodeIO "hip-tanh"   1 E.encoder (decoder tanhRule)   initialize finalize
-codeMinSum = mkLDPC_CodeIO "hip-minsum" 1 E.encoder (decoder minSumRule) initialize finalize
+-- | maxThreadCount of these codes (Utils.hs:53): how many Haskell threads may decode at once.  The harness picks the
+-- closure by ThreadId `rem` maxThreadCount (Utils.hs:63-69).
+hipThreads :: Int
+hipThreads = 64
 
-initialize :: IO ()
-initialize = do rc <- c_init 0
-                if rc /= 0 then c_lastError >>= peekCString >>= error else return ()
+-- | frames the batcher of one GPU collects at most, and how long (microseconds) a lone caller waits for company
+coalesceFrames, coalesceWaitUs :: CInt
+coalesceFrames = 64
+coalesceWaitUs = 200
 
-finalize :: () -> IO ()
+-- vars of the Code (the CUDA plug-ins keep their CudaAllocations there, Arraylet2.hs:287-293): the number of GPUs and,
+-- per (graph, rule, schedule, GPU), the batcher its replicas share
+data Vars = Vars { nDev :: Int, nextReplica :: IORef Int, batchers :: IORef [((String, CInt, CInt, Int), Ptr LdpcBatcher)] }
+
+initialize :: IO Vars
+initialize = do
+  n <- c_devCount
+  if n <= 0 then error "libldpc_hip: no HIP device visible (there is no CPU fallback)" else return ()
+  mapM_ (\d -> do rc <- c_init (fromIntegral d)           -- checks every device is a gfx950 GPU
+                  if rc /= 0 then c_lastError >>= peekCString >>= error else return ()) [0 .. fromIntegral n - 1 :: Int]
+  Vars (fromIntegral n) <$> newIORef 0 <*> newIORef []
+
+finalize :: Vars -> IO ()
 finalize _ = c_shutdown >> return ()
+
+codeTanh, codeMinSum, codeMinSumLayered, codeTanhBool, codeMinSumBool :: Code
+codeTanh          = mkLDPC_CodeIO "hip-tanh"           hipThreads E.encoder (decoderQC   tanhRule   flooding) initialize finalize
+codeMinSum        = mkLDPC_CodeIO "hip-minsum"         hipThreads E.encoder (decoderQC   minSumRule flooding) initialize finalize
+codeMinSumLayered = mkLDPC_CodeIO "hip-minsum-layered" hipThreads E.encoder (decoderQC   minSumRule layered)  initialize finalize
+codeTanhBool      = mkLDPC_CodeIO "hip-tanh-bool"      hipThreads O.encoder (decoderBool tanhRule   flooding) initialize finalize
+codeMinSumBool    = mkLDPC_CodeIO "hip-minsum-bool"    hipThreads O.encoder (decoderBool minSumRule flooding) initialize finalize
 
 -- rotation of the single set bit, -1 for an empty block (Fast/Arraylet.hs:68-79)
 offsetsOf :: Q.QuasiCyclic Integer -> [Int32]
@@ -58,20 +92,59 @@ offsetsOf (Q.QuasiCyclic _ qm) = map f (M.toList qm)
         g x | x `testBit` 0 = 0
             | otherwise     = 1 + g (x `shiftR` 1)
 
-decoder :: CInt -> () -> Q.QuasiCyclic Integer
-        -> IO (Rate -> Int -> U.Vector Double -> IO (Maybe (U.Vector Bool)))
-decoder rule _ h@(Q.QuasiCyclic sz qm) = do
+type Closure = Rate -> Int -> U.Vector Double -> IO (Maybe (U.Vector Bool))
+
+-- `decoder vars h` is called maxThreadCount times by mkLDPC (Utils.hs:53); call number i serves GPU (i mod #GPUs)
+decoderQC :: CInt -> CInt -> Vars -> Q.QuasiCyclic Integer -> IO Closure
+decoderQC rule sched vars h@(Q.QuasiCyclic sz qm) = do
   let offs = S.fromList (offsetsOf h)
-  code <- S.unsafeWith offs $ \p ->
-            c_codeQC (fromIntegral sz) (fromIntegral (M.nrows qm)) (fromIntegral (M.ncols qm)) p
-  ctx  <- c_ctxCreate code rule f32 1
-  if ctx == nullPtr then c_lastError >>= peekCString >>= error else return ()
-  let n = sz * M.ncols qm
+      key  = "qc" ++ show (sz, M.nrows qm, M.ncols qm, S.toList offs)
+      mk   = S.unsafeWith offs $ \p -> c_codeQC (fromIntegral sz) (fromIntegral (M.nrows qm)) (fromIntegral (M.ncols qm)) p
+  closureFor vars key rule sched mk (sz * M.ncols qm)
+
+-- the `Matrix Bool` decoders' input (Reference/Orig.hs:30-31): H as CSR, columns ascending inside a row
+decoderBool :: CInt -> CInt -> Vars -> M.Matrix Bool -> IO Closure
+decoderBool rule sched vars h = do
+  let rows   = [ [ fromIntegral (c - 1) :: Int32 | c <- [1 .. M.ncols h], h M.! (r, c) ] | r <- [1 .. M.nrows h] ]
+      rowPtr = S.fromList (scanl (+) 0 (map (fromIntegral . length) rows)) :: S.Vector Int32
+      colIdx = S.fromList (concat rows) :: S.Vector Int32
+      key    = "csr" ++ show (M.nrows h, M.ncols h, S.toList colIdx)
+      mk     = S.unsafeWith rowPtr $ \pr -> S.unsafeWith colIdx $ \pc ->
+                 c_codeCSR (fromIntegral (M.nrows h)) (fromIntegral (M.ncols h)) pr pc
+  closureFor vars key rule sched mk (M.ncols h)
+
+-- one batcher (one ldpc_ctx behind it) per (graph, rule, schedule, GPU); every replica of that GPU shares it
+closureFor :: Vars -> String -> CInt -> CInt -> IO (Ptr LdpcCode) -> Int -> IO Closure
+closureFor vars key rule sched mkCode n = do
+  i <- atomicModifyIORef' (nextReplica vars) (\k -> (k + 1, k))
+  let dev = i `mod` nDev vars
+      k4  = (key, rule, sched, dev)
+  known <- lookup k4 <$> readIORef (batchers vars)
+  b <- case known of
+         Just b  -> return b
+         Nothing -> do
+           code <- mkCode
+           if code == nullPtr then c_lastError >>= peekCString >>= error else return ()
+           -- ldpc_ctx_config { size_t struct_size; int device, variant, dtype, max_batch, path, schedule; }
+           ctx <- allocaBytes 32 $ \cfg -> do
+                    pokeByteOff cfg 0  (32 :: CSize)
+                    pokeByteOff cfg 8  (fromIntegral dev :: CInt)
+                    pokeByteOff cfg 12 rule
+                    pokeByteOff cfg 16 f32
+                    pokeByteOff cfg 20 coalesceFrames
+                    pokeByteOff cfg 24 pathAuto
+                    pokeByteOff cfg 28 sched
+                    c_ctxCfg code cfg
+           if ctx == nullPtr then c_lastError >>= peekCString >>= error else return ()
+           b <- c_batcher ctx coalesceFrames coalesceWaitUs
+           if b == nullPtr then c_lastError >>= peekCString >>= error else return ()
+           atomicModifyIORef' (batchers vars) (\l -> ((k4, b) : l, ()))
+           return b
   return $ \_rate maxI origLam -> do            -- origLam is already un-punctured (Utils.hs:55,69)
     let llr = S.convert origLam :: S.Vector Double
     bits <- SM.new n
     rc <- S.unsafeWith llr $ \pl -> SM.unsafeWith bits $ \pb ->
-            alloca $ \pit -> alloca $ \pcv -> c_decodeOne ctx (fromIntegral maxI) pl pb pit pcv
+            alloca $ \pit -> alloca $ \pcv -> c_decodeOne b (fromIntegral maxI) pl pb pit pcv
     if rc /= 0
       then return Nothing                       -- harness substitutes hard(inp) (Utils.hs:70-71)
       else do out <- S.freeze bits

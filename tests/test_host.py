@@ -78,6 +78,11 @@ def test_ecc_record_mirrors_mkLDPC(hip):
     out, ok = ecc.decode(llr[:1280])
     o = oracle.decode(c.graph, "min", 50, llr)
     assert ok and np.array_equal(out, o["bits"][:1024])
+    # "-bool": the same matrix taken as a plain Boolean matrix (the Haskell binding's `Matrix Bool` codes): CSR graph, same answers
+    eb = hip.ECC(CODES, "ldpc/hip-minsum-bool/jpl.1024.4.5/50/4/5", max_batch=4)
+    assert len(eb.code.layers()) == 384 + 1 and "csr" in eb.decoder.kernel_name
+    outb, okb = eb.decode(llr[:1280])
+    assert okb and np.array_equal(outb, out)
     mo = hip.ECC(CODES, "ldpc/hip-tanh/moon.7.13/20", max_batch=2)
     assert (mo.message_length, mo.codeword_length) == (7, 20)
     m = load("moon.7.13")

@@ -57,7 +57,7 @@ def test_coalesced_calls_equal_one_by_one_and_share_launches(hip):
     c = load("jpl.1024.4.5")
     _, llr = c.frames(256, 3.2, seed=22)
     ecc = hip.ECC(CODES, NAME, max_batch=64)
-    one_by_one = [ecc.decode(l[:1280])[0] for l in llr[:64]]
+    one_by_one = [ecc.decode(l[:1280])[0] for l in llr]
     ecc.set_coalescing(32, 5000)
     got = [None] * 256
     def work(i):
@@ -67,9 +67,10 @@ def test_coalesced_calls_equal_one_by_one_and_share_launches(hip):
     _run_threads(32, work)
     calls, launches = ecc.coalescing_stats()
     assert calls == 256 and launches <= 64, (calls, launches)        # 32 callers at a time: far fewer launches than frames
-    assert all(np.array_equal(got[f], one_by_one[f]) for f in range(64))
-    ref = oracle.decode_batch(c.graph, "min", 50, llr, nthreads=8)[0]
-    assert all(np.array_equal(got[f], ref[f][:1024]) for f in range(256))
+    assert all(np.array_equal(got[f], one_by_one[f]) for f in range(256))      # exactly what ldpc_decode_one gives
+    ref, _, rconv = oracle.decode_batch(c.graph, "min", 50, llr, nthreads=8)
+    agree = np.array([np.array_equal(got[f], ref[f][:1024]) for f in range(256)])
+    assert agree.mean() > 0.97        # (f32 kernels vs the double oracle: a frame at the edge of convergence may differ)
     # a lone caller is served after the wait budget, not never
     t0 = time.time()
     out, ok = ecc.decode(llr[3][:1280])
@@ -111,7 +112,7 @@ def test_native_cli_ranks(hip):
     def rows(extra):
         p = subprocess.run([CLI] + args + extra, capture_output=True, text=True, timeout=300)
         assert p.returncode == 0, p.stderr
-        return [l.split() for l in p.stdout.splitlines() if l.strip()]
+        return [l.split() for l in p.stdout.splitlines() if len(l.split()) > 5 and l.split()[1].startswith("ldpc/")]   # (RCCL prints a banner)
     one = rows(["-d0"])
     two = rows(["-d0,0", "-thost"])            # two ranks (threads) sharing the GPU, tallies summed on the host
     three = rows(["-d0,0,0", "-thost"])        # 20000 frames do not divide by 3: ragged shards

@@ -138,12 +138,54 @@ void rank_main(Shared &S, int r) {
 }
 }  // namespace
 
+// -H<threads>[,<coalesce>[,<wait us>]]: what a per-frame HARNESS sees.  <threads> host threads call the record's decode
+// (ldpc_ecc_decode: one frame per call, host double LLRs in, message bits out -- the closure of Utils.hs:62-72) on frames
+// taken from the device frame source; with <coalesce> > 0 the calls go through a batcher (ldpc_ecc_set_coalescing).
+static int harness_mode(const std::string &codes_dir, const std::string &name, double db, long frames, uint64_t seed, int threads, int coalesce, int wait_us) {
+    const int pool = 4096;
+    ldpc_ecc *ecc = ldpc_ecc_create(codes_dir.c_str(), name.c_str(), std::max(pool, coalesce));
+    if (!ecc) { fprintf(stderr, "# %s: %s\n", name.c_str(), ldpc_last_error()); return 1; }
+    const int k = ldpc_ecc_message_length(ecc), n_tx = ldpc_ecc_codeword_length(ecc), N = ldpc_ecc_unpunctured_length(ecc);
+    float *d_llr = nullptr;
+    if (hipMalloc((void **)&d_llr, (size_t)pool * N * sizeof(float)) != hipSuccess) return 1;
+    if (ldpc_sim_generate(ldpc_ecc_sim(ecc), seed, 0, pool, db, d_llr, nullptr, nullptr) != LDPC_OK) { fprintf(stderr, "%s\n", ldpc_last_error()); return 1; }
+    std::vector<float> h((size_t)pool * N);
+    if (hipMemcpy(h.data(), d_llr, h.size() * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) return 1;
+    (void)hipFree(d_llr);
+    std::vector<double> llr((size_t)pool * n_tx);
+    for (int f = 0; f < pool; f++) for (int i = 0; i < n_tx; i++) llr[(size_t)f * n_tx + i] = h[(size_t)f * N + i];
+    if (coalesce > 0 && ldpc_ecc_set_coalescing(ecc, coalesce, wait_us) != LDPC_OK) { fprintf(stderr, "%s\n", ldpc_last_error()); return 1; }
+    std::vector<std::thread> th;
+    std::vector<long> ok_count(threads, 0);
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int t = 0; t < threads; t++)
+        th.emplace_back([&, t] {
+            std::vector<uint8_t> out((size_t)k);
+            for (long f = t; f < frames; f += threads) {
+                int ok = 0;
+                (void)ldpc_ecc_decode(ecc, &llr[(size_t)(f % pool) * n_tx], out.data(), &ok);
+                ok_count[t] += ok;
+            }
+        });
+    for (auto &x : th) x.join();
+    const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    long calls = 0, launches = 0;
+    (void)ldpc_ecc_coalescing_stats(ecc, &calls, &launches);
+    printf("%8.2f %s  %4.2f %8ld frames one per call, %d threads, coalescing %d (wait %d us): %9.2f Mbit/s harness-visible, %8.0f frames/s, %.1f us per call per thread, %ld launches\n",
+           dt, ldpc_ecc_name(ecc), db, frames, threads, coalesce, wait_us, frames * (double)k / dt / 1e6, frames / dt, dt / frames * threads * 1e6,
+           coalesce > 0 ? launches : frames);
+    ldpc_ecc_destroy(ecc);
+    return 0;
+}
+
 int main(int argc, char **argv) {
     Shared S;
     std::vector<std::string> names;
     S.frames = 65536; S.batch = 16384; S.seed = 0x5EEDC0DEull;
     S.devs = {0};
     std::string tally = "auto";
+    bool harness = false;
+    int h_threads = 1, h_coalesce = 0, h_wait = 200;
     std::string codes_dir = getenv("LDPC_CODES_DIR") ? getenv("LDPC_CODES_DIR") : "codes";
     for (int i = 1; i < argc; i++) {
         const char *a = argv[i];
@@ -155,6 +197,7 @@ int main(int argc, char **argv) {
             for (const char *p = a + 2; *p;) { S.devs.push_back((int)strtol(p, (char **)&p, 10)); if (*p == ',') p++; else break; }
         }
         else if (!strncmp(a, "-t", 2)) tally = a + 2;
+        else if (!strncmp(a, "-H", 2)) { harness = true; sscanf(a + 2, "%d,%d,%d", &h_threads, &h_coalesce, &h_wait); }
         else if (!strncmp(a, "-c", 2)) codes_dir = a + 2;
         else {
             char *end = nullptr;
@@ -171,6 +214,13 @@ int main(int argc, char **argv) {
     S.use_rccl = tally == "rccl" || (tally == "auto" && P > 1 && distinct);
     if (S.use_rccl && !distinct) { fprintf(stderr, "-trccl needs distinct devices (RCCL has one rank per GPU); use -thost\n"); return 2; }
     if (ldpc_init(S.devs[0]) != LDPC_OK) { fprintf(stderr, "ldpc_init: %s\n", ldpc_last_error()); return 1; }
+    if (harness) {
+        int rc = 0;
+        for (const std::string &name : names)
+            for (double db : S.ebn0s) rc |= harness_mode(codes_dir, name, db, S.frames, S.seed, std::max(1, h_threads), h_coalesce, h_wait);
+        ldpc_shutdown();
+        return rc;
+    }
     const long per_rank = (S.frames + P - 1) / P;
     if (S.batch > per_rank) S.batch = (int)per_rank;
     if (S.use_rccl) {

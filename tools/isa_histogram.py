@@ -17,8 +17,8 @@ the loop two counts are given:
 A dynamic cross-check is the PMC pass of tools/profile.sh: SQ_INSTS_VALU / SQ_WAVES / (mean turns per frame).
 
 Issue cost classes (clk per wave-instruction per SIMD, measured on MI355X with tools/microbench_valu.hip,
-profiles/*_microbench.txt): "2" full rate, "4" half rate, "8" transcendental (quarter rate), "f64", "?" = not
-measured (priced at 4).  cost_weighted_clk = sum(count * clk): the VALU-pipe time one wave-turn needs at best.
+profiles/*_microbench*.txt): "2" full rate, "4" half rate, "8" transcendental (quarter rate, 8.2), "pk" packed f32 (4.7),
+"f64", "?" = not measured (priced at 4).  cost_weighted_clk = sum(count * clk): the VALU-pipe time one wave-turn needs at best.
 """
 from __future__ import annotations
 
@@ -48,9 +48,9 @@ def valu_class(m):
     if base in CLK4 or base.startswith("v_cmp_") or base.startswith("v_cmpx_"):
         return "4", 4
     if base in TRANS:
-        return "8", 8
+        return "8", 8.2     # measured 8.1-8.4 (tools/microbench_valu2.hip, profiles/r02_microbench_valu2.txt)
     if base in PK2:
-        return "pk", 4      # measured: see microbench table (priced per instruction)
+        return "pk", 4.7    # measured 4.5-4.8 per instruction: two f32 results per lane at the rate of two plain ops
     if base.endswith("_f64") or "_f64_" in base:
         return "f64", 8
     return "?", 4

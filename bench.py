@@ -68,7 +68,10 @@ def main():
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     dist = None
-    if world > 1:
+    # LDPC_BENCH_FORCE_DIST=1: initialise the process group and run the collectives even with ONE rank -- the RCCL calls of
+    # the N > 1 path on a 1-GPU box (tests/test_bench_contract_gpu.py)
+    force_dist = os.environ.get("LDPC_BENCH_FORCE_DIST") == "1" and "RANK" in os.environ
+    if world > 1 or force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if rehearse:
@@ -112,7 +115,7 @@ def main():
         dec.decode_batch_dev(llr[i % nbuf].data_ptr(), bits.data_ptr(), B, args.iters, iters_t.data_ptr(), conv_t.data_ptr(), sp, llr_f16=f16)
 
     def barrier():
-        if world > 1:
+        if dist is not None:
             dist.barrier()
 
     tally = torch.zeros(4, dtype=torch.int64, device=dev)  # frames, frame errors, bit errors, sum iters
@@ -138,7 +141,7 @@ def main():
     tally[2] = wrong.sum()
     tally[3] = iters_t.sum()
     from ecc_ldpc_amd import harness
-    dist_mod = dist if world > 1 else None
+    dist_mod = dist
     elapsed = harness.max_over_ranks(t1 - t0, dev, dist_mod)
     harness.all_reduce_tallies(tally, dist_mod)  # the path's only collective: 32 bytes over RCCL/xGMI
     frames_total = world * args.steps * B
@@ -180,7 +183,7 @@ def main():
     torch.cuda.synchronize()
     ecc.close()
     del llr, msg, bits, iters_t, conv_t, tally
-    if world > 1:
+    if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
 

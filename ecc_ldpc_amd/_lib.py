@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.environ.get("LDPC_SO") or os.path.join(HERE, "libldpc_hip.so")  # LDPC_SO: ablation builds (tools/)
 
 OK, EINVAL, ENOMEM, EHIP, ENODEVICE, EUNSUPPORTED, EDEGREE, EFORMAT, ENOTFOUND = 0, -1, -2, -3, -4, -5, -6, -7, -8
-TANH, MINSUM = 0, 1
+TANH, MINSUM, TANH_CM = 0, 1, 2
 F32, F64, F16 = 0, 1, 2
 PATH_AUTO, PATH_FLOOD, PATH_FUSED = 0, 1, 2
 SCHED_FLOODING, SCHED_LAYERED = 0, 1
@@ -291,7 +291,8 @@ def init(device: int = 0):
     check(lib().ldpc_init(int(device)))
 
 
-_VARIANTS = {"tanh": TANH, "min": MINSUM, "minsum": MINSUM, "min-sum": MINSUM, TANH: TANH, MINSUM: MINSUM}
+_VARIANTS = {"tanh": TANH, "min": MINSUM, "minsum": MINSUM, "min-sum": MINSUM, "cm": TANH_CM, "tanh-cm": TANH_CM, TANH: TANH, MINSUM: MINSUM,
+             TANH_CM: TANH_CM}
 _DTYPES = {"f32": F32, "f64": F64, "f16": F16, F32: F32, F64: F64, F16: F16}
 _PATHS = {"auto": PATH_AUTO, "flood": PATH_FLOOD, "fused": PATH_FUSED, 0: 0, 1: 1, 2: 2}
 _SCHEDULES = {"flooding": SCHED_FLOODING, "flood": SCHED_FLOODING, "layered": SCHED_LAYERED, 0: 0, 1: 1}

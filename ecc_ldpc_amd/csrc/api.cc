@@ -371,7 +371,11 @@ ldpc_ctx *ldpc_ctx_create_cfg(const ldpc_code *code_c, const ldpc_ctx_config *cf
     const int variant = cfg->variant, dtype = cfg->dtype, max_batch = cfg->max_batch, path = cfg->path;
     const int schedule = cfg->struct_size >= sizeof(ldpc_ctx_config) ? cfg->schedule : LDPC_SCHED_FLOODING;
     if (schedule != LDPC_SCHED_FLOODING && schedule != LDPC_SCHED_LAYERED) { set_error(LDPC_EINVAL, "unknown schedule %d", schedule); return nullptr; }
-    if (!code || max_batch <= 0 || (variant != LDPC_TANH && variant != LDPC_MINSUM) ||
+    if (variant == LDPC_TANH_CM && (dtype != LDPC_F64 || schedule != LDPC_SCHED_FLOODING || path == LDPC_PATH_FUSED)) {
+        set_error(LDPC_EUNSUPPORTED, "LDPC_TANH_CM (arraylet-cm numerics) is a parity mode: f64, flooding schedule, flood path (an f32 kernel is 1e-5 away from either tanh flavour)");
+        return nullptr;
+    }
+    if (!code || max_batch <= 0 || (variant != LDPC_TANH && variant != LDPC_MINSUM && variant != LDPC_TANH_CM) ||
         (dtype != LDPC_F32 && dtype != LDPC_F64 && dtype != LDPC_F16) ||
         (path != LDPC_PATH_AUTO && path != LDPC_PATH_FLOOD && path != LDPC_PATH_FUSED)) {
         set_error(LDPC_EINVAL, "ldpc_ctx_create: bad arguments (variant=%d dtype=%d max_batch=%d path=%d)", variant, dtype, max_batch, path);
@@ -393,7 +397,7 @@ ldpc_ctx *ldpc_ctx_create_cfg(const ldpc_code *code_c, const ldpc_ctx_config *cf
         if (dtype == LDPC_F16) { set_error(LDPC_EUNSUPPORTED, "the layered schedule exists for f32 and f64"); return nullptr; }
         if (code->max_row_deg > 32) { set_error(LDPC_EUNSUPPORTED, "layered schedule: check rows above weight 32 (this code has %d)", code->max_row_deg); return nullptr; }
     }
-    const bool fused_ok = schedule == LDPC_SCHED_FLOODING && ldpc::fused_supported(*code, variant, dtype);
+    const bool fused_ok = schedule == LDPC_SCHED_FLOODING && variant != LDPC_TANH_CM && ldpc::fused_supported(*code, variant, dtype);
     if (path == LDPC_PATH_FUSED && !fused_ok) {
         if (schedule == LDPC_SCHED_LAYERED) { set_error(LDPC_EUNSUPPORTED, "no on-chip kernel for the layered schedule (state lives in HBM: LDPC_PATH_FLOOD)"); return nullptr; }
         set_error(LDPC_EUNSUPPORTED, "no fused kernel for this code/variant/dtype (%s)", ldpc::fused_why_not(*code, variant, dtype));
@@ -423,6 +427,7 @@ ldpc_ctx *ldpc_ctx_create_cfg(const ldpc_code *code_c, const ldpc_ctx_config *cf
     d.row_ptr = tabs.row_ptr; d.col_idx = tabs.col_idx; d.col_ptr = tabs.col_ptr; d.csc_edge = tabs.csc_edge;
     d.unsat = nullptr; d.iters = nullptr; d.conv = nullptr; d.done = nullptr;
     d.wide_rows = 0;
+    d.cm_order = variant == LDPC_TANH_CM ? 1 : 0;
     ctx->flood.variant = variant; ctx->flood.dtype = dtype; ctx->flood.timer = &ctx->timer;
     // (the staging buffers of the host-pointer entry points are allocated on first use: a context driven
     //  through ldpc_decode_batch_dev with 65 536 frames would otherwise park 3 GB of HBM)
@@ -436,7 +441,7 @@ ldpc_ctx *ldpc_ctx_create_cfg(const ldpc_code *code_c, const ldpc_ctx_config *cf
         // scratch is only touched by rows whose degree has no register kernel
         bool need_scratch = false;
         const char *wz = getenv("LDPC_FLOOD_WIDE");   // LDPC_FLOOD_WIDE=0: rows of weight 9..32 through the O(d^2) fallback (A/B)
-        const bool paddable = !(variant == LDPC_TANH && dtype == LDPC_F64) && !(wz && !strcmp(wz, "0"));
+        const bool paddable = !(variant != LDPC_MINSUM && dtype == LDPC_F64) && !(wz && !strcmp(wz, "0"));
         for (int m = 0; m < code->M; m++) {
             int dg = code->row_ptr[m + 1] - code->row_ptr[m];
             if (dg <= 8 || dg == 18) continue;

@@ -122,6 +122,27 @@ __device__ void cn_row_generic(const FloodDev &d, ST *__restrict__ msg, ST *__re
                 neg ^= (tj > CT(0)) ? 1u : 0u;
             }
             out = CT(-0.75) * (neg ? -mag : mag);
+        } else if constexpr (VARIANT == LDPC_V_TANH_CM && sizeof(CT) == 8) {
+            // arraylet-cm: the whole row's StableDiv (right fold), then `sdiv` by this edge's factor
+            double sa = 0, sb = 0, xk = 0;
+            for (int j = deg - 1; j >= 0; j--) {
+                int col = d.col_idx[ebeg + j];
+                double tj = Store<ST>::ld(lam + (size_t)col * d.Bp + b) - Store<ST>::ld(msg + (size_t)(ebeg + j) * d.Bp + b);
+                const double v = tanh(-(tj / 2.0));
+                if (j == k) xk = v;
+                const double a = v >= 1.0 ? 1.0 : v, bq = v >= 1.0 ? v : 1.0;
+                if (j == deg - 1) { sa = a; sb = bq; }
+                else {
+                    const bool a_smaller = fabs(a) < fabs(sa);
+                    const double mn = a_smaller ? a : sa, mx = a_smaller ? sa : a;
+                    sb = (bq * mx) * sb;
+                    sa = mn;
+                }
+            }
+            const double q = (sa == xk) ? sb : sa * (sb / xk);
+            double y = 0.5 * log((1.0 + q) / (1.0 - q));
+            if (isinf(y)) y = (q > 0.0 ? 1.0 : (q < 0.0 ? -1.0 : q)) * kAtanhClamp;
+            out = -2.0 * y;
         } else if constexpr (sizeof(CT) == 8) {
             double prod = 1.0;
             for (int j = 0; j < deg; j++) {
@@ -192,7 +213,7 @@ __global__ __launch_bounds__(kWave *kCnWaves) void flood_cn_kernel(FloodDev d, S
     const bool active = force ? true : (d.done[b] == 0);
     if (!active) return; // lanes of finished (or padding) frames drop out; an all-done wave exits
     const bool so = syndrome_only != 0;
-    constexpr bool kPaddable = !(VARIANT == LDPC_V_TANH && sizeof(typename Store<ST>::CT) == 8);  // f64 tanh: O(d^2) anyway
+    constexpr bool kPaddable = !(VARIANT != LDPC_V_MINSUM && sizeof(typename Store<ST>::CT) == 8);  // f64 tanh (both numerics): O(d^2) anyway
     const bool wide_row = kPaddable && d.wide_rows && deg > 8 && deg <= 32 && deg != 18;
     if constexpr (WIDE) {
         if (!wide_row) return;
@@ -278,6 +299,15 @@ __global__ __launch_bounds__(256) void flood_vn_kernel(FloodDev d, const ST *__r
     CT acc = Store<ST>::ld(orig + (size_t)col * d.Bp + b);
     const int qb = d.col_ptr[col], qe = d.col_ptr[col + 1];
     const int deg = qe - qb;   // wave-uniform
+    if (d.cm_order) {   // arraylet-cm: lam' = orig + foldr1 (+) [ne' of the column, ascending row] (CachedMult.hs:190-194,261-262)
+        if (deg > 0) {
+            CT sum = Store<ST>::ld(msg + (size_t)d.csc_edge[qe - 1] * d.Bp + b);
+            for (int q = qe - 2; q >= qb; q--) sum = Store<ST>::ld(msg + (size_t)d.csc_edge[q] * d.Bp + b) + sum;
+            acc = acc + sum;
+        }
+        Store<ST>::st(lam + (size_t)col * d.Bp + b, acc);
+        return;
+    }
     // Two ways of getting a column's message loads in flight together (a plain loop pays one memory round trip per
     // edge): a function per weight, or predicated loads after clustered index loads.  Measured on one box, jpl.4096,
     // 16 384 frames, whole flood path: f32 1 050 (predicated) vs 990 Mbit/s (per weight), fp16 storage 1 110 vs
@@ -855,6 +885,10 @@ static int layered_step_impl(FloodState &s, hipStream_t st, int batch, const dou
 }
 
 #define DISPATCH(FN, ...)                                                                   \
+    if (s.variant == LDPC_TANH_CM) {                                                        \
+        if (s.dtype == LDPC_F64) return FN<double, LDPC_V_TANH_CM>(__VA_ARGS__);            \
+        return set_error(LDPC_EUNSUPPORTED, "the arraylet-cm numerics exist in f64 only");  \
+    }                                                                                       \
     switch (s.dtype) {                                                                      \
         case LDPC_F32: return s.variant == LDPC_MINSUM ? FN<float, LDPC_V_MINSUM>(__VA_ARGS__) : FN<float, LDPC_V_TANH>(__VA_ARGS__);   \
         case LDPC_F64: return s.variant == LDPC_MINSUM ? FN<double, LDPC_V_MINSUM>(__VA_ARGS__) : FN<double, LDPC_V_TANH>(__VA_ARGS__); \

@@ -431,6 +431,7 @@ ldpc_ecc *ldpc_ecc_create_replicas(const char *codes_dir, const char *code_name,
         if (ends("-bool")) { as_bool = true; dec.resize(dec.size() - 5); }
         if (ends("-layered")) { schedule = LDPC_SCHED_LAYERED; dec.resize(dec.size() - 8); }   // extension: row-layered schedule
         if (dec == "hip-tanh") variant = LDPC_TANH;
+        else if (dec == "hip-tanh-cm") variant = LDPC_TANH_CM;   // the reference's `arraylet-cm` numerics (f64 parity mode)
         else if (dec == "hip-minsum") variant = LDPC_MINSUM;
         else { set_error(LDPC_ENOTFOUND, "decoder '%s' is not provided by libldpc_hip (hip-tanh, hip-minsum [-layered][-f32|-f64|-f16])", xs[1].c_str()); return nullptr; }
 

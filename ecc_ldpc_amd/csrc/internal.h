@@ -20,6 +20,7 @@ int set_error(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3
 struct FloodDev {
     int M, N, E, Bp;
     int wide_rows;           // rows of weight 9..32 go to the padded-register CN instance (0: O(d^2) fallback, A/B)
+    int cm_order;            // arraylet-cm column sum: orig + foldr1 (+) (CachedMult.hs:261-262) instead of foldr (+) orig
     const int32_t *row_ptr;  // [M+1]
     const int32_t *col_idx;  // [E]   CSR, ascending column inside a row
     const int32_t *col_ptr;  // [N+1]

@@ -43,6 +43,7 @@ namespace ldpc { enum { LLR_F32 = 0, LLR_F64 = 1, LLR_F16 = 2 }; }
 
 #define LDPC_V_TANH 0
 #define LDPC_V_MINSUM 1
+#define LDPC_V_TANH_CM 2   // the reference's `arraylet-cm` numerics (Fast/CachedMult.hs): f64 only, flood path only
 
 namespace ldpc {
 
@@ -145,6 +146,37 @@ __device__ __forceinline__ void cn_tanh_f64(double (&t)[DEG]) {
             if (j != k) prod = prod * th[j];
         double y = 0.5 * log((1.0 + prod) / (1.0 - prod));
         if (isinf(y)) y = (prod > 0.0 ? 1.0 : -1.0) * kAtanhClamp;
+        t[k] = -2.0 * y;
+    }
+}
+
+// tanh rule with the row product cached as a StableDiv -- the reference's `arraylet-cm` decoder,
+// src/ECC/Code/LDPC/Fast/CachedMult.hs:25-56 (StableDiv, lit, smult, sdiv) and :247-259: per row
+//   S = foldr1 smult [lit x_j | ascending column],  x_j = tanh(-(t_j/2)),   ne'_k = -2 atanh' (S `sdiv` x_k)
+// StableDiv (a, b): a = the factor closest to zero, b = the product of the others.  Same real function as cn_tanh_f64,
+// different roundings.
+template <int DEG>
+__device__ __forceinline__ void cn_tanh_cm_f64(double (&t)[DEG]) {
+    double x[DEG];
+#pragma unroll
+    for (int k = 0; k < DEG; k++) x[k] = tanh(-(t[k] / 2.0));
+    double sa, sb;
+    { const double v = x[DEG - 1]; if (v >= 1.0) { sa = 1.0; sb = v; } else { sa = v; sb = 1.0; } }            // lit (:41-44)
+#pragma unroll
+    for (int k = DEG - 2; k >= 0; k--) {                                                                          // smult (lit x_k) acc (:46-50)
+        const double v = x[k];
+        const double a = v >= 1.0 ? 1.0 : v, bq = v >= 1.0 ? v : 1.0;
+        const bool a_smaller = fabs(a) < fabs(sa);                                                                // absMinMax (:31-34)
+        const double mn = a_smaller ? a : sa, mx = a_smaller ? sa : a;
+        sb = (bq * mx) * sb;
+        sa = mn;
+    }
+#pragma unroll
+    for (int k = 0; k < DEG; k++) {
+        const double c = x[k];
+        const double q = (sa == c) ? sb : sa * (sb / c);                                                          // sdiv (:52-55)
+        double y = 0.5 * log((1.0 + q) / (1.0 - q));
+        if (isinf(y)) y = (q > 0.0 ? 1.0 : (q < 0.0 ? -1.0 : q)) * kAtanhClamp;
         t[k] = -2.0 * y;
     }
 }
@@ -299,6 +331,8 @@ template <typename CT, int VARIANT, int DEG>
 __device__ __forceinline__ void cn_update(CT (&t)[DEG]) {
     if constexpr (VARIANT == LDPC_V_MINSUM) {
         cn_minsum<CT, DEG>(t);
+    } else if constexpr (VARIANT == LDPC_V_TANH_CM && sizeof(CT) == 8) {
+        cn_tanh_cm_f64<DEG>(t);
     } else if constexpr (sizeof(CT) == 8) {
         cn_tanh_f64<DEG>(t);
     } else {

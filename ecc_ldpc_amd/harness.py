@@ -30,7 +30,7 @@ def shard_frames(total_frames: int, rank: int, world: int, first_frame: int = 0)
 
 def all_reduce_tallies(tally, dist=None):
     """tally: torch int64 tensor [4] on the rank's device -> summed over ranks in place."""
-    if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
+    if dist is not None and dist.is_initialized():      # (also with one rank: the collective itself is exercised)
         if dist.get_backend() == "gloo" and tally.is_cuda:  # rehearsal of the N > 1 path without RCCL
             host = tally.cpu()
             dist.all_reduce(host, op=dist.ReduceOp.SUM)
@@ -42,7 +42,7 @@ def all_reduce_tallies(tally, dist=None):
 
 def max_over_ranks(seconds: float, device, dist=None) -> float:
     import torch
-    multi = dist is not None and dist.is_initialized() and dist.get_world_size() > 1
+    multi = dist is not None and dist.is_initialized()
     if multi and dist.get_backend() == "gloo":
         device = "cpu"
     t = torch.tensor([seconds], dtype=torch.float64, device=device)

@@ -47,8 +47,11 @@ extern "C" {
 typedef struct ldpc_code ldpc_code; /* immutable parity-check graph, host + device tables */
 typedef struct ldpc_ctx ldpc_ctx;   /* one decoder replica: device buffers + stream          */
 
-/* check-node rule.  LDPC_TANH: Reference/Orig.hs:81-92 ; LDPC_MINSUM: Reference/Min.hs:75-87 */
-typedef enum { LDPC_TANH = 0, LDPC_MINSUM = 1 } ldpc_variant;
+/* check-node rule.  LDPC_TANH: Reference/Orig.hs:81-92 ; LDPC_MINSUM: Reference/Min.hs:75-87 ;
+ * LDPC_TANH_CM: the tanh rule with the roundings of the reference's `arraylet-cm` decoder (Fast/CachedMult.hs:25-56,
+ * 233-264: row product cached as a StableDiv, leave-one-out by division, column sum orig + foldr1 (+)) -- the same real
+ * function as LDPC_TANH, ~1e-11 apart in double.  Parity mode only: LDPC_F64, flooding schedule, flood path. */
+typedef enum { LDPC_TANH = 0, LDPC_MINSUM = 1, LDPC_TANH_CM = 2 } ldpc_variant;
 /* arithmetic / storage type of LLRs and messages on the device.
  * F32: the cudabits kernels' `typedef float float_ty` (cudabits/common.h:1).
  * F64: parity mode, same type as the CPU reference (Double).
@@ -288,7 +291,7 @@ ldpc_code *ldpc_code_from_matrix(const ldpc_matrix *m);
  * C mirror of what mkLDPC returns (src/ECC/Code/LDPC/Utils.hs:35-75): ECC{name, encode, decode,
  * message_length, codeword_length}, selected by the reference's code-name grammar
  *   ldpc/<decoder>/<matrix-name>/<max-rounds>[/<x>/<y>]        (Utils.hs:82-88,100-108; rate x%y)
- * with <decoder> in {hip-tanh, hip-minsum}[-layered][-f32|-f64|-f16].  NULL + LDPC_ENOTFOUND for any other
+ * with <decoder> in {hip-tanh, hip-minsum}[-layered][-f32|-f64|-f16] or hip-tanh-cm-f64.  NULL + LDPC_ENOTFOUND for any other
  * name (the factory's `_ -> return []`). One decoder replica is created (maxThreadCount = 1, like
  * the CUDA plug-ins, GPU/CUDA/Arraylet2.hs:61). */
 typedef struct ldpc_ecc ldpc_ecc;

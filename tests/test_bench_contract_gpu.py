@@ -75,3 +75,13 @@ def test_flood_path_reports_an_hbm_roofline():
     d = _run([sys.executable, "bench.py", "--steps", "2", "--warmup", "1", "--batch", "2048", "--cpu-seconds", "0", "--path", "flood"])
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and "flood_cn" in r["kernel"] and 0 < r["frac"] <= 1.0 and d["proof_of_work"]["ok"]
+
+
+def test_rccl_collectives_run_with_one_rank():
+    """The N > 1 path's process-group setup and its two collectives (all-reduce of the tallies, max of the elapsed time) over
+    the real RCCL backend, with a single rank on this 1-GPU box: next to the library's own HIP client in the process."""
+    d = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+              "--master-port", "29534", "bench.py", "--gpus", "1", "--steps", "2", "--warmup", "1", "--batch", "2048", "--cpu-seconds", "0"],
+             env={"LDPC_BENCH_FORCE_DIST": "1"}, only_line=False)
+    assert d["n_gpus"] == 1 and "rehearsal" not in d and d["proof_of_work"]["ok"]
+    assert abs(d["value"] - 2 * 2048 * 4096 / (d["ms_per_step"] * 2e-3) / 1e6) / d["value"] < 0.02

@@ -246,9 +246,27 @@ def committed_traffic(args, dec, B):
     return None, None
 
 
-def isa_entry(kernel_name):
+def isa_entry(kernel_name, code=None, variant="min"):
     """instruction histogram of the kernel's iteration loop from the build's own assembly
-    (ecc_ldpc_amd/build/isa_stats.json, written by build.py with tools/isa_histogram.py)"""
+    (ecc_ldpc_amd/build/isa_stats.json, written by build.py with tools/isa_histogram.py); for a run-time specialised
+    kernel: from the assembly of its generated source, compiled once with the tool chain and kept next to the cached
+    code object (jit_cache/<kernel>.isa.json)"""
+    if kernel_name.startswith("ldpc_jit_") and code is not None:
+        try:
+            import importlib.util
+            import ecc_ldpc_amd as E
+            cache = os.path.join(E.lib().ldpc_jit_cache_dir().decode(), kernel_name + ".isa.json")
+            if os.path.exists(cache):
+                ent = json.load(open(cache))
+            else:
+                spec = importlib.util.spec_from_file_location("isa_histogram", os.path.join(ROOT, "tools", "isa_histogram.py"))
+                mod = importlib.util.module_from_spec(spec)
+                spec.loader.exec_module(mod)
+                ent = mod.run_on_source(code.jit_source(variant), os.path.join(ROOT, "ecc_ldpc_amd", "csrc"), kernel_name)[0]
+                json.dump(ent, open(cache, "w"))
+            return None if any(lp.get("inner_loops") for lp in ent["loops"]) else ent
+        except Exception:
+            return None
     try:
         stats = json.load(open(os.path.join(ROOT, "ecc_ldpc_amd", "build", "isa_stats.json")))
     except Exception:
@@ -299,7 +317,7 @@ def rooflines(args, dec, B, Eg, N, n_tx, k, s_bytes, launches, kernel_ms, turns_
              "algorithmic_bytes_per_launch": bytes_per_launch, "bytes_model": "(2E+N)*s * frames per check-node launch"}
         return r, hbm
     threads, fpw = dec.kernel_geometry
-    ent = isa_entry(dec.kernel_name)
+    ent = isa_entry(dec.kernel_name, dec.code, "min" if args.variant == "minsum" else "tanh")
     r = {"bound": "valu", "unit": "G wave-instr/s", "peak": round(VALU_PEAK / 1e9, 1), "kernel": dec.kernel_name, "launches": launches,
          "avg_launch_ms": round(avg_ms, 4), "traffic": traffic, "traffic_source": tsrc and f"{tsrc} (committed PMC pass, not measured in this run)",
          "frame_turns_timed": turns_timed, "threads_per_workgroup": threads, "frames_per_workgroup": fpw}

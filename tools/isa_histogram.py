@@ -304,6 +304,24 @@ def run(paths, kernel_regex=None):
     return out
 
 
+def run_on_source(source_text, include_dir, kernel_regex=None, defines=("LDPC_JIT",)):
+    """Compile a translation unit to gfx950 assembly with the tool chain and analyse it: the route for the run-time
+    specialised kernels (jit.cc), whose source exists only as a generated string (Code.jit_source in the binding)."""
+    import os
+    import tempfile
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    with tempfile.TemporaryDirectory() as d:
+        src, asm = os.path.join(d, "k.hip"), os.path.join(d, "k.s")
+        open(src, "w").write(source_text)
+        cmd = [hipcc, "-S", "--cuda-device-only", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-w",
+               "-I" + include_dir] + ["-D" + x for x in defines] + ["-x", "hip", src, "-o", asm]
+        subprocess.run(cmd, check=True, capture_output=True, timeout=600)
+        res = run([asm], kernel_regex)
+        for r in res:
+            r["source"] = "generated translation unit (jit.cc)"
+        return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("asm", nargs="+")

@@ -30,10 +30,12 @@ struct ldpc_batcher {
     std::vector<Request *> pending;
     int pending_iters = 0;
     bool decoding = false;                 // a leader is inside the decoder replica (which is not re-entrant)
-    std::vector<double> llr[2];            // staging, alternating per batch: arrivals fill one while the other decodes
+    // staging in page-locked memory (ldpc_host_alloc): batches above 16 frames then run zero-copy -- the decode kernel
+    // reads the LLRs and writes the bits over PCIe itself (api.cc decode_host) -- and smaller ones skip a bounce copy
+    double *llr[2] = {nullptr, nullptr};   // alternating per batch: arrivals fill one while the other decodes
     int fill = 0;
-    std::vector<uint8_t> out_bits, out_conv;
-    std::vector<int32_t> out_iters;
+    uint8_t *out_bits = nullptr, *out_conv = nullptr;
+    int32_t *out_iters = nullptr;
     long calls = 0, launches = 0;
 };
 
@@ -48,17 +50,24 @@ ldpc_batcher *ldpc_batcher_create(ldpc_ctx *ctx, int max_frames, int max_wait_us
     if (!b) { set_error(LDPC_ENOMEM, "out of host memory"); return nullptr; }
     try {
         b->ctx = ctx; b->N = N; b->max_frames = max_frames; b->max_wait_us = max_wait_us;
-        b->llr[0].assign((size_t)max_frames * N, 0.0);
-        b->llr[1].assign((size_t)max_frames * N, 0.0);
-        b->out_bits.assign((size_t)max_frames * N, 0);
-        b->out_conv.assign((size_t)max_frames, 0);
-        b->out_iters.assign((size_t)max_frames, 0);
         b->pending.reserve((size_t)max_frames);
     } catch (...) { delete b; set_error(LDPC_ENOMEM, "out of host memory"); return nullptr; }
+    (void)hipSetDevice(ldpc_ctx_device(ctx));
+    const size_t F = (size_t)max_frames;
+    b->llr[0] = (double *)ldpc_host_alloc(F * N * sizeof(double));
+    b->llr[1] = (double *)ldpc_host_alloc(F * N * sizeof(double));
+    b->out_bits = (uint8_t *)ldpc_host_alloc(F * N);
+    b->out_conv = (uint8_t *)ldpc_host_alloc(F);
+    b->out_iters = (int32_t *)ldpc_host_alloc(F * sizeof(int32_t));
+    if (!b->llr[0] || !b->llr[1] || !b->out_bits || !b->out_conv || !b->out_iters) { ldpc_batcher_destroy(b); return nullptr; }
     return b;
 }
 
-void ldpc_batcher_destroy(ldpc_batcher *b) { delete b; }
+void ldpc_batcher_destroy(ldpc_batcher *b) {
+    if (!b) return;
+    ldpc_host_free(b->llr[0]); ldpc_host_free(b->llr[1]); ldpc_host_free(b->out_bits); ldpc_host_free(b->out_conv); ldpc_host_free(b->out_iters);
+    delete b;
+}
 
 int ldpc_batcher_stats(ldpc_batcher *b, long *calls, long *launches) {
     if (!b) return set_error(LDPC_EINVAL, "null batcher");
@@ -97,7 +106,7 @@ int ldpc_batcher_decode_one(ldpc_batcher *b, int max_iters, const double *llr, u
     b->launches++;
     b->cv_room.notify_all();                // the next batch may start collecting while this one decodes
     lk.unlock();
-    int rc = ldpc_decode_batch_f64(b->ctx, max_iters, n, b->llr[side].data(), b->out_bits.data(), b->out_iters.data(), b->out_conv.data(), nullptr);
+    int rc = ldpc_decode_batch_f64(b->ctx, max_iters, n, b->llr[side], b->out_bits, b->out_iters, b->out_conv, nullptr);
     const int code = rc == LDPC_OK ? LDPC_OK : ldpc_last_error_code();
     for (int i = 0; i < n; i++) {
         ldpc_batcher::Request *q = batch[i];

@@ -198,18 +198,6 @@ def test_tanh_f32_fused(hip, name, dbs):
     print(f"{name} fused tanh f32: worst teacher-forced relative LLR error {worst:.3e} over {len(states)} turns; {c1.mean() * 100:.0f}% converged")
 
 
-def test_record_kernel_still_matches(hip, monkeypatch):
-    """The compressed-record kernel (LDPC_FUSED_KERNEL=rec) is kept for A/B measurements: it must give
-    the same bits as the default per-edge-message kernel."""
-    c = load("jpl.4096.4.5")
-    llr = _frames(c, 8, (2.0, 3.2), 900).astype(np.float32)
-    code = c.hip_code(hip)
-    a = hip.Decoder(code, "min", "f32", len(llr), path="fused").decode_batch(llr, 50)
-    monkeypatch.setenv("LDPC_FUSED_KERNEL", "rec")
-    b = hip.Decoder(code, "min", "f32", len(llr), path="fused").decode_batch(llr, 50)
-    assert all(np.array_equal(x, y) for x, y in zip(a, b))
-
-
 def test_concurrent_contexts_on_separate_streams(hip):
     """Several decoder replicas (the reference's maxThreadCount > 1, Utils.hs:53) working at once on their
     own streams must not disturb each other: fused kernels keep no per-context device state, the flood path

@@ -307,6 +307,12 @@ def rooflines(args, dec, B, Eg, N, n_tx, k, s_bytes, launches, kernel_ms, turns_
              "algorithmic_bytes_timed": bytes_timed, "frame_sweeps_timed": turns_timed,
              "bytes_model": "sum_frames(sweeps_f)*4E*s + frames*E*s (one persistent launch decodes the batch; lam and messages live in HBM)"}
         return r, None
+    if dec.path != "fused" and "flood_qc_kernel" in dec.kernel_name:
+        # flooding from HBM, one workgroup per frame, ONE launch per batch: the contract's byte model is exactly this
+        # kernel's algorithmic traffic -- (3E+3N)*s per frame and turn run, the LLRs in, the bits out
+        r = dict(hbm)
+        r.update({"traffic": None, "kernel": dec.kernel_name, "launches": launches, "avg_launch_ms": round(avg_ms, 4), "frame_turns_timed": turns_timed})
+        return r, None
     if dec.path != "fused":
         # flood path: state in HBM, two kernels per turn; the timed kernel is the check-node kernel and every launch of
         # it streams (2E+N)*s bytes per frame of the batch
@@ -359,9 +365,10 @@ def proof_of_work(args, E, ecc, dec, sim, llr_t, msg_t, bits, iters_t, conv_t, s
         return proof_of_work_layered(args, E, ecc, dec, sim, llr_t, msg_t, bits, iters_t, conv_t, sp, f16, n)
     flood_dtype = "f32" if args.dtype == "f16" else args.dtype     # fused-F16(llr) == F32 decoder on the fp16-rounded LLRs
     variant = "min" if args.variant == "minsum" else "tanh"
-    out = {"sample_frames": n, "checked_against": "flood path (ldpc_ctx_create_ex path=LDPC_PATH_FLOOD)", "points": []}
+    other = "fused" if dec.path == "flood" else "flood"     # a different implementation of the same schedule
+    out = {"sample_frames": n, "checked_against": f"{other} path (another kernel family for the same decoder)", "points": []}
     try:
-        flood = E.Decoder(ecc.code, variant, flood_dtype, n, path="flood")
+        flood = E.Decoder(ecc.code, variant, flood_dtype, n, path=other)
     except E.LdpcError as e:
         out["error"] = str(e)
         return out

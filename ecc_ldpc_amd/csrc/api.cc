@@ -431,9 +431,11 @@ ldpc_ctx *ldpc_ctx_create_cfg(const ldpc_code *code_c, const ldpc_ctx_config *cf
     ctx->flood.variant = variant; ctx->flood.dtype = dtype; ctx->flood.timer = &ctx->timer;
     // (the staging buffers of the host-pointer entry points are allocated on first use: a context driven
     //  through ldpc_decode_batch_dev with 65 536 frames would otherwise park 3 GB of HBM)
-    if (ctx->path == LDPC_PATH_FLOOD && schedule == LDPC_SCHED_LAYERED && ldpc::layered_qc_why_not(*code, variant, dtype) == nullptr) {
-        // QC code: one workgroup per frame (a frame stops when ITS rule fires); any other H: the batch-major kernel below
-        ctx->lqc = ldpc::layered_qc_create(*code, variant, dtype, max_batch);
+    const int qc_flooding = schedule == LDPC_SCHED_FLOODING ? 1 : 0;
+    if (ctx->path == LDPC_PATH_FLOOD && ldpc::layered_qc_why_not(*code, variant, dtype, qc_flooding) == nullptr) {
+        // QC code, either schedule: one workgroup per frame, state in HBM (a frame stops when ITS rule fires);
+        // any other H, fp16 storage and the arraylet-cm parity mode: the batch-major kernels below
+        ctx->lqc = ldpc::layered_qc_create(*code, variant, dtype, max_batch, qc_flooding);
         if (!ctx->lqc) { ldpc_ctx_destroy(ctx); return nullptr; }
         ldpc::layered_qc_set_timer(ctx->lqc, &ctx->timer);
     } else if (ctx->path == LDPC_PATH_FLOOD) {

@@ -4,8 +4,9 @@
 
 namespace ldpc {
 struct LayeredQcState;
-const char *layered_qc_why_not(const ldpc_code &c, int variant, int dtype);
-LayeredQcState *layered_qc_create(const ldpc_code &c, int variant, int dtype, int max_batch);
+// flooding = 0: the layered schedule (layers = block rows); 1: the reference's flooding schedule with the same mapping
+const char *layered_qc_why_not(const ldpc_code &c, int variant, int dtype, int flooding);
+LayeredQcState *layered_qc_create(const ldpc_code &c, int variant, int dtype, int max_batch, int flooding);
 void layered_qc_destroy(LayeredQcState *s);
 void layered_qc_set_timer(LayeredQcState *s, KernelTimer *t);
 const LaunchInfo &layered_qc_launch_info(const LayeredQcState &s);

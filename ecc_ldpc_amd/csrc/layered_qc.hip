@@ -1,4 +1,5 @@
-// layered_qc.hip -- row-layered schedule for quasi-cyclic codes of ANY size, state in HBM, one workgroup per FRAME.
+// layered_qc.hip -- quasi-cyclic codes of ANY size with the state in HBM, one workgroup per FRAME: the row-layered
+// schedule (first part of this file) and the reference's flooding schedule (flood_qc_kernel, second part).
 //
 // BASELINE.json configs[4]: "DVB-S2 n = 64 800 long code, layered min-sum + early termination".  A frame of that
 // size keeps 253 KB of LLRs and 886 KB of messages -- nothing of it fits on-chip -- and early termination makes frames
@@ -35,6 +36,9 @@ struct QcLayerDev {
     int sz, nbr, nbc, N, E;         // E = (number of circulants) * sz
     const int32_t *tab;             // per circulant, block-row-major: {block column * sz, rotation} (two words)
     const int32_t *lbeg;            // [nbr + 1] first circulant of each block row
+    // flooding schedule only: the circulants of each block column in DESCENDING block-row order (Orig.hs:96 foldr)
+    const int32_t *ctab;            // per entry {circulant index, rotation} (two words)
+    const int32_t *cbeg;            // [nbc + 1]
 };
 
 struct QcLayerArgs {
@@ -45,7 +49,9 @@ struct QcLayerArgs {
     const double *st_lam, *st_ne_in; double *st_ne_out, *st_lam_out; uint8_t *st_syn;   // teacher-forced sweep (CSR edge order)
 };
 
-template <typename CT, int VARIANT, int DEG, int MODE /* 0: sweep, 1: first sweep (messages are zero), 2: syndrome only */>
+// MODE 0: layered sweep, 1: first layered sweep (messages are zero), 2: syndrome only,
+//      3: flooding check-node pass (new messages written, lam untouched), 4: the same on the first turn (messages are zero)
+template <typename CT, int VARIANT, int DEG, int MODE>
 __device__ __forceinline__ void qc_row(const QcLayerDev &g, CT *__restrict__ lam, CT *__restrict__ msg, int e0, int r, bool live, bool &odd, bool &flip) {
     int idx[DEG];
     CT l[DEG], t[DEG];
@@ -58,7 +64,8 @@ __device__ __forceinline__ void qc_row(const QcLayerDev &g, CT *__restrict__ lam
     }
 #pragma unroll
     for (int k = 0; k < DEG; k++) l[k] = live ? lam[idx[k]] : CT(0);
-    if constexpr (MODE == 0) {
+    constexpr bool kReadMsg = MODE == 0 || MODE == 3, kFlooding = MODE >= 3;
+    if constexpr (kReadMsg) {
 #pragma unroll
         for (int k = 0; k < DEG; k++) t[k] = live ? msg[(size_t)(e0 + k) * g.sz + r] : CT(0);
     }
@@ -69,13 +76,17 @@ __device__ __forceinline__ void qc_row(const QcLayerDev &g, CT *__restrict__ lam
     if constexpr (MODE == 2) return;
     CT nm[DEG];
 #pragma unroll
-    for (int k = 0; k < DEG; k++) { t[k] = (MODE == 0) ? l[k] - t[k] : l[k] - CT(0); nm[k] = t[k]; }
+    for (int k = 0; k < DEG; k++) { t[k] = kReadMsg ? l[k] - t[k] : l[k] - CT(0); nm[k] = t[k]; }
     cn_update<CT, VARIANT, DEG>(nm);
 #pragma unroll
     for (int k = 0; k < DEG; k++) {
-        const CT nw = t[k] + nm[k];
-        flip |= live && (hard(nw) != hard(l[k]));
-        if (live) { lam[idx[k]] = nw; msg[(size_t)(e0 + k) * g.sz + r] = nm[k]; }
+        if constexpr (kFlooding) {
+            if (live) msg[(size_t)(e0 + k) * g.sz + r] = nm[k];
+        } else {
+            const CT nw = t[k] + nm[k];
+            flip |= live && (hard(nw) != hard(l[k]));
+            if (live) { lam[idx[k]] = nw; msg[(size_t)(e0 + k) * g.sz + r] = nm[k]; }
+        }
     }
 }
 
@@ -94,7 +105,8 @@ __device__ __forceinline__ void qc_row_padded(const QcLayerDev &g, CT *__restric
     }
 #pragma unroll
     for (int k = 0; k < DMAX; k++) l[k] = (live && k < deg) ? lam[idx[k]] : CT(0);
-    if constexpr (MODE == 0) {
+    constexpr bool kReadMsg = MODE == 0 || MODE == 3, kFlooding = MODE >= 3;
+    if constexpr (kReadMsg) {
 #pragma unroll
         for (int k = 0; k < DMAX; k++) t[k] = (live && k < deg) ? msg[(size_t)(e0 + k) * g.sz + r] : CT(0);
     }
@@ -105,14 +117,18 @@ __device__ __forceinline__ void qc_row_padded(const QcLayerDev &g, CT *__restric
     if constexpr (MODE == 2) return;
     CT nm[DMAX];
 #pragma unroll
-    for (int k = 0; k < DMAX; k++) { t[k] = (k < deg) ? ((MODE == 0) ? l[k] - t[k] : l[k] - CT(0)) : CT(INFINITY); nm[k] = t[k]; }
+    for (int k = 0; k < DMAX; k++) { t[k] = (k < deg) ? (kReadMsg ? l[k] - t[k] : l[k] - CT(0)) : CT(INFINITY); nm[k] = t[k]; }
     cn_update_padded<CT, VARIANT, DMAX>(nm, deg);
 #pragma unroll
     for (int k = 0; k < DMAX; k++) {
         if (k < deg) {
-            const CT nw = t[k] + nm[k];
-            flip |= live && (hard(nw) != hard(l[k]));
-            if (live) { lam[idx[k]] = nw; msg[(size_t)(e0 + k) * g.sz + r] = nm[k]; }
+            if constexpr (kFlooding) {
+                if (live) msg[(size_t)(e0 + k) * g.sz + r] = nm[k];
+            } else {
+                const CT nw = t[k] + nm[k];
+                flip |= live && (hard(nw) != hard(l[k]));
+                if (live) { lam[idx[k]] = nw; msg[(size_t)(e0 + k) * g.sz + r] = nm[k]; }
+            }
         }
     }
 }
@@ -124,7 +140,7 @@ __device__ __forceinline__ void qc_layer(const QcLayerDev &g, CT *lam, CT *msg, 
         case 0: return;
         case 1:
             if constexpr (VARIANT == LDPC_V_TANH) qc_row<CT, VARIANT, 1, MODE>(g, lam, msg, e0, r, live, odd, flip);
-            else qc_row<CT, VARIANT, 2, 2>(g, lam, msg, e0, r, live, odd, flip);    // (min-sum on weight 1 is rejected at creation; never reached)
+            else qc_row<CT, LDPC_V_TANH, 1, 2>(g, lam, msg, e0, r, live, odd, flip);    // (min-sum on weight 1 is rejected at creation; never reached)
             return;
         case 2: qc_row<CT, VARIANT, 2, MODE>(g, lam, msg, e0, r, live, odd, flip); return;
         case 3: qc_row<CT, VARIANT, 3, MODE>(g, lam, msg, e0, r, live, odd, flip); return;
@@ -218,48 +234,144 @@ __global__ __launch_bounds__(1024) void layered_qc_kernel(QcLayerDev g, CT *lam_
     }
 }
 
+// ==================================================================== flooding schedule, same mapping
+// The reference's own schedule (Orig.hs:67-98) for QC codes whose frame does not fit on-chip: per turn a check-node pass
+// over the block rows (syndrome of hard(lam) from the gathered values, new messages in place), then a variable-node
+// pass: thread c owns column c of every block column and adds its messages in the reference's order -- foldr (+) orig,
+// i.e. descending row (Orig.hs:96); the message of circulant (br, bc) for column c sits at row (c - rot) mod sz, so the
+// reads are rotated but contiguous.  One launch is the whole decode; a frame stops the turn ITS syndrome is zero.
+// Same arithmetic and orders as flood.hip's two kernels: f64 bit-exact with the oracle, f32 identical to that path.
+template <typename CT>
+__device__ __forceinline__ CT qc_column(const QcLayerDev &g, const CT *__restrict__ msg, int bc, int c, CT acc) {
+    const int q0 = ((cidx_t)g.cbeg)[bc], deg = ((cidx_t)g.cbeg)[bc + 1] - q0;
+    for (int base = 0; base < deg; base += 8) {       // eight messages in flight at a time
+        CT v[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const int jj = base + j < deg ? base + j : deg - 1;
+            const int e = ((cidx_t)g.ctab)[2 * (q0 + jj)], rot = ((cidx_t)g.ctab)[2 * (q0 + jj) + 1];
+            int r = c - rot;
+            r += (r < 0) ? g.sz : 0;
+            v[j] = (base + j < deg) ? msg[(size_t)e * g.sz + r] : CT(0);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; j++)
+            if (base + j < deg) acc = v[j] + acc;
+    }
+    return acc;
+}
+
+template <typename CT, int VARIANT, int DCLASS>
+__global__ __launch_bounds__(1024) void flood_qc_kernel(QcLayerDev g, CT *lam_all, CT *msg_all, QcLayerArgs A) {
+    const int r = threadIdx.x;
+    const bool live = r < g.sz;
+    const size_t frame = blockIdx.x;
+    CT *lam = lam_all + frame * (size_t)g.N;
+    CT *msg = msg_all + frame * (size_t)g.E;
+    const size_t fN = frame * (size_t)g.N;
+    if (A.step_mode) {
+        for (int i = r; i < g.N; i += blockDim.x) lam[i] = (CT)A.st_lam[fN + i];
+        for (int l = 0; l < g.nbr; l++) {
+            const int e0 = g.lbeg[l], deg = g.lbeg[l + 1] - e0;
+            if (live)
+                for (int k = 0; k < deg; k++) msg[(size_t)(e0 + k) * g.sz + r] = (CT)A.st_ne_in[frame * (size_t)g.E + (size_t)e0 * g.sz + (size_t)r * deg + k];
+        }
+    } else {
+        for (int i = r; i < g.N; i += blockDim.x) lam[i] = load_llr<CT>(A.llr, fN + i, A.llr_fmt);
+    }
+    __syncthreads();
+    bool conv = false;
+    int n = 0;
+    for (;; n++) {
+        if (A.trace && !A.step_mode) {
+            for (int i = r; i < g.N; i += blockDim.x) A.trace[(frame * (A.max_iters + 1) + n) * (size_t)g.N + i] = (double)lam[i];
+        }
+        bool odd = false, flip = false;
+        const bool last = !A.step_mode && n >= A.max_iters;     // Orig.hs:70: only the syndrome is still wanted
+        if (last) { for (int l = 0; l < g.nbr; l++) qc_layer<CT, VARIANT, DCLASS, 2>(g, lam, msg, l, r, live, odd, flip); }
+        else if (n == 0 && !A.step_mode) { for (int l = 0; l < g.nbr; l++) qc_layer<CT, VARIANT, DCLASS, 4>(g, lam, msg, l, r, live, odd, flip); }
+        else { for (int l = 0; l < g.nbr; l++) qc_layer<CT, VARIANT, DCLASS, 3>(g, lam, msg, l, r, live, odd, flip); }
+        const int any = __syncthreads_or(odd ? 1 : 0);            // also: every new message is written before a column reads it
+        if (A.step_mode) { if (r == 0) A.st_syn[frame] = any ? 0 : 1; }
+        else {
+            if (!any) { conv = true; break; }                      // Orig.hs:69
+            if (last) break;                                       // Orig.hs:70
+        }
+        if (live)
+            for (int bc = 0; bc < g.nbc; bc++) {
+                const size_t i = (size_t)bc * g.sz + r;
+                lam[i] = qc_column<CT>(g, msg, bc, r, load_llr<CT>(A.llr, fN + i, A.llr_fmt));
+            }
+        __syncthreads();
+        if (A.step_mode) break;
+    }
+    if (A.step_mode) {
+        for (int i = r; i < g.N; i += blockDim.x) A.st_lam_out[fN + i] = (double)lam[i];
+        for (int l = 0; l < g.nbr; l++) {
+            const int e0 = g.lbeg[l], deg = g.lbeg[l + 1] - e0;
+            if (live)
+                for (int k = 0; k < deg; k++) A.st_ne_out[frame * (size_t)g.E + (size_t)e0 * g.sz + (size_t)r * deg + k] = (double)msg[(size_t)(e0 + k) * g.sz + r];
+        }
+        return;
+    }
+    for (int i = r; i < g.N; i += blockDim.x) {
+        const CT v = conv ? lam[i] : load_llr<CT>(A.llr, fN + i, A.llr_fmt);
+        A.bits[fN + i] = v > CT(0) ? 1 : 0;
+        if (A.final_lam) A.final_lam[fN + i] = (double)v;
+    }
+    if (r == 0) {
+        if (A.iters) A.iters[frame] = conv ? n : A.max_iters;
+        if (A.conv) A.conv[frame] = conv ? 1 : 0;
+    }
+}
+
 // ------------------------------------------------------------------ host side
 struct LayeredQcState {
     int variant = 0, dtype = 0, max_batch = 0, max_row_deg = 0, threads = 0;
     QcLayerDev g{};
+    bool flooding = false;
     int32_t *d_tab = nullptr;
-    int32_t *d_lbeg = nullptr;
+    int32_t *d_lbeg = nullptr, *d_ctab = nullptr, *d_cbeg = nullptr;
     void *lam = nullptr, *msg = nullptr;
     KernelTimer *timer = nullptr;
     LaunchInfo info;
 };
 
-const char *layered_qc_why_not(const ldpc_code &c, int variant, int dtype) {
+const char *layered_qc_why_not(const ldpc_code &c, int variant, int dtype, int flooding) {
     if (c.sz <= 0) return "code was not created from a quasi-cyclic description";
     if (c.sz > 1024) return "circulant size above 1024";
-    if (dtype != LDPC_F32 && dtype != LDPC_F64) return "the layered schedule exists for f32 and f64";
+    if (dtype != LDPC_F32 && dtype != LDPC_F64) return "the frame-per-workgroup HBM kernels exist for f32 and f64";
+    if (variant != LDPC_TANH && variant != LDPC_MINSUM) return "tanh and min-sum rules only";
     if (c.max_row_deg > 32) return "check rows above weight 32";
-    if ((int)c.layer_ptr.size() != c.block_rows + 1) return "layers were replaced: not the block rows";
-    for (int br = 0; br <= c.block_rows; br++) if (c.layer_ptr[br] != br * c.sz) return "layers were replaced: not the block rows";
-    const char *e = getenv("LDPC_LAYERED_QC");
-    if (e && !strcmp(e, "0")) return "disabled (LDPC_LAYERED_QC=0)";
+    if (!flooding) {
+        if ((int)c.layer_ptr.size() != c.block_rows + 1) return "layers were replaced: not the block rows";
+        for (int br = 0; br <= c.block_rows; br++) if (c.layer_ptr[br] != br * c.sz) return "layers were replaced: not the block rows";
+    }
+    const char *e = getenv(flooding ? "LDPC_FLOOD_QC" : "LDPC_LAYERED_QC");
+    if (e && !strcmp(e, "0")) return flooding ? "disabled (LDPC_FLOOD_QC=0)" : "disabled (LDPC_LAYERED_QC=0)";
     return nullptr;
 }
 
 void layered_qc_destroy(LayeredQcState *s) {
     if (!s) return;
-    (void)hipFree(s->d_tab); (void)hipFree(s->d_lbeg); (void)hipFree(s->lam); (void)hipFree(s->msg);
+    (void)hipFree(s->d_tab); (void)hipFree(s->d_lbeg); (void)hipFree(s->d_ctab); (void)hipFree(s->d_cbeg); (void)hipFree(s->lam); (void)hipFree(s->msg);
     delete s;
 }
 
-LayeredQcState *layered_qc_create(const ldpc_code &c, int variant, int dtype, int max_batch) {
-    const char *why = layered_qc_why_not(c, variant, dtype);
+LayeredQcState *layered_qc_create(const ldpc_code &c, int variant, int dtype, int max_batch, int flooding) {
+    const char *why = layered_qc_why_not(c, variant, dtype, flooding);
     if (why) { set_error(LDPC_EUNSUPPORTED, "%s", why); return nullptr; }
     LayeredQcState *s = new (std::nothrow) LayeredQcState();
     if (!s) { set_error(LDPC_ENOMEM, "out of host memory"); return nullptr; }
     try {
-        s->variant = variant; s->dtype = dtype; s->max_batch = max_batch; s->max_row_deg = c.max_row_deg;
+        s->variant = variant; s->dtype = dtype; s->max_batch = max_batch; s->max_row_deg = c.max_row_deg; s->flooding = flooding != 0;
         std::vector<int32_t> tab;
         std::vector<int32_t> lbeg(1, 0);
+        std::vector<std::vector<std::pair<int, int>>> cols((size_t)c.block_cols);   // per block column: (circulant index, rotation), ascending block row
         for (int br = 0; br < c.block_rows; br++) {
             for (int bc = 0; bc < c.block_cols; bc++) {
                 const int off = c.offsets[(size_t)br * c.block_cols + bc];
-                if (off >= 0) { tab.push_back(bc * c.sz); tab.push_back(off); }
+                if (off >= 0) { cols[bc].push_back({(int)(tab.size() / 2), off}); tab.push_back(bc * c.sz); tab.push_back(off); }
             }
             lbeg.push_back((int32_t)(tab.size() / 2));
         }
@@ -270,6 +382,15 @@ LayeredQcState *layered_qc_create(const ldpc_code &c, int variant, int dtype, in
         if (e == hipSuccess) e = hipMalloc((void **)&s->d_lbeg, sizeof(int32_t) * lbeg.size());
         if (e == hipSuccess) e = hipMalloc(&s->lam, (size_t)max_batch * c.N * es);
         if (e == hipSuccess) e = hipMalloc(&s->msg, (size_t)max_batch * std::max(c.E, 1) * es);
+        std::vector<int32_t> ctab, cbeg(1, 0);
+        for (auto &col : cols) {
+            for (auto it = col.rbegin(); it != col.rend(); ++it) { ctab.push_back(it->first); ctab.push_back(it->second); }   // descending block row
+            cbeg.push_back((int32_t)(ctab.size() / 2));
+        }
+        if (e == hipSuccess) e = hipMalloc((void **)&s->d_ctab, sizeof(int32_t) * std::max<size_t>(ctab.size(), 2));
+        if (e == hipSuccess) e = hipMalloc((void **)&s->d_cbeg, sizeof(int32_t) * cbeg.size());
+        if (e == hipSuccess && !ctab.empty()) e = hipMemcpy(s->d_ctab, ctab.data(), sizeof(int32_t) * ctab.size(), hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(s->d_cbeg, cbeg.data(), sizeof(int32_t) * cbeg.size(), hipMemcpyHostToDevice);
         if (e == hipSuccess && !tab.empty()) e = hipMemcpy(s->d_tab, tab.data(), sizeof(int32_t) * tab.size(), hipMemcpyHostToDevice);
         if (e == hipSuccess) e = hipMemcpy(s->d_lbeg, lbeg.data(), sizeof(int32_t) * lbeg.size(), hipMemcpyHostToDevice);
         if (e != hipSuccess) {
@@ -278,8 +399,8 @@ LayeredQcState *layered_qc_create(const ldpc_code &c, int variant, int dtype, in
             layered_qc_destroy(s);
             return nullptr;
         }
-        s->g.tab = s->d_tab; s->g.lbeg = s->d_lbeg;
-        snprintf(s->info.name, sizeof(s->info.name), "ldpc::layered_qc_kernel<%s, %d, %d>", dtype == LDPC_F64 ? "double" : "float",
+        s->g.tab = s->d_tab; s->g.lbeg = s->d_lbeg; s->g.ctab = s->d_ctab; s->g.cbeg = s->d_cbeg;
+        snprintf(s->info.name, sizeof(s->info.name), "ldpc::%s<%s, %d, %d>", flooding ? "flood_qc_kernel" : "layered_qc_kernel", dtype == LDPC_F64 ? "double" : "float",
                  variant == LDPC_MINSUM ? LDPC_V_MINSUM : LDPC_V_TANH, c.max_row_deg <= 8 ? 8 : (c.max_row_deg <= 20 ? 20 : 32));
         s->info.threads = s->threads; s->info.frames_per_wg = 1;
         return s;
@@ -293,7 +414,11 @@ template <typename CT, int VARIANT>
 static int launch(LayeredQcState &s, hipStream_t st, QcLayerArgs &a) {
     const dim3 grid(a.batch), block(s.threads);
     if (s.timer && !a.step_mode) s.timer->begin(st);
-    if (s.max_row_deg <= 8) hipLaunchKernelGGL((layered_qc_kernel<CT, VARIANT, 8>), grid, block, 0, st, s.g, (CT *)s.lam, (CT *)s.msg, a);
+    if (s.flooding) {
+        if (s.max_row_deg <= 8) hipLaunchKernelGGL((flood_qc_kernel<CT, VARIANT, 8>), grid, block, 0, st, s.g, (CT *)s.lam, (CT *)s.msg, a);
+        else if (s.max_row_deg <= 20) hipLaunchKernelGGL((flood_qc_kernel<CT, VARIANT, 20>), grid, block, 0, st, s.g, (CT *)s.lam, (CT *)s.msg, a);
+        else hipLaunchKernelGGL((flood_qc_kernel<CT, VARIANT, 32>), grid, block, 0, st, s.g, (CT *)s.lam, (CT *)s.msg, a);
+    } else if (s.max_row_deg <= 8) hipLaunchKernelGGL((layered_qc_kernel<CT, VARIANT, 8>), grid, block, 0, st, s.g, (CT *)s.lam, (CT *)s.msg, a);
     else if (s.max_row_deg <= 20) hipLaunchKernelGGL((layered_qc_kernel<CT, VARIANT, 20>), grid, block, 0, st, s.g, (CT *)s.lam, (CT *)s.msg, a);
     else hipLaunchKernelGGL((layered_qc_kernel<CT, VARIANT, 32>), grid, block, 0, st, s.g, (CT *)s.lam, (CT *)s.msg, a);
     if (s.timer && !a.step_mode) s.timer->end(st);

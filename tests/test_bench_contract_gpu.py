@@ -74,7 +74,11 @@ def test_early_exit_is_priced_by_the_iterations_run():
 def test_flood_path_reports_an_hbm_roofline():
     d = _run([sys.executable, "bench.py", "--steps", "2", "--warmup", "1", "--batch", "2048", "--cpu-seconds", "0", "--path", "flood"])
     r = d["roofline"]
-    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and "flood_cn" in r["kernel"] and 0 < r["frac"] <= 1.0 and d["proof_of_work"]["ok"]
+    # QC code: the frame-per-workgroup flooding kernel (one launch per batch); LDPC_FLOOD_QC=0 gives the batch-major pair
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and "flood_qc_kernel" in r["kernel"] and 0 < r["frac"] <= 1.0 and d["proof_of_work"]["ok"]
+    d2 = _run([sys.executable, "bench.py", "--steps", "2", "--warmup", "1", "--batch", "2048", "--cpu-seconds", "0", "--path", "flood"],
+              env={"LDPC_FLOOD_QC": "0"})
+    assert "flood_cn" in d2["roofline"]["kernel"] and 0 < d2["roofline"]["frac"] <= 1.0 and d2["proof_of_work"]["ok"]
 
 
 def test_rccl_collectives_run_with_one_rank():

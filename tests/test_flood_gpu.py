@@ -143,3 +143,29 @@ def test_minsum_degree_one_rejected(hip):
     bits, it, cv = hip.Decoder(code, "tanh", "f64", 1, path="flood").decode_one(np.array([1.0, -2.0, 3.0]), 3)
     o = oracle.decode(oracle.Graph.from_dense(np.array([[1, 0, 0], [1, 1, 1]], np.uint8)), "tanh", 3, np.array([1.0, -2.0, 3.0]))
     assert np.array_equal(bits, o["bits"]) and it == o["iters"]
+
+
+@pytest.mark.parametrize("name", ["jpl.1024.4.5", "jpl.4096.4.5"])
+def test_frame_major_and_batch_major_flood_kernels_agree(hip, name, monkeypatch):
+    """QC codes on the flood path run one workgroup per frame (layered_qc.hip flood_qc_kernel); LDPC_FLOOD_QC=0 keeps the
+    batch-major kernel pair (any H).  Same arithmetic, same orders: identical f32 results, f64 trajectories bit for bit."""
+    c = load(name)
+    F = 70 if name == "jpl.1024.4.5" else 20
+    _, llr = c.frames(F, 3.0, seed=321)
+    code = c.hip_code(hip)
+    for variant in ("min", "tanh"):
+        qc = hip.Decoder(code, variant, "f32", F, path="flood")
+        monkeypatch.setenv("LDPC_FLOOD_QC", "0")
+        bm = hip.Decoder(code, variant, "f32", F, path="flood")
+        bm64 = hip.Decoder(code, variant, "f64", 3, path="flood")
+        monkeypatch.delenv("LDPC_FLOOD_QC")
+        assert "flood_qc_kernel" in qc.kernel_name and "flood_cn" in bm.kernel_name
+        a, b = qc.decode_batch(llr.astype(np.float32), 40), bm.decode_batch(llr.astype(np.float32), 40)
+        assert all(np.array_equal(x, y) for x, y in zip(a, b)), (name, variant)
+        if variant == "min":
+            ta = hip.Decoder(code, variant, "f64", 3, path="flood").decode_trace(llr[:3], 20)
+            tb = bm64.decode_trace(llr[:3], 20)
+            assert all(np.array_equal(x, y) for x, y in zip(ta, tb))
+            for f in range(3):
+                o = oracle.decode(c.graph, "min", 20, llr[f], trace=True)
+                assert np.array_equal(ta[3][f, : o["iters"] + 1], o["trace_lam"])

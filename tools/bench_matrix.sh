@@ -10,6 +10,10 @@ run --steps 3 --warmup 1 --batch 16384 --variant tanh                 # tanh rul
 LDPC_HIP_PATH=flood run --steps 3 --warmup 1 --batch 16384 --variant tanh
 run --steps 6 --warmup 2 --code jpl.1024.4.5                          # configs[1]
 run --steps 3 --warmup 1 --batch 16384 --code jpl.1024.4.5 --variant tanh
+run --steps 3 --warmup 1 --batch 32768 --code dvbs2like.64800.1.2 --rate none --schedule layered --ebn0 2     # configs[4]: DVB-S2-shaped long code, layered
+run --steps 3 --warmup 1 --batch 8192 --code dvbs2like.64800.1.2 --rate none --ebn0 2                            # the same code, flooding (frame-per-workgroup HBM kernel)
+run --steps 3 --warmup 1 --batch 16384 --schedule layered --ebn0 3                                               # jpl.4096 layered (from HBM) in the waterfall
+run --steps 3 --warmup 1 --batch 65536 --ebn0 3                                                                  # jpl.4096 flooding (on-chip) at the same point
 for db in 1 2 3 4; do run --steps 3 --warmup 1 --code 1920.1280.3.303 --rate none --variant tanh --ebn0 $db; done   # configs[2], generic on-chip kernel
 LDPC_HIP_PATH=flood run --steps 3 --warmup 1 --code 1920.1280.3.303 --rate none --variant tanh --ebn0 1
 run --steps 3 --warmup 1 --code 1920.1280.3.303 --rate none --variant minsum --ebn0 1
@@ -17,5 +21,6 @@ python - <<'PY'
 import json
 for l in open('gpurun_out/bench_matrix.jsonl'):
     d = json.loads(l)
-    print(f"{d['config']['code_name']:48s} {d['config']['path']:5s} {d['dtype']} B={d['config']['batch_per_gpu']:6d} {d['value']:9.1f} Mbit/s  {d['ms_per_step']:8.2f} ms  rl {d['roofline']['frac']:.3f}  ber {d['ber']:.3e} fer {d['fer']:.3f} it {d['mean_iters']:.1f}")
+    r = d['roofline']
+    print(f"{d['config']['code_name']:52s} {d['config']['path']:5s} {d['dtype']} B={d['config']['batch_per_gpu']:6d} {d['value']:9.1f} Mbit/s  {d['ms_per_step']:8.2f} ms  {r['bound']} roofline {r['frac'] if r['frac'] is not None else float('nan'):.3f}  ber {d['ber']:.3e} fer {d['fer']:.3f} it {d['mean_iters']:.1f}  {r['kernel'][:40]}")
 PY

@@ -133,6 +133,81 @@ __device__ __forceinline__ void qc_row_padded(const QcLayerDev &g, CT *__restric
     }
 }
 
+// ---- min-sum with ROW RECORDS instead of per-edge messages (layered schedule) ---------------------------------------
+// The messages a min-sum check row sends take two magnitudes: 3/4 min1 everywhere, 3/4 min2 at the arg-min (the
+// reference's MinSum2 / `omit` semigroup, Utils.hs:133-144).  Kept in HBM as {c1, c2, meta = signs | idx << 27} -- 12
+// bytes per row (f32) instead of 4 per edge: on the DVB-S2-shaped code (weight-7 rows) a sweep moves 0.39 MB of
+// records instead of 1.81 MB of messages.  The rebuilt messages are the per-edge kernel's bit for bit (same
+// comparisons, first arg-min wins, the one rounding of Min.hs:78 applied once).  Rows up to weight 27.
+template <typename CT, int DMAX, bool FIRST>
+__device__ __forceinline__ void qc_row_rec(const QcLayerDev &g, CT *__restrict__ lam, CT *__restrict__ rc1, CT *__restrict__ rc2, uint32_t *__restrict__ rmeta,
+                                           int e0, int deg, int row, int r, bool live, bool &odd, bool &flip) {
+    int idx[DMAX];
+    CT l[DMAX], t[DMAX];
+#pragma unroll
+    for (int k = 0; k < DMAX; k++) {
+        const int kk = k < deg ? k : 0;
+        const int cb = ((cidx_t)g.tab)[2 * (e0 + kk)], rot = ((cidx_t)g.tab)[2 * (e0 + kk) + 1];
+        int c = r + rot;
+        c -= (c >= g.sz) ? g.sz : 0;
+        idx[k] = cb + c;
+    }
+#pragma unroll
+    for (int k = 0; k < DMAX; k++) l[k] = (live && k < deg) ? lam[idx[k]] : CT(0);
+    CT c1 = CT(0), c2 = CT(0);
+    uint32_t meta = 0;
+    if constexpr (!FIRST) {
+        if (live) { c1 = rc1[row]; c2 = rc2[row]; meta = rmeta[row]; }
+    }
+    bool par = false;
+#pragma unroll
+    for (int k = 0; k < DMAX; k++) par ^= (k < deg) && hard(l[k]);
+    odd |= par && live;
+    const uint32_t oidx = meta >> 27;
+#pragma unroll
+    for (int k = 0; k < DMAX; k++) {
+        CT old = CT(0);
+        if constexpr (!FIRST) { const CT mag = ((uint32_t)k == oidx) ? c2 : c1; old = ((meta >> k) & 1u) ? -mag : mag; }
+        t[k] = (k < deg) ? l[k] - old : CT(INFINITY);
+    }
+    // cn_minsum (ldpc_math.h) with its result captured as a record
+    CT m1 = fabs(t[0]), m2 = CT(INFINITY);
+    int i1 = 0;
+    unsigned parity = (t[0] > CT(0)) ? 1u : 0u;
+#pragma unroll
+    for (int k = 1; k < DMAX; k++) {
+        const CT a = fabs(t[k]);
+        parity ^= (k < deg && t[k] > CT(0)) ? 1u : 0u;
+        if (a < m1) { m2 = m1; m1 = a; i1 = k; }
+        else if (a < m2) { m2 = a; }
+    }
+    const CT n1 = CT(0.75) * m1, n2 = CT(0.75) * m2;      // |(-3/4) * acc|: the one rounding of Min.hs:78
+    uint32_t nsig = 0;
+#pragma unroll
+    for (int k = 0; k < DMAX; k++) {
+        if (k < deg) {
+            const unsigned neg = parity ^ ((t[k] > CT(0)) ? 1u : 0u);   // sign of prod_{j/=k} x_j ; message = (-3/4) * (neg ? -mag : mag)
+            const CT mag = (k == i1) ? n2 : n1;
+            const CT nm = neg ? mag : -mag;
+            nsig |= (neg ? 0u : 1u) << k;                               // sign bit of the message
+            const CT nw = t[k] + nm;
+            flip |= live && (hard(nw) != hard(l[k]));
+            if (live) lam[idx[k]] = nw;
+        }
+    }
+    if (live) { rc1[row] = n1; rc2[row] = n2; rmeta[row] = nsig | ((uint32_t)i1 << 27); }
+}
+
+template <typename CT, int DCLASS, bool FIRST>
+__device__ __forceinline__ void qc_layer_rec(const QcLayerDev &g, CT *lam, CT *rc1, CT *rc2, uint32_t *rmeta, int layer, int r, bool live, bool &odd, bool &flip) {
+    const int e0 = ((cidx_t)g.lbeg)[layer], deg = ((cidx_t)g.lbeg)[layer + 1] - e0;
+    const int row = layer * g.sz + r;
+    if (deg <= 0) return;
+    if (deg <= 8) { qc_row_rec<CT, 8, FIRST>(g, lam, rc1, rc2, rmeta, e0, deg, row, r, live, odd, flip); return; }
+    if constexpr (DCLASS >= 20) { if (deg <= 20) { qc_row_rec<CT, 20, FIRST>(g, lam, rc1, rc2, rmeta, e0, deg, row, r, live, odd, flip); return; } }
+    if constexpr (DCLASS >= 32) { qc_row_rec<CT, 27, FIRST>(g, lam, rc1, rc2, rmeta, e0, deg, row, r, live, odd, flip); }
+}
+
 template <typename CT, int VARIANT, int DCLASS, int MODE>
 __device__ __forceinline__ void qc_layer(const QcLayerDev &g, CT *lam, CT *msg, int layer, int r, bool live, bool &odd, bool &flip) {
     const int e0 = ((cidx_t)g.lbeg)[layer], deg = ((cidx_t)g.lbeg)[layer + 1] - e0;
@@ -164,13 +239,17 @@ __device__ __forceinline__ void qc_layer(const QcLayerDev &g, CT *lam, CT *msg, 
 }
 
 // block = ceil(sz / 64) waves; thread r = row r of every circulant (threads >= sz idle); grid = frames
-template <typename CT, int VARIANT, int DCLASS>
+// RECORDS: min-sum rows kept as records (qc_row_rec) -- msg_all then holds [frame][3][M] words instead of [frame][E] messages
+template <typename CT, int VARIANT, int DCLASS, bool RECORDS>
 __global__ __launch_bounds__(1024) void layered_qc_kernel(QcLayerDev g, CT *lam_all, CT *msg_all, QcLayerArgs A) {
     const int r = threadIdx.x;
     const bool live = r < g.sz;
     const size_t frame = blockIdx.x;
     CT *lam = lam_all + frame * (size_t)g.N;
-    CT *msg = msg_all + frame * (size_t)g.E;
+    const int Mrows = g.nbr * g.sz;
+    CT *msg = msg_all + frame * (RECORDS ? (size_t)3 * Mrows : (size_t)g.E);
+    CT *rc1 = msg, *rc2 = msg + Mrows;
+    uint32_t *rmeta = reinterpret_cast<uint32_t *>(msg + 2 * (size_t)Mrows);   // (f64: the upper half of each cell is unused)
     const size_t fN = frame * (size_t)g.N;
     // ---- lam <- channel LLRs (or the given state)
     if (A.step_mode) {
@@ -198,7 +277,10 @@ __global__ __launch_bounds__(1024) void layered_qc_kernel(QcLayerDev g, CT *lam_
     if (!conv) {
         for (n = 1; n <= A.max_iters; n++) {
             bool odd = false, flip = false;
-            if (n == 1 && !A.step_mode) {
+            if constexpr (RECORDS) {
+                if (n == 1) { for (int l = 0; l < g.nbr; l++) { qc_layer_rec<CT, DCLASS, true>(g, lam, rc1, rc2, rmeta, l, r, live, odd, flip); __syncthreads(); } }
+                else { for (int l = 0; l < g.nbr; l++) { qc_layer_rec<CT, DCLASS, false>(g, lam, rc1, rc2, rmeta, l, r, live, odd, flip); __syncthreads(); } }
+            } else if (n == 1 && !A.step_mode) {
                 for (int l = 0; l < g.nbr; l++) { qc_layer<CT, VARIANT, DCLASS, 1>(g, lam, msg, l, r, live, odd, flip); __syncthreads(); }
             } else {
                 for (int l = 0; l < g.nbr; l++) { qc_layer<CT, VARIANT, DCLASS, 0>(g, lam, msg, l, r, live, odd, flip); __syncthreads(); }
@@ -330,6 +412,7 @@ struct LayeredQcState {
     int variant = 0, dtype = 0, max_batch = 0, max_row_deg = 0, threads = 0;
     QcLayerDev g{};
     bool flooding = false;
+    bool records = false;     // layered min-sum: row records instead of per-edge messages (LDPC_LAYERED_RECORDS=0: per edge, A/B)
     int32_t *d_tab = nullptr;
     int32_t *d_lbeg = nullptr, *d_ctab = nullptr, *d_cbeg = nullptr;
     void *lam = nullptr, *msg = nullptr;
@@ -381,7 +464,12 @@ LayeredQcState *layered_qc_create(const ldpc_code &c, int variant, int dtype, in
         hipError_t e = hipMalloc((void **)&s->d_tab, sizeof(int32_t) * std::max<size_t>(tab.size(), 2));
         if (e == hipSuccess) e = hipMalloc((void **)&s->d_lbeg, sizeof(int32_t) * lbeg.size());
         if (e == hipSuccess) e = hipMalloc(&s->lam, (size_t)max_batch * c.N * es);
-        if (e == hipSuccess) e = hipMalloc(&s->msg, (size_t)max_batch * std::max(c.E, 1) * es);
+        {
+            const char *re = getenv("LDPC_LAYERED_RECORDS");
+            s->records = !flooding && variant == LDPC_MINSUM && c.max_row_deg <= 27 && !(re && !strcmp(re, "0"));
+        }
+        // (sized for the per-edge form either way: the teacher-forced step always runs it)
+        if (e == hipSuccess) e = hipMalloc(&s->msg, (size_t)max_batch * std::max(std::max(c.E, 3 * c.M), 1) * es);
         std::vector<int32_t> ctab, cbeg(1, 0);
         for (auto &col : cols) {
             for (auto it = col.rbegin(); it != col.rend(); ++it) { ctab.push_back(it->first); ctab.push_back(it->second); }   // descending block row
@@ -400,8 +488,9 @@ LayeredQcState *layered_qc_create(const ldpc_code &c, int variant, int dtype, in
             return nullptr;
         }
         s->g.tab = s->d_tab; s->g.lbeg = s->d_lbeg; s->g.ctab = s->d_ctab; s->g.cbeg = s->d_cbeg;
-        snprintf(s->info.name, sizeof(s->info.name), "ldpc::%s<%s, %d, %d>", flooding ? "flood_qc_kernel" : "layered_qc_kernel", dtype == LDPC_F64 ? "double" : "float",
-                 variant == LDPC_MINSUM ? LDPC_V_MINSUM : LDPC_V_TANH, c.max_row_deg <= 8 ? 8 : (c.max_row_deg <= 20 ? 20 : 32));
+        snprintf(s->info.name, sizeof(s->info.name), "ldpc::%s<%s, %d, %d%s>", flooding ? "flood_qc_kernel" : "layered_qc_kernel", dtype == LDPC_F64 ? "double" : "float",
+                 variant == LDPC_MINSUM ? LDPC_V_MINSUM : LDPC_V_TANH, c.max_row_deg <= 8 ? 8 : (c.max_row_deg <= 20 ? 20 : 32),
+                 flooding ? "" : (s->records ? ", true" : ", false"));
         s->info.threads = s->threads; s->info.frames_per_wg = 1;
         return s;
     } catch (...) { layered_qc_destroy(s); set_error(LDPC_ENOMEM, "out of host memory"); return nullptr; }
@@ -418,9 +507,15 @@ static int launch(LayeredQcState &s, hipStream_t st, QcLayerArgs &a) {
         if (s.max_row_deg <= 8) hipLaunchKernelGGL((flood_qc_kernel<CT, VARIANT, 8>), grid, block, 0, st, s.g, (CT *)s.lam, (CT *)s.msg, a);
         else if (s.max_row_deg <= 20) hipLaunchKernelGGL((flood_qc_kernel<CT, VARIANT, 20>), grid, block, 0, st, s.g, (CT *)s.lam, (CT *)s.msg, a);
         else hipLaunchKernelGGL((flood_qc_kernel<CT, VARIANT, 32>), grid, block, 0, st, s.g, (CT *)s.lam, (CT *)s.msg, a);
-    } else if (s.max_row_deg <= 8) hipLaunchKernelGGL((layered_qc_kernel<CT, VARIANT, 8>), grid, block, 0, st, s.g, (CT *)s.lam, (CT *)s.msg, a);
-    else if (s.max_row_deg <= 20) hipLaunchKernelGGL((layered_qc_kernel<CT, VARIANT, 20>), grid, block, 0, st, s.g, (CT *)s.lam, (CT *)s.msg, a);
-    else hipLaunchKernelGGL((layered_qc_kernel<CT, VARIANT, 32>), grid, block, 0, st, s.g, (CT *)s.lam, (CT *)s.msg, a);
+    } else if (VARIANT == LDPC_V_MINSUM && s.records && !a.step_mode) {
+        if constexpr (VARIANT == LDPC_V_MINSUM) {
+            if (s.max_row_deg <= 8) hipLaunchKernelGGL((layered_qc_kernel<CT, VARIANT, 8, true>), grid, block, 0, st, s.g, (CT *)s.lam, (CT *)s.msg, a);
+            else if (s.max_row_deg <= 20) hipLaunchKernelGGL((layered_qc_kernel<CT, VARIANT, 20, true>), grid, block, 0, st, s.g, (CT *)s.lam, (CT *)s.msg, a);
+            else hipLaunchKernelGGL((layered_qc_kernel<CT, VARIANT, 32, true>), grid, block, 0, st, s.g, (CT *)s.lam, (CT *)s.msg, a);
+        }
+    } else if (s.max_row_deg <= 8) hipLaunchKernelGGL((layered_qc_kernel<CT, VARIANT, 8, false>), grid, block, 0, st, s.g, (CT *)s.lam, (CT *)s.msg, a);
+    else if (s.max_row_deg <= 20) hipLaunchKernelGGL((layered_qc_kernel<CT, VARIANT, 20, false>), grid, block, 0, st, s.g, (CT *)s.lam, (CT *)s.msg, a);
+    else hipLaunchKernelGGL((layered_qc_kernel<CT, VARIANT, 32, false>), grid, block, 0, st, s.g, (CT *)s.lam, (CT *)s.msg, a);
     if (s.timer && !a.step_mode) s.timer->end(st);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return set_error(LDPC_EHIP, "layered_qc launch: %s", hipGetErrorString(e));

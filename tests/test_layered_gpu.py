@@ -176,3 +176,29 @@ def test_dvbs2_shaped_long_code(hip):
     ob, oi, oc = oracle.decode_batch(g, "min", 50, llr, nthreads=6)
     assert np.array_equal(fb, ob) and np.array_equal(fc, oc)
     print(f"dvbs2like 1.6 dB: layered {its.tolist()} sweeps, flooding {fi.tolist()} turns")
+
+
+@pytest.mark.parametrize("name", ["jpl.4096.4.5", "ira-12x24-sz64", "regular36-sz128"])
+def test_row_records_equal_per_edge_messages(hip, name, monkeypatch):
+    """layered min-sum on QC codes keeps a check row's messages in HBM as a record {3/4 min1, 3/4 min2, signs | arg-min}
+    (12 bytes per row) instead of one word per edge; the rebuilt messages must be the per-edge kernel's bit for bit:
+    identical f32 results and f64 trajectories, and the oracle's trajectory in f64."""
+    c = _get(name)
+    lp = _layers(c)
+    F = 20 if c.N > 4000 else 48
+    _, llr = c.frames(F, 3.0 if name != "ira-12x24-sz64" else 2.0, seed=555)
+    code = c.hip_code(hip)
+    rec = hip.Decoder(code, "min", "f32", F, schedule="layered")
+    rec64 = hip.Decoder(code, "min", "f64", 4, schedule="layered")
+    monkeypatch.setenv("LDPC_LAYERED_RECORDS", "0")
+    edge = hip.Decoder(code, "min", "f32", F, schedule="layered")
+    edge64 = hip.Decoder(code, "min", "f64", 4, schedule="layered")
+    monkeypatch.delenv("LDPC_LAYERED_RECORDS")
+    assert rec.kernel_name.endswith(", true>") and edge.kernel_name.endswith(", false>")
+    a, b = rec.decode_batch(llr.astype(np.float32), 40), edge.decode_batch(llr.astype(np.float32), 40)
+    assert all(np.array_equal(x, y) for x, y in zip(a, b)) and len(set(a[1].tolist())) > 2
+    ta, tb = rec64.decode_trace(llr[:4], 25), edge64.decode_trace(llr[:4], 25)
+    assert all(np.array_equal(x, y) for x, y in zip(ta, tb))
+    for f in range(4):
+        o = oracle.decode_layered(c.graph, lp, "min", 25, llr[f], trace=True)
+        assert ta[1][f] == o["iters"] and np.array_equal(ta[3][f, : o["iters"] + 1], o["trace_lam"])

@@ -222,25 +222,34 @@ def proof_of_work_layered(args, E, ecc, dec, sim, llr_t, msg_t, bits, iters_t, c
     return out
 
 
-PROFILE_TAGS = {   # committed rocprofv3 PMC passes of these workloads at 65 536 frames per launch (tools/profile.sh)
-    ("jpl.4096.4.5", "minsum", "f32"): "jpl4096_f32_minsum", ("jpl.1024.4.5", "minsum", "f32"): "jpl1024_f32_minsum",
-    ("jpl.4096.4.5", "tanh", "f32"): "jpl4096_f32_tanh", ("1920.1280.3.303", "tanh", "f32"): "mackay_f32_tanh"}
+PROFILE_TAGS = {   # committed rocprofv3 PMC passes (tools/profile.sh): (code, variant, dtype, kernel family) -> (tag, frames per launch profiled)
+    ("jpl.4096.4.5", "minsum", "f32", "fused"): ("jpl4096_f32_minsum", 65536), ("jpl.1024.4.5", "minsum", "f32", "fused"): ("jpl1024_f32_minsum", 65536),
+    ("jpl.4096.4.5", "tanh", "f32", "fused"): ("jpl4096_f32_tanh", 16384), ("1920.1280.3.303", "tanh", "f32", "fused"): ("mackay_f32_tanh", 65536),
+    ("jpl.4096.4.5", "minsum", "f32", "flood_qc"): ("floodqc_jpl4096_f32_minsum", 16384),
+    ("dvbs2like.64800.1.2", "minsum", "f32", "layered_qc"): ("dvbs2like_layered_f32_minsum", 8192)}
 
 
 def committed_traffic(args, dec, B):
     """HBM bytes per launch of the dominant kernel from a COMMITTED rocprofv3 PMC pass (profiles/*_pmc.json:
     FETCH_SIZE and WRITE_SIZE collected in separate --pmc runs of this same command, FETCH_SIZE doubled as the
     gfx950 guide prescribes), scaled by frames per launch -> (bytes, source file) or (None, None).  Counters cannot be
-    read from inside the process; this value is therefore NOT measured in this run and says which file it is from."""
-    tag = PROFILE_TAGS.get((args.code, args.variant, args.dtype))
-    if dec.path != "fused" or tag is None:
+    read from inside the process; this value is therefore NOT measured in this run and says which file it is from.
+    (For a kernel with early exit the scaling by frames assumes the profiled Eb/N0.)"""
+    kname = dec.kernel_name
+    family = "fused" if dec.path == "fused" else ("flood_qc" if "flood_qc_kernel" in kname else ("layered_qc" if "layered_qc_kernel" in kname else None))
+    ent = PROFILE_TAGS.get((args.code, args.variant, args.dtype, family))
+    if ent is None:
         return None, None
+    tag, frames = ent
     for rnd in ("r02_final_", "r01_final_"):
         path = os.path.join(ROOT, "profiles", rnd + tag + "_pmc.json")
         try:
-            h = json.load(open(path))["hbm_bytes_per_launch"]
+            prof = json.load(open(path))
+            if family != "fused" and family.replace("_qc", "_qc_kernel") not in prof["kernel"]:
+                continue
+            h = prof["hbm_bytes_per_launch"]
             fetch = h.get("FETCH_SIZE_corrected_bytes", 2 * h["FETCH_SIZE_raw_bytes"])
-            return int((fetch + h["WRITE_SIZE_bytes"]) * B / 65536), os.path.relpath(path, ROOT)
+            return int((fetch + h["WRITE_SIZE_bytes"]) * B / frames), os.path.relpath(path, ROOT)
         except Exception:
             continue
     return None, None
@@ -300,18 +309,25 @@ def rooflines(args, dec, B, Eg, N, n_tx, k, s_bytes, launches, kernel_ms, turns_
     if dec.path != "fused" and dec.schedule == "layered":
         # layered schedule from HBM: ONE launch is the whole decode of the batch; per sweep every edge reads and writes its
         # lam cell and its message (4E*s), plus the syndrome pass before the first sweep (E*s); priced with the sweeps run
-        bytes_timed = turns_timed * 4 * Eg * s_bytes + frames_timed * Eg * s_bytes
+        records = dec.kernel_name.endswith(", true>")   # min-sum rows as {c1, c2, meta} records: 2*s + 4 bytes per ROW instead of s per edge
+        per_sweep = 2 * Eg * s_bytes + (2 * dec.code.M * (2 * s_bytes + 4) if records else 2 * Eg * s_bytes)
+        bytes_timed = turns_timed * per_sweep + frames_timed * Eg * s_bytes
         ach = bytes_timed / (kernel_ms * 1e-3) / 1e9 if kernel_ms else 0.0
         r = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
-             "traffic": None, "kernel": dec.kernel_name, "launches": launches, "avg_launch_ms": round(avg_ms, 4),
-             "algorithmic_bytes_timed": bytes_timed, "frame_sweeps_timed": turns_timed,
-             "bytes_model": "sum_frames(sweeps_f)*4E*s + frames*E*s (one persistent launch decodes the batch; lam and messages live in HBM)"}
+             "traffic": traffic, "traffic_source": tsrc and f"{tsrc} (committed PMC pass, not measured in this run)",
+             "kernel": dec.kernel_name, "launches": launches, "avg_launch_ms": round(avg_ms, 4),
+             "algorithmic_bytes_timed": bytes_timed, "algorithmic_bytes_per_launch": bytes_timed // steps, "frame_sweeps_timed": turns_timed,
+             "bytes_model": ("sum_frames(sweeps_f)*(2E*s + 2M*(2s+4)) + frames*E*s: lam cells read+written per edge, one record per row read+written"
+                             if records else "sum_frames(sweeps_f)*4E*s + frames*E*s: lam cells and messages read+written per edge") +
+                            " (one launch decodes the batch; state in HBM)"}
         return r, None
     if dec.path != "fused" and "flood_qc_kernel" in dec.kernel_name:
         # flooding from HBM, one workgroup per frame, ONE launch per batch: the contract's byte model is exactly this
         # kernel's algorithmic traffic -- (3E+3N)*s per frame and turn run, the LLRs in, the bits out
         r = dict(hbm)
-        r.update({"traffic": None, "kernel": dec.kernel_name, "launches": launches, "avg_launch_ms": round(avg_ms, 4), "frame_turns_timed": turns_timed})
+        r.update({"traffic": traffic, "traffic_source": tsrc and f"{tsrc} (committed PMC pass, not measured in this run)", "kernel": dec.kernel_name,
+                  "launches": launches, "avg_launch_ms": round(avg_ms, 4), "frame_turns_timed": turns_timed,
+                  "algorithmic_bytes_per_launch": model_bytes // steps})
         return r, None
     if dec.path != "fused":
         # flood path: state in HBM, two kernels per turn; the timed kernel is the check-node kernel and every launch of

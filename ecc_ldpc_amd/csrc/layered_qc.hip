@@ -240,8 +240,16 @@ __device__ __forceinline__ void qc_layer(const QcLayerDev &g, CT *lam, CT *msg, 
 
 // block = ceil(sz / 64) waves; thread r = row r of every circulant (threads >= sz idle); grid = frames
 // RECORDS: min-sum rows kept as records (qc_row_rec) -- msg_all then holds [frame][3][M] words instead of [frame][E] messages
+// Waves per SIMD asked of the register allocator for light rows (weight <= 8, f32).  A workgroup of w waves takes
+// ceil(w/4) wave slots on the fuller SIMDs, so DVB-S2's 6-wave frames need 2: with the 86 VGPRs / 104 SGPRs the compiler
+// takes when left alone only 2 frames were resident per CU (12.6 waves measured); held to 64 / 80 (SGPRs spill to VGPR
+// lanes, no scratch) 3 (17.4 waves): 82.5 -> 67.5 ms for 8 192 frames of the long code (tools/microbench_residency.hip has
+// the placement rule: 384-thread blocks reach 4.5 per CU at best).
+#ifndef LQC_WAVES_LIGHT
+#define LQC_WAVES_LIGHT 8
+#endif
 template <typename CT, int VARIANT, int DCLASS, bool RECORDS>
-__global__ __launch_bounds__(1024) void layered_qc_kernel(QcLayerDev g, CT *lam_all, CT *msg_all, QcLayerArgs A) {
+__global__ __launch_bounds__(1024, (DCLASS <= 8 && sizeof(CT) == 4 ? LQC_WAVES_LIGHT : 4)) void layered_qc_kernel(QcLayerDev g, CT *lam_all, CT *msg_all, QcLayerArgs A) {
     const int r = threadIdx.x;
     const bool live = r < g.sz;
     const size_t frame = blockIdx.x;
@@ -344,7 +352,7 @@ __device__ __forceinline__ CT qc_column(const QcLayerDev &g, const CT *__restric
 }
 
 template <typename CT, int VARIANT, int DCLASS>
-__global__ __launch_bounds__(1024) void flood_qc_kernel(QcLayerDev g, CT *lam_all, CT *msg_all, QcLayerArgs A) {
+__global__ __launch_bounds__(1024, (DCLASS <= 8 && sizeof(CT) == 4 ? LQC_WAVES_LIGHT : 4)) void flood_qc_kernel(QcLayerDev g, CT *lam_all, CT *msg_all, QcLayerArgs A) {
     const int r = threadIdx.x;
     const bool live = r < g.sz;
     const size_t frame = blockIdx.x;

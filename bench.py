@@ -226,7 +226,7 @@ PROFILE_TAGS = {   # committed rocprofv3 PMC passes (tools/profile.sh): (code, v
     ("jpl.4096.4.5", "minsum", "f32", "fused"): ("jpl4096_f32_minsum", 65536), ("jpl.1024.4.5", "minsum", "f32", "fused"): ("jpl1024_f32_minsum", 65536),
     ("jpl.4096.4.5", "tanh", "f32", "fused"): ("jpl4096_f32_tanh", 16384), ("1920.1280.3.303", "tanh", "f32", "fused"): ("mackay_f32_tanh", 65536),
     ("jpl.4096.4.5", "minsum", "f32", "flood_qc"): ("floodqc_jpl4096_f32_minsum", 16384),
-    ("dvbs2like.64800.1.2", "minsum", "f32", "layered_qc"): ("dvbs2like_layered_f32_minsum", 8192)}
+    ("dvbs2like.64800.1.2", "minsum", "f32", "layered_qc"): ("dvbs2like_layered_f32_minsum", 32768)}
 
 
 def committed_traffic(args, dec, B):

@@ -351,8 +351,9 @@ __device__ __forceinline__ CT qc_column(const QcLayerDev &g, const CT *__restric
     return acc;
 }
 
+// (no register budget here: held to 64 VGPRs / 80 SGPRs the flooding kernel lost 12 % on the long code: 1 663 -> 1 465 Mbit/s)
 template <typename CT, int VARIANT, int DCLASS>
-__global__ __launch_bounds__(1024, (DCLASS <= 8 && sizeof(CT) == 4 ? LQC_WAVES_LIGHT : 4)) void flood_qc_kernel(QcLayerDev g, CT *lam_all, CT *msg_all, QcLayerArgs A) {
+__global__ __launch_bounds__(1024) void flood_qc_kernel(QcLayerDev g, CT *lam_all, CT *msg_all, QcLayerArgs A) {
     const int r = threadIdx.x;
     const bool live = r < g.sz;
     const size_t frame = blockIdx.x;

@@ -81,6 +81,24 @@ __device__ __forceinline__ uint32_t bfi(uint32_t mask, uint32_t a, uint32_t b) {
     return r;
 }
 
+// Geometry of one wave group of the per-edge-message QC kernels.  SZ = circulant size; a block column holds V positions
+// in LDS; VT threads serve it.  Power-of-two SZ below 64: CPW = 64/SZ frames interleaved lane by lane fill a wave
+// (V = VT = 64).  Any other SZ: one frame, V = SZ positions, VT = SZ rounded up to whole waves (the top lanes idle).
+template <int SZ>
+struct QcGeom {
+    static constexpr bool POW2 = (SZ & (SZ - 1)) == 0;
+    static constexpr int CPW = (POW2 && SZ < 64) ? 64 / SZ : 1;
+    static constexpr int V = SZ * CPW;
+    static constexpr int VT = (V + 63) / 64 * 64;
+};
+// position wrap inside a block column: a < 2 * (vmask + 1) bytes.  vmask + 1 = V * sizeof(CT); a power of two wraps with
+// an AND, anything else with the unsigned-min trick (a - vb wraps to a huge value when a < vb).  vmask is a compile-time
+// constant at every call site, so the test folds.
+__device__ __forceinline__ uint32_t qc_wrap(uint32_t a, uint32_t vmask) {
+    const uint32_t vb = vmask + 1u;
+    return (vb & vmask) == 0u ? (a & vmask) : (a < a - vb ? a : a - vb);
+}
+
 template <typename CT> struct Bits;
 template <> struct Bits<float> { using U = uint32_t; };
 template <> struct Bits<double> { using U = uint64_t; };

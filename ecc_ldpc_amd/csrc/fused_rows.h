@@ -19,7 +19,7 @@ struct DynRow {
 };
 template <typename CT, int SZ, class T, int EBEG>
 struct StatRow {
-    static constexpr uint32_t CPW = SZ >= 64 ? 1 : 64 / SZ, V = SZ * CPW, ES = sizeof(CT);
+    static constexpr uint32_t CPW = QcGeom<SZ>::CPW, V = QcGeom<SZ>::V, ES = sizeof(CT);
     __device__ __forceinline__ constexpr uint32_t lo(int k) const { return T::rot[EBEG + k] * CPW * ES; }
     __device__ __forceinline__ constexpr uint32_t hi(int k) const { return T::bc[EBEG + k] * V * ES; }
 };
@@ -114,7 +114,7 @@ template <int RPL, int HSTEP>
 __device__ __forceinline__ uint32_t row_addr(uint32_t a0, uint32_t p4, uint32_t lo, uint32_t vmask, int h) {
     if (h == 0) return a0;
     if (RPL == 2) return a0 ^ (uint32_t)HSTEP;
-    return ((p4 + HSTEP * h) + lo) & vmask;
+    return qc_wrap((p4 + HSTEP * h) + lo, vmask);
 }
 
 // phase A for the RPL rows a lane owns in one block row of degree D.  msg: [RPL][D] registers.
@@ -126,7 +126,7 @@ __device__ __forceinline__ bool rows_a(const char *lds, Row tabrow, uint32_t p4,
     static_for<0, D>([&](auto kc) {
         constexpr int k = decltype(kc)::value;
         const uint32_t lo = tabrow.lo(k), hi = tabrow.hi(k);
-        uint32_t a0 = (p4 + lo) & vmask;   // position inside the block column; `hi` (its base) is added below
+        uint32_t a0 = qc_wrap(p4 + lo, vmask);   // position inside the block column; `hi` (its base) is added below
 #pragma unroll
         for (int h = 0; h < RPL; h++) l[h][k] = lds_ld<CT>(lds + hi, row_addr<RPL, HSTEP>(a0, p4, lo, vmask, h));
     });
@@ -190,7 +190,7 @@ __device__ __forceinline__ void rows_b(char *lds, Row tabrow, uint32_t p4, uint3
     static_for<0, D>([&](auto kc) {
         constexpr int k = decltype(kc)::value;
         const uint32_t lo = tabrow.lo(k), hi = tabrow.hi(k);
-        adr[k] = (p4 + lo) & vmask;
+        adr[k] = qc_wrap(p4 + lo, vmask);
 #pragma unroll
         for (int h = 0; h < RPL; h++) cur[h][k] = lds_ld<CT>(lds + hi, row_addr<RPL, HSTEP>(adr[k], p4, lo, vmask, h));
     });

@@ -109,7 +109,7 @@ struct Split {
 template <typename CT, int SZ, class Plan, class T, int P, int Q, int I0, int I1>
 __device__ __forceinline__ void split_round_chunk(char *lds, uint32_t p4, uint32_t vmask, const CT *msg, const CT *orig_rot, const float *gllr, uint32_t r0) {
     using S = Split<Plan, T>;
-    constexpr uint32_t ES = sizeof(CT), CPW = SZ >= 64 ? 1 : 64 / SZ, V = SZ * CPW;
+    constexpr uint32_t ES = sizeof(CT), CPW = QcGeom<SZ>::CPW, V = QcGeom<SZ>::V;
     asm volatile("" : "+v"(p4));
     if constexpr (Q == 0) {
         static_for<I0, I1>([&](auto ic) {
@@ -118,8 +118,8 @@ __device__ __forceinline__ void split_round_chunk(char *lds, uint32_t p4, uint32
             constexpr int e = S::nth(Q, P, decltype(ic)::value);
             constexpr int ms = S::slot(e), os = S::oslot(T::bc[e]);
             CT o;
-            if constexpr (SPLIT_ORIG_REGS) o = orig_rot[os]; else o = (CT)gllr[T::bc[e] * SZ + ((r0 + T::rot[e]) & (SZ - 1))];
-            lds_st<CT>(lds + T::bc[e] * V * ES, (p4 + T::rot[e] * CPW * ES) & vmask, msg[ms] + o);
+            if constexpr (SPLIT_ORIG_REGS) o = orig_rot[os]; else o = (CT)gllr[T::bc[e] * SZ + ((r0 + T::rot[e]) % SZ)];
+            lds_st<CT>(lds + T::bc[e] * V * ES, qc_wrap(p4 + T::rot[e] * CPW * ES, vmask), msg[ms] + o);
         });
         return;
     }
@@ -128,7 +128,7 @@ __device__ __forceinline__ void split_round_chunk(char *lds, uint32_t p4, uint32
     static_for<I0, I1>([&](auto ic) {
         constexpr int i = decltype(ic)::value;
         constexpr int e = S::nth(Q, P, i);
-        adr[i - I0] = (p4 + T::rot[e] * CPW * ES) & vmask;
+        adr[i - I0] = qc_wrap(p4 + T::rot[e] * CPW * ES, vmask);
         cur[i - I0] = lds_ld<CT>(lds + T::bc[e] * V * ES, adr[i - I0]);
     });
     static_for<I0, I1>([&](auto ic) {
@@ -156,14 +156,15 @@ __device__ __forceinline__ void split_round(char *lds, uint32_t p4, uint32_t vma
 template <typename CT, int VARIANT, class Plan, int SZ, class T, int P>
 __device__ __forceinline__ void split_body(const FusedArgs &A, char *lds, const uint32_t tid) {
     using S = Split<Plan, T>;
-    constexpr int CPW = SZ >= 64 ? 1 : 64 / SZ, V = SZ * CPW;  // frames per workgroup, threads per pair
-    constexpr int N = Plan::NBC * SZ, THREADS = Plan::NP * V, NW = THREADS / 64;
+    constexpr int CPW = QcGeom<SZ>::CPW, V = QcGeom<SZ>::V, VT = QcGeom<SZ>::VT;  // frames per workgroup, positions per block column, threads per group
+    constexpr int N = Plan::NBC * SZ, THREADS = Plan::NP * VT, NW = THREADS / 64;
     constexpr uint32_t ES = sizeof(CT), vmask = V * ES - 1;
-    constexpr int LAM_BYTES = Plan::NBC * V * (int)ES;
+    constexpr int LAM_BYTES = (Plan::NBC * V * (int)ES + 15) / 16 * 16;
     // Only p4 (the lane's LDS byte offset inside a block column) lives across the iteration loop; everything else
     // about the lane's place -- frame, row, global offsets -- is recomputed from it where needed (Where), so that
     // it does not occupy registers next to the messages.
-    const uint32_t p4 = (tid & (V - 1)) * ES;
+    if constexpr (VT != V) { if ((tid % VT) >= (uint32_t)V) return; }   // circulant size not a multiple of 64: the top lanes of the group idle
+    const uint32_t p4 = (tid % VT) * ES;
     struct Where {
         uint32_t sub, r0; long long frame; bool valid; size_t fN, fE;
         __device__ __forceinline__ Where(uint32_t p, int batch) {
@@ -201,7 +202,7 @@ __device__ __forceinline__ void split_body(const FusedArgs &A, char *lds, const 
                 CT v = maybe_round_f16<CT>(load_llr_as<CT, FMT>(A.llr, fN + bc * SZ + r0), A.llr_round16);
                 obits.set(bc / Plan::NP, v > CT(0));
                 if (A.step_mode) v = (CT)A.st_lam[fN + bc * SZ + r0];
-                lds_st<CT>(lds, p4 | (bc * V * ES), v);
+                lds_st<CT>(lds, p4 + (bc * V * ES), v);
             }
         });
         if (A.step_mode) {   // teacher-forced step: LDS holds the given lam, the channel LLRs come from memory
@@ -210,7 +211,7 @@ __device__ __forceinline__ void split_body(const FusedArgs &A, char *lds, const 
                 if constexpr (SPLIT_ORIG_REGS && S::oowner(bc) == P) {
                     constexpr int e0 = Rounds<T>::round0_edge(bc);
                     constexpr int os = S::oslot(bc);
-                    orig[os] = maybe_round_f16<CT>(load_llr_as<CT, FMT>(A.llr, fN + bc * SZ + ((r0 + T::rot[e0]) & (SZ - 1))), A.llr_round16);
+                    orig[os] = maybe_round_f16<CT>(load_llr_as<CT, FMT>(A.llr, fN + bc * SZ + ((r0 + T::rot[e0]) % SZ)), A.llr_round16);
                 }
             });
         }
@@ -235,7 +236,7 @@ __device__ __forceinline__ void split_body(const FusedArgs &A, char *lds, const 
             if constexpr (SPLIT_ORIG_REGS && S::oowner(bc) == P) {
                 constexpr int e0 = Rounds<T>::round0_edge(bc);
                 constexpr int os = S::oslot(bc);
-                orig[os] = lds_ld<CT>(lds + bc * V * ES, (p4 + T::rot[e0] * CPW * ES) & vmask);
+                orig[os] = lds_ld<CT>(lds + bc * V * ES, qc_wrap(p4 + T::rot[e0] * CPW * ES, vmask));
             }
         });
     }
@@ -264,7 +265,7 @@ __device__ __forceinline__ void split_body(const FusedArgs &A, char *lds, const 
             static_for<0, Plan::NBC>([&](auto bcc) {
                 constexpr int bc = decltype(bcc)::value;
                 if constexpr ((bc % Plan::NP) == P)
-                    A.trace[((size_t)w.frame * (A.max_iters + 1) + n) * N + bc * SZ + w.r0] = (double)lds_ld<CT>(lds, p4 | (bc * V * ES));
+                    A.trace[((size_t)w.frame * (A.max_iters + 1) + n) * N + bc * SZ + w.r0] = (double)lds_ld<CT>(lds, p4 + (bc * V * ES));
             });
         }
         const bool last = (n >= turns);
@@ -305,7 +306,7 @@ __device__ __forceinline__ void split_body(const FusedArgs &A, char *lds, const 
                 static_for<0, Plan::NBC>([&](auto bcc) {
                     constexpr int bc = decltype(bcc)::value;
                     if constexpr ((bc % Plan::NP) == P) {
-                        CT v = lds_ld<CT>(lds, p4 | (bc * V * ES));
+                        CT v = lds_ld<CT>(lds, p4 + (bc * V * ES));
                         res.bits.set(bc / Plan::NP, v > CT(0));
                     }
                 });
@@ -313,7 +314,7 @@ __device__ __forceinline__ void split_body(const FusedArgs &A, char *lds, const 
                     const Where w(p4, A.batch);
                     static_for<0, Plan::NBC>([&](auto bcc) {
                         constexpr int bc = decltype(bcc)::value;
-                        if constexpr ((bc % Plan::NP) == P) A.final_lam[w.fN + bc * SZ + w.r0] = (double)lds_ld<CT>(lds, p4 | (bc * V * ES));
+                        if constexpr ((bc % Plan::NP) == P) A.final_lam[w.fN + bc * SZ + w.r0] = (double)lds_ld<CT>(lds, p4 + (bc * V * ES));
                     });
                 }
             }
@@ -338,7 +339,7 @@ __device__ __forceinline__ void split_body(const FusedArgs &A, char *lds, const 
     if (A.step_mode) {
         static_for<0, Plan::NBC>([&](auto bcc) {
             constexpr int bc = decltype(bcc)::value;
-            if constexpr ((bc % Plan::NP) == P) A.final_lam[w.fN + bc * SZ + w.r0] = (double)lds_ld<CT>(lds, p4 | (bc * V * ES));
+            if constexpr ((bc % Plan::NP) == P) A.final_lam[w.fN + bc * SZ + w.r0] = (double)lds_ld<CT>(lds, p4 + (bc * V * ES));
         });
         static_for<0, Plan::NBR>([&](auto brc) {
             constexpr int br = decltype(brc)::value;
@@ -385,7 +386,7 @@ __device__ __forceinline__ void split_body(const FusedArgs &A, char *lds, const 
 }
 
 template <class Plan, int SZ> struct SplitGeom {
-    static constexpr int CPW = SZ >= 64 ? 1 : 64 / SZ, V = SZ * CPW, THREADS = Plan::NP * V, NW = THREADS / 64;
+    static constexpr int CPW = QcGeom<SZ>::CPW, V = QcGeom<SZ>::V, VT = QcGeom<SZ>::VT, THREADS = Plan::NP * VT, NW = THREADS / 64;
     static_assert(THREADS <= 1024, "a frame's wave groups must fit one workgroup");
 };
 
@@ -393,10 +394,10 @@ template <class Plan, int SZ> struct SplitGeom {
 template <typename CT, int VARIANT, class Plan, int SZ, class T>
 __device__ __forceinline__ void split_kernel_body(const FusedArgs &A) {
     using G = SplitGeom<Plan, SZ>;
-    static_assert((SZ & (SZ - 1)) == 0 && SZ >= 16, "circulant size must be a power of two");
-    __shared__ __attribute__((aligned(16))) char lds[Plan::NBC * G::V * (int)sizeof(CT) + 4 * G::NW];
+    static_assert(SZ >= 2, "circulant size");
+    __shared__ __attribute__((aligned(16))) char lds[(Plan::NBC * G::V * (int)sizeof(CT) + 15) / 16 * 16 + 4 * G::NW];
     const uint32_t tid = threadIdx.x;
-    const uint32_t pair = __builtin_amdgcn_readfirstlane(tid / G::V);  // wave-uniform (V is a multiple of 64)
+    const uint32_t pair = __builtin_amdgcn_readfirstlane(tid / G::VT);  // wave-uniform (VT is a multiple of 64)
     static_for<0, Plan::NP>([&](auto pc) {
         constexpr int P = decltype(pc)::value;
         if (pair == (uint32_t)P) split_body<CT, VARIANT, Plan, SZ, T, P>(A, lds, tid);

@@ -270,10 +270,15 @@ void deal_cost(const PlanChoice &p, const std::vector<int> &own, int np, int *ma
 
 const char *choose_plan(const ldpc_code &c, int variant, PlanChoice &p) {
     if (c.sz <= 0) return "code was not created from a quasi-cyclic description";
-    if (c.sz < 16 || (c.sz & (c.sz - 1))) return "circulant size must be a power of two >= 16 for the split kernel";
+    if (c.sz < 16) return "circulant size below 16 (the generic on-chip kernel takes those)";
     if (c.sz > 1024) return "circulant size above 1024";
     p.sz = c.sz; p.nbr = c.block_rows; p.nbc = c.block_cols;
-    p.cpw = c.sz >= 64 ? 1 : 64 / c.sz; p.v = c.sz * p.cpw;
+    // fused_common.h QcGeom: power-of-two sizes below 64 interleave 64/sz frames per wave; any other size runs one frame
+    // on sz rounded up to whole waves (the top lanes idle, positions wrap with sub + min instead of an AND)
+    const bool pow2 = (c.sz & (c.sz - 1)) == 0;
+    p.cpw = (pow2 && c.sz < 64) ? 64 / c.sz : 1;
+    const int vpos = c.sz * p.cpw;          // positions of a block column in LDS
+    p.v = (vpos + 63) / 64 * 64;            // threads of one wave group
     p.deg.assign(p.nbr, 0); p.ebeg.assign(p.nbr + 1, 0);
     for (int br = 0; br < p.nbr; br++) {
         for (int bc = 0; bc < p.nbc; bc++) {
@@ -292,7 +297,7 @@ const char *choose_plan(const ldpc_code &c, int variant, PlanChoice &p) {
         for (int b : p.bc) hit[b] = 1;
         for (char h : hit) if (!h) return "an empty block column";
     }
-    const size_t lds = (size_t)p.nbc * p.v * 4 + 64;
+    const size_t lds = (size_t)p.nbc * vpos * 4 + 64;
     if (lds > 160 * 1024) return "a frame's LLRs do not fit in 160 KB of LDS";
     const int cap = variant == LDPC_TANH ? kMsgCapTanh : kMsgCapMinsum;
     const int max_np = std::min(1024 / p.v, p.nbr);

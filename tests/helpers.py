@@ -172,7 +172,29 @@ def synthetic(name) -> SyntheticQC:
             for br in rng.choice(4, 2 + (bc % 2), replace=False):
                 mask[br, bc] = True
         return SyntheticQC(name, 256, _random_offsets(mask, 256, 19))
+    if name in ("wimax-12x24-sz96", "wifi-12x24-sz27", "dvbs2short-20x45-sz360"):
+        # circulant sizes that are NOT powers of two (WiMAX 802.16e: 24..96, WiFi 802.11n: 27/54/81, DVB-S2: 360): IRA shapes,
+        # synthetic rotations.  dvbs2short: n = 16 200, k = 9 000, the short-frame size of DVB-S2 (its LLRs fit in LDS: 65 KB)
+        sz = {"wimax-12x24-sz96": 96, "wifi-12x24-sz27": 27, "dvbs2short-20x45-sz360": 360}[name]
+        R, K = (20, 25) if sz == 360 else (12, 12)
+        rng = np.random.default_rng(20 + sz)
+        mask = np.zeros((R, K + R), bool)
+        for br in range(R):
+            mask[br, K + br] = True
+            if br:
+                mask[br, K + br - 1] = True
+        mask[0, K + R - 1] = True
+        for bc in range(K):
+            for br in rng.choice(R, 3 + (3 if bc % 4 == 0 else 0), replace=False):
+                mask[br, bc] = True
+        off = _random_offsets(mask, sz, 21 + sz)
+        for br in range(R):
+            off[br, K + br] = 0
+            if br:
+                off[br, K + br - 1] = 0
+        return SyntheticQC(name, sz, off)
     raise KeyError(name)
 
 
-SYNTHETIC_NAMES = ["jpl4096-permuted", "regular36-sz128", "ira-12x24-sz64", "small-2x4-sz32", "irregular-20x30-sz64", "wide-4x40-sz256"]
+SYNTHETIC_NAMES = ["jpl4096-permuted", "regular36-sz128", "ira-12x24-sz64", "small-2x4-sz32", "irregular-20x30-sz64", "wide-4x40-sz256",
+                   "wimax-12x24-sz96", "wifi-12x24-sz27", "dvbs2short-20x45-sz360"]

@@ -58,6 +58,9 @@ int fused_split_launch(int variant, int sz, hipStream_t st, FusedArgs &a, Kernel
         info->frames_per_wg = sz == 128 ? SplitGeom<PlanAR4JA45, 128>::CPW : SplitGeom<PlanAR4JA45, 32>::CPW;
     }
     if (timer && !a.step_mode) timer->begin(st);
+#ifdef SPLIT_ABLATION_MINSUM128   // timing builds (tools/build_ablation.sh): the headline instance only
+    launch_split<LDPC_V_MINSUM, 128, TabJpl4096>(st, a);
+#else
     if (sz == 128) {
         if (variant == LDPC_MINSUM) launch_split<LDPC_V_MINSUM, 128, TabJpl4096>(st, a);
         else launch_split<LDPC_V_TANH, 128, TabJpl4096>(st, a);
@@ -65,6 +68,7 @@ int fused_split_launch(int variant, int sz, hipStream_t st, FusedArgs &a, Kernel
         if (variant == LDPC_MINSUM) launch_split<LDPC_V_MINSUM, 32, TabJpl1024>(st, a);
         else launch_split<LDPC_V_TANH, 32, TabJpl1024>(st, a);
     }
+#endif
     if (timer && !a.step_mode) timer->end(st);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return set_error(LDPC_EHIP, "fused_split launch: %s", hipGetErrorString(e));

@@ -430,10 +430,26 @@ ldpc_ecc *ldpc_ecc_create_replicas(const char *codes_dir, const char *code_name,
         bool as_bool = false;   // "-bool": take H as a plain Boolean matrix (the Haskell binding's `Matrix Bool` flavour, haskell/.../HIP.hs)
         if (ends("-bool")) { as_bool = true; dec.resize(dec.size() - 5); }
         if (ends("-layered")) { schedule = LDPC_SCHED_LAYERED; dec.resize(dec.size() - 8); }   // extension: row-layered schedule
+        // The reference's own decoder names are accepted as aliases of the decoder that computes the same thing here, so
+        // that a command line written for the reference runs unchanged (the ECC keeps the name it was asked for):
+        //   reference, sparse (Reference/Orig.hs:21, Sparse.hs:39) and min, sparsemin (Min.hs:24, SparseMin.hs:42) take H
+        //   as a Boolean matrix; arraylet, arraylet-min, arraylet-cm (Fast/Arraylet.hs:138, ArrayletMin.hs:136,
+        //   CachedMult.hs:207) and the CUDA plug-ins (GPU/CUDA/Arraylet1.hs:60, Arraylet2.hs:61, TwoArrays.hs:61,
+        //   CachedMult.hs:66) take it quasi-cyclic.  arraylet-cm's last-ulp numerics exist in f64 only (LDPC_TANH_CM).
+        static const struct { const char *ref, *hip; bool as_bool; int dtype; } kAliases[] = {
+            {"reference", "hip-tanh", true, -1},      {"sparse", "hip-tanh", true, -1},
+            {"min", "hip-minsum", true, -1},          {"sparsemin", "hip-minsum", true, -1},
+            {"arraylet", "hip-tanh", false, -1},      {"arraylet-min", "hip-minsum", false, -1},
+            {"arraylet-cm", "hip-tanh-cm", false, LDPC_F64},
+            {"cuda-arraylet1", "hip-tanh", false, -1}, {"cuda-arraylet2", "hip-tanh", false, -1},
+            {"two-arrays", "hip-tanh", false, -1},     {"cuda-arraylet-cm", "hip-tanh", false, -1},
+        };
+        for (const auto &a : kAliases)
+            if (dec == a.ref) { dec = a.hip; as_bool = as_bool || a.as_bool; if (a.dtype >= 0) dtype = a.dtype; break; }
         if (dec == "hip-tanh") variant = LDPC_TANH;
         else if (dec == "hip-tanh-cm") variant = LDPC_TANH_CM;   // the reference's `arraylet-cm` numerics (f64 parity mode)
         else if (dec == "hip-minsum") variant = LDPC_MINSUM;
-        else { set_error(LDPC_ENOTFOUND, "decoder '%s' is not provided by libldpc_hip (hip-tanh, hip-minsum [-layered][-f32|-f64|-f16])", xs[1].c_str()); return nullptr; }
+        else { set_error(LDPC_ENOTFOUND, "decoder '%s' is not provided by libldpc_hip (hip-tanh, hip-minsum [-layered][-bool][-f32|-f64|-f16], or a reference name: reference, min, sparse, sparsemin, arraylet, arraylet-min, arraylet-cm, cuda-arraylet1/2)", xs[1].c_str()); return nullptr; }
 
         // A matrix name that is a plain FILE under codes_dir is a stand-alone parity-check matrix in
         // MacKay's alist order with no generator (codes/1920.1280.3.303; the reference cannot load it,

@@ -291,8 +291,12 @@ ldpc_code *ldpc_code_from_matrix(const ldpc_matrix *m);
  * C mirror of what mkLDPC returns (src/ECC/Code/LDPC/Utils.hs:35-75): ECC{name, encode, decode,
  * message_length, codeword_length}, selected by the reference's code-name grammar
  *   ldpc/<decoder>/<matrix-name>/<max-rounds>[/<x>/<y>]        (Utils.hs:82-88,100-108; rate x%y)
- * with <decoder> in {hip-tanh, hip-minsum}[-layered][-f32|-f64|-f16] or hip-tanh-cm-f64.  NULL + LDPC_ENOTFOUND for any other
- * name (the factory's `_ -> return []`). One decoder replica is created (maxThreadCount = 1, like
+ * with <decoder> in {hip-tanh, hip-minsum}[-layered][-bool][-f32|-f64|-f16] or hip-tanh-cm-f64 (-bool: H taken as a plain
+ * Boolean matrix, the `Matrix Bool` decoders' input).  The reference's own decoder names are accepted as aliases, so a
+ * command line written for it runs unchanged: reference, sparse -> hip-tanh-bool; min, sparsemin -> hip-minsum-bool;
+ * arraylet, cuda-arraylet1, cuda-arraylet2, two-arrays, cuda-arraylet-cm -> hip-tanh; arraylet-min -> hip-minsum;
+ * arraylet-cm -> hip-tanh-cm-f64 (a dtype suffix may follow: ldpc/reference-f64/...).  The ECC keeps the name it was
+ * asked for.  NULL + LDPC_ENOTFOUND for any other name (the factory's `_ -> return []`). One decoder replica is created (maxThreadCount = 1, like
  * the CUDA plug-ins, GPU/CUDA/Arraylet2.hs:61). */
 typedef struct ldpc_ecc ldpc_ecc;
 ldpc_ecc *ldpc_ecc_create(const char *codes_dir, const char *code_name, int max_batch);

@@ -55,7 +55,7 @@ def test_loader_search_order_and_errors(tmp_path):
 
 
 def test_code_name_grammar_rejections():
-    for bad in ("ldpc/reference/jpl.1024.4.5/50", "bpsk", "ldpc/hip-minsum/jpl.1024.4.5/x", "ldpc/hip-minsum/jpl.1024.4.5/50/4"):
+    for bad in ("ldpc/ldpc-zero/jpl.1024.4.5/50", "ldpc/model-3-4/jpl.1024.4.5/50", "bpsk", "ldpc/hip-minsum/jpl.1024.4.5/x", "ldpc/hip-minsum/jpl.1024.4.5/50/4"):
         with pytest.raises(E.LdpcError) as e:
             E.ECC(CODES, bad)
         assert e.value.code == -8, bad  # not ours: the factory's `_ -> return []`
@@ -83,6 +83,17 @@ def test_ecc_record_mirrors_mkLDPC(hip):
     assert len(eb.code.layers()) == 384 + 1 and "csr" in eb.decoder.kernel_name
     outb, okb = eb.decode(llr[:1280])
     assert okb and np.array_equal(outb, out)
+    # the reference's own decoder names are aliases (host.cc kAliases): same answers, and the ECC keeps the name it was given
+    ea = hip.ECC(CODES, "ldpc/arraylet-min/jpl.1024.4.5/50/4/5", max_batch=4)
+    assert ea.name == "ldpc/arraylet-min/jpl.1024.4.5/50/4/5" and ea.decoder.kernel_name == ecc.decoder.kernel_name
+    outa, oka = ea.decode(llr[:1280])
+    assert oka and np.array_equal(outa, out)
+    em = hip.ECC(CODES, "ldpc/min/jpl.1024.4.5/50/4/5", max_batch=4)          # Reference.Min: Boolean H
+    assert "csr" in em.decoder.kernel_name and np.array_equal(em.decode(llr[:1280])[0], out)
+    ecm = hip.ECC(CODES, "ldpc/arraylet-cm/jpl.1024.4.5/20/4/5", max_batch=2)  # StableDiv numerics: f64 only
+    ref_cm = hip.ECC(CODES, "ldpc/hip-tanh-cm-f64/jpl.1024.4.5/20/4/5", max_batch=2)
+    assert ecm.decoder.kernel_name == ref_cm.decoder.kernel_name
+    assert np.array_equal(ecm.decode(llr[:1280])[0], ref_cm.decode(llr[:1280])[0])
     mo = hip.ECC(CODES, "ldpc/hip-tanh/moon.7.13/20", max_batch=2)
     assert (mo.message_length, mo.codeword_length) == (7, 20)
     m = load("moon.7.13")

@@ -1,0 +1,93 @@
+#!/usr/bin/env python3
+"""Differential fuzz of the on-chip QC kernels (built-in / run-time specialised / table-driven / generic) against the HBM
+flood path on random single-circulant protographs: circulant sizes that are and are not powers of two, 2..16 block rows,
+row weights 2..24, punctured-looking weight-1 columns included.  Both paths implement the same decoder; for f32 they must
+agree bit for bit (hard bits, iteration counts, converged flags); so must the two kernels of the row-layered schedule.  Usage: python tools/fuzz_qc.py [n_codes] [first_seed]
+Prints one line per (code, rule); exit status 1 on the first disagreement."""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import ecc_ldpc_amd as E  # noqa: E402
+from tests.helpers import SyntheticQC  # noqa: E402
+
+SIZES = [16, 24, 27, 32, 48, 54, 64, 81, 96, 100, 128, 160, 192, 256, 360, 384]
+
+
+def random_code(seed):
+    rng = np.random.default_rng(seed)
+    sz = int(rng.choice(SIZES))
+    R = int(rng.integers(2, 17))
+    C = int(rng.integers(R + 1, min(4 * R, 48) + 1))
+    while C * sz * 4 > 150 * 1024:
+        C -= 1
+    if C <= R:
+        return None
+    mask = np.zeros((R, C), bool)
+    wmax = min(C, 24)
+    for br in range(R):
+        w = int(rng.integers(2, max(3, min(wmax, 3 + C // 2)) + 1))
+        mask[br, rng.choice(C, w, replace=False)] = True
+    for bc in range(C):                       # no empty column; most columns weight >= 2
+        need = 1 if rng.random() < 0.15 else 2
+        while mask[:, bc].sum() < min(need, R):
+            mask[int(rng.integers(0, R)), bc] = True
+    off = np.where(mask, rng.integers(0, sz, mask.shape), -1).astype(np.int32)
+    return SyntheticQC(f"fuzz{seed}-{R}x{C}-sz{sz}", sz, off)
+
+
+def main():
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 16
+    first = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
+    E.init(0)
+    F, bad = 192, 0
+    for seed in range(first, first + n):
+        c = random_code(seed)
+        if c is None:
+            continue
+        code = c.hip_code(E)
+        llr = np.concatenate([c.frames(F // 2, 2.5, seed)[1], c.frames(F // 2, 6.0, seed + 1)[1]]).astype(np.float32)
+        for rule in ("min", "tanh"):
+            t0 = time.time()
+            try:
+                fused = E.Decoder(code, rule, "f32", F, path="fused")
+            except E.LdpcError as e:      # a frame no on-chip kernel holds: LDPC_PATH_AUTO would take the HBM path
+                print(f"{c.name:26s} {rule:4s} no on-chip kernel ({str(e)[:60]}...)", flush=True)
+                fused = None
+            flood = E.Decoder(code, rule, "f32", F, path="flood")
+            b = flood.decode_batch(llr, 30)
+            a = fused.decode_batch(llr, 30) if fused else b
+            same = all(np.array_equal(x, y) for x, y in zip(a, b))
+            if fused:
+                print(f"{c.name:26s} {rule:4s} rows {c.offsets.shape[0]:2d} max row weight {int((c.offsets >= 0).sum(1).max()):2d} "
+                      f"{fused.kernel_name[:44]:44s} vs {flood.kernel_name[:28]:28s} converged {a[2].mean():.2f} mean iters {a[1].mean():5.1f} "
+                      f"{'ok' if same else 'MISMATCH'}  ({time.time() - t0:.0f} s)", flush=True)
+            if not same:
+                bad += 1
+                d = [int((x != y).sum()) for x, y in zip(a, b)]
+                print("   differing (bits, iters, conv):", d, flush=True)
+            del fused, flood
+            # row-layered schedule: the frame-per-workgroup QC kernel (min-sum: row records) against the batch-major any-H kernel
+            qc = E.Decoder(code, rule, "f32", F, schedule="layered")
+            os.environ["LDPC_LAYERED_QC"] = "0"
+            bm = E.Decoder(code, rule, "f32", F, schedule="layered")
+            del os.environ["LDPC_LAYERED_QC"]
+            a = qc.decode_batch(llr, 20)
+            b = bm.decode_batch(llr, 20)
+            same = all(np.array_equal(x, y) for x, y in zip(a, b))
+            print(f"{'':26s} {rule:4s} layered {qc.kernel_name[:50]:50s} vs {bm.kernel_name[:20]:20s} converged {a[2].mean():.2f} mean sweeps {a[1].mean():5.1f} "
+                  f"{'ok' if same else 'MISMATCH'}", flush=True)
+            if not same:
+                bad += 1
+                print("   differing (bits, sweeps, conv):", [int((x != y).sum()) for x, y in zip(a, b)], flush=True)
+            del qc, bm
+    print("fuzz:", "FAILED" if bad else "all equal")
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

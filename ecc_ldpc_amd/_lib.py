@@ -498,6 +498,47 @@ class Decoder:
             pass
 
 
+class Batcher:
+    """ldpc_batcher on one decoder replica: concurrent per-frame decode_one() calls (one per host thread, the reference
+    harness's calling convention, Utils.hs:63-69) are collected into one launch.  This is the object the Haskell binding
+    shares between the replicas of one GPU (haskell/ECC/Code/LDPC/GPU/HIP.hs closureFor)."""
+
+    def __init__(self, decoder: Decoder, max_frames=64, max_wait_us=200):
+        self.decoder = decoder
+        self._h = lib().ldpc_batcher_create(decoder._h, int(max_frames), int(max_wait_us))
+        if not self._h:
+            raise LdpcError(lib().ldpc_last_error_code(), last_error())
+        _register(self)
+
+    def decode_one(self, llr, max_iters):
+        llr = np.ascontiguousarray(llr, np.float64)
+        N = self.decoder.code.N
+        assert llr.shape == (N,)
+        bits = np.zeros(N, np.uint8)
+        it, cv = C.c_int(), C.c_int()
+        check(lib().ldpc_batcher_decode_one(self._h, int(max_iters), ptr(llr, C.c_double), ptr(bits, C.c_uint8), C.byref(it), C.byref(cv)))
+        return bits, it.value, bool(cv.value)
+
+    def stats(self):
+        """-> (decode calls, launches) so far"""
+        a, b = C.c_long(), C.c_long()
+        check(lib().ldpc_batcher_stats(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def close(self):
+        if self._h:
+            lib().ldpc_batcher_destroy(self._h)
+        self._h = None
+
+    def __del__(self):
+        if _finalizing():
+            return
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class Matrix:
     """A loaded matrix file (ldpc_matrix): the reference's LoaderMatrix (Data/BitMatrix/Loader.hs:49-52)."""
 

@@ -85,15 +85,15 @@ def test_ecc_record_mirrors_mkLDPC(hip):
     assert okb and np.array_equal(outb, out)
     # the reference's own decoder names are aliases (host.cc kAliases): same answers, and the ECC keeps the name it was given
     ea = hip.ECC(CODES, "ldpc/arraylet-min/jpl.1024.4.5/50/4/5", max_batch=4)
-    assert ea.name == "ldpc/arraylet-min/jpl.1024.4.5/50/4/5" and ea.decoder.kernel_name == ecc.decoder.kernel_name
+    assert ea.name == "ldpc/arraylet-min/jpl.1024.4.5/50/4/5"
     outa, oka = ea.decode(llr[:1280])
-    assert oka and np.array_equal(outa, out)
+    assert oka and np.array_equal(outa, out) and ea.decoder.kernel_name == ecc.decoder.kernel_name
     em = hip.ECC(CODES, "ldpc/min/jpl.1024.4.5/50/4/5", max_batch=4)          # Reference.Min: Boolean H
     assert "csr" in em.decoder.kernel_name and np.array_equal(em.decode(llr[:1280])[0], out)
     ecm = hip.ECC(CODES, "ldpc/arraylet-cm/jpl.1024.4.5/20/4/5", max_batch=2)  # StableDiv numerics: f64 only
     ref_cm = hip.ECC(CODES, "ldpc/hip-tanh-cm-f64/jpl.1024.4.5/20/4/5", max_batch=2)
-    assert ecm.decoder.kernel_name == ref_cm.decoder.kernel_name
     assert np.array_equal(ecm.decode(llr[:1280])[0], ref_cm.decode(llr[:1280])[0])
+    assert ecm.decoder.kernel_name == ref_cm.decoder.kernel_name
     mo = hip.ECC(CODES, "ldpc/hip-tanh/moon.7.13/20", max_batch=2)
     assert (mo.message_length, mo.codeword_length) == (7, 20)
     m = load("moon.7.13")

@@ -90,6 +90,53 @@ def test_coalesced_calls_equal_one_by_one_and_share_launches(hip):
     ecc.close()
 
 
+def test_haskell_binding_call_sequence(hip):
+    """haskell/ECC/Code/LDPC/GPU/HIP.hs closureFor, call for call: ldpc_code_create_qc / _csr -> ldpc_ctx_create_cfg
+    {device, rule, f32, 64 frames, auto path, schedule} -> ldpc_batcher_create(ctx, 64, 200 us) -> ldpc_batcher_decode_one
+    from hipThreads = 64 host threads.  Same answers as ldpc_decode_one on the same context, for the QC codes, the
+    `Matrix Bool` (CSR) codes and the layered code; the bad-argument paths the binding could hit give error codes."""
+    c = load("jpl.1024.4.5")
+    _, llr = c.frames(128, 3.4, seed=31)
+    flavours = [(c.hip_code(hip, prefer_qc=True), "min", "flooding"), (c.hip_code(hip, prefer_qc=True), "tanh", "flooding"),
+                (c.hip_code(hip, prefer_qc=False), "min", "flooding"), (c.hip_code(hip, prefer_qc=True), "min", "layered")]
+    for code, rule, sched in flavours:
+        dec = hip.Decoder(code, rule, "f32", 64, device=0, schedule=sched)           # ldpc_ctx_create_cfg
+        want = [dec.decode_one(l, 30) for l in llr]
+        b = hip.Batcher(dec, 64, 200)
+        got = [None] * 128
+        def work(i):
+            for f in (i, i + 64):
+                got[f] = b.decode_one(llr[f], 30)
+        _run_threads(64, work)
+        calls, launches = b.stats()
+        assert calls == 128 and launches < 128, (calls, launches)
+        for f in range(128):
+            assert np.array_equal(got[f][0], want[f][0]) and got[f][1:] == want[f][1:], (rule, sched, f)
+        # callers with different max_iters never share a batch, and still get their own answers
+        def work2(i):
+            got[i] = b.decode_one(llr[i], 5 if i % 2 else 30)
+        _run_threads(16, work2)
+        for i in range(16):
+            assert np.array_equal(got[i][0], dec.decode_one(llr[i], 5 if i % 2 else 30)[0])
+        b.close()
+        with pytest.raises(hip.LdpcError) as e:
+            hip.Batcher(dec, 65, 200)                                                  # more frames than the context holds
+        assert e.value.code == -1
+        with pytest.raises(hip.LdpcError):
+            hip.Batcher(dec, 0, 200)
+        dec.close()
+    # struct_size too small / unknown enum values are refused before anything is allocated
+    import ctypes as C
+    from ecc_ldpc_amd._lib import CtxConfig, lib
+    code = c.hip_code(hip)
+    for bad in (dict(struct_size=8), dict(variant=7), dict(dtype=9), dict(schedule=5), dict(max_batch=0), dict(device=99)):
+        cfg = CtxConfig(C.sizeof(CtxConfig), 0, 1, 0, 64, 0, 0)
+        for k, v in bad.items():
+            setattr(cfg, k, v)
+        assert not lib().ldpc_ctx_create_cfg(code._h, C.byref(cfg)), bad
+        assert lib().ldpc_last_error_code() in (-1, -4, -5), (bad, lib().ldpc_last_error_code())
+
+
 def test_explicit_device_from_a_thread_without_init(hip):
     c = load("jpl.1024.4.5")
     _, llr = c.frames(4, 4.0, seed=23)

@@ -154,8 +154,9 @@ int compile_hiprtc(const std::string &source, std::vector<char> &co) {
 
 // the tool-chain route: same source, same headers, same options through `hipcc --genco`
 int compile_hipcc(const std::string &source, std::vector<char> &co) {
-    char tmpl[] = "/tmp/ldpc_jit_XXXXXX";
-    if (!mkdtemp(tmpl)) return set_error(LDPC_EHIP, "mkdtemp failed");
+    const char *tmp = getenv("TMPDIR");
+    std::string tmpl = std::string(tmp && *tmp ? tmp : "/tmp") + "/ldpc_jit_XXXXXX";
+    if (!mkdtemp(&tmpl[0])) return set_error(LDPC_EHIP, "mkdtemp(%s) failed", tmpl.c_str());
     std::string d(tmpl);
     for (int i = 0; i < kJitHeaderCount; i++) { std::ofstream f(d + "/" + kJitHeaders[i].name); f << kJitHeaders[i].text; }
     { std::ofstream f(d + "/ldpc_jit.hip"); f << source; }

@@ -163,7 +163,7 @@ def test_standalone_mackay_matrix_record(hip):
 def test_cli_rows(hip, capsys):
     """The ecc-ldpc-like CLI (reference usage: main/Main.hs:38-40, NOTES.txt:2-3)."""
     from ecc_ldpc_amd import cli
-    rc = cli.main(["3", "4.5", "ldpc/hip-minsum/jpl.1024.4.5/50/4/5", "ldpc/reference/jpl.1024.4.5/50", "-m2048", "-b1024"])
+    rc = cli.main(["3", "4.5", "ldpc/hip-minsum/jpl.1024.4.5/50/4/5", "ldpc/ldpc-zero/jpl.1024.4.5/50", "-m2048", "-b1024"])   # (ldpc-zero: not ours)
     out = capsys.readouterr()
     rows = [l.split() for l in out.out.strip().splitlines()]
     assert rc == 0 and len(rows) == 2 and "no such code" in out.err

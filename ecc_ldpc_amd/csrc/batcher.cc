@@ -8,6 +8,9 @@
 // `max_frames` requests are queued or `max_wait_us` have passed, decodes all of them with ONE ldpc_decode_batch_f64
 // call and hands every caller its own result.  Callers block exactly like ldpc_decode_one's do; results are those of
 // ldpc_decode_one bit for bit (same kernels, frames are independent).
+// Measured (jpl.4096, 50 turns, 16 host cores, callers = batch limit): 64 threads 338-376 Mbit/s, 128: 408, 256: 467, 512:
+// 339 -- about 100 000 calls/s is what the host side sustains (wake-ups, the 40 KB copy of each call's LLRs).  Copying the
+// LLRs outside the lock was tried: +14 % at 64 threads, 2.8x SLOWER at 256 (the leader then waits for descheduled copiers).
 #include <string.h>
 
 #include <chrono>

@@ -27,6 +27,14 @@ __global__ __launch_bounds__(256) void ks(float *out, int iters) {   // scalar-p
         if (K == 4) { R8(asm volatile(BITOP8 : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c));) }
         if (K == 5) { R8(asm volatile(U8("v_sqrt_f32") : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c));) }
         if (K == 6) { R8(asm volatile(U8("v_cvt_f16_f32") : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c));) }
+        // do transcendentals overlap with plain VALU work?  7: inside one wave, 8 v_exp then 24 v_mul (x8 per iteration);
+        // 8: between waves of one SIMD: even waves run v_exp only, odd waves v_mul only, 26 v_mul for 8 v_exp (equal time alone)
+        if (K == 7) { R8(asm volatile(U8("v_exp_f32") B8("v_mul_f32") B8("v_mul_f32") B8("v_mul_f32") : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c));) }
+        if (K == 8 || K == 9 || K == 10) {
+            const bool trans = ((threadIdx.x >> 6) & 1) == 0;
+            if (trans) { if (K != 10) { R8(asm volatile(U8("v_exp_f32") : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c));) } }
+            else if (K != 9) { R8(asm volatile(B8("v_mul_f32") B8("v_mul_f32") B8("v_mul_f32") "v_mul_f32 %0, %8, %0\nv_mul_f32 %1, %8, %1\n" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c));) }
+        }
     }
     out[blockIdx.x * 256 + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7;
 }
@@ -70,5 +78,8 @@ int main() {
         run("v_pk_fma_f32", kp<0>, w); run("v_pk_mul_f32", kp<1>, w); run("v_pk_add_f32", kp<2>, w);
         printf("\n");
     }
+    // overlap of the transcendental unit with plain VALU (clk figures below are per R8 block of the named mix, 8 waves/SIMD)
+    run("8exp+24mul/wave", ks<7>, 8);
+    run("exp|mul waves", ks<8>, 8); run("exp waves only", ks<9>, 8); run("mul waves only", ks<10>, 8);
     return 0;
 }

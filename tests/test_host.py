@@ -61,6 +61,22 @@ def test_code_name_grammar_rejections():
         assert e.value.code == -8, bad  # not ours: the factory's `_ -> return []`
 
 
+def test_reference_decoder_names_are_recognised_without_a_gpu():
+    """the alias table (host.cc kAliases) is part of the name grammar: on a box without a GPU a reference name gets past
+    it and fails at the device (no CPU fallback), an unknown name fails at the grammar"""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("needs a box without a GPU")
+    for name in ("reference", "min", "sparse", "sparsemin", "arraylet", "arraylet-min", "arraylet-cm", "cuda-arraylet1", "cuda-arraylet2",
+                 "two-arrays", "hip-minsum", "hip-tanh-layered", "hip-minsum-bool-f64"):
+        with pytest.raises(E.LdpcError) as e:
+            E.ECC(CODES, f"ldpc/{name}/jpl.1024.4.5/50/4/5")
+        assert e.value.code == -4, (name, e.value.code, str(e.value))     # LDPC_ENODEVICE, not LDPC_ENOTFOUND
+    with pytest.raises(E.LdpcError) as e:
+        E.ECC(CODES, "ldpc/arraylet-max/jpl.1024.4.5/50/4/5")
+    assert e.value.code == -8
+
+
 @pytest.mark.gpu
 def test_ecc_record_mirrors_mkLDPC(hip):
     ecc = hip.ECC(CODES, "ldpc/hip-minsum/jpl.1024.4.5/50/4/5", max_batch=4)

@@ -98,3 +98,27 @@ def test_layered_invariants_and_speed_of_convergence():
     # layers whose rows share a column are rejected (rows 0..63 of jpl.1024 span two block rows)
     with pytest.raises(RuntimeError):
         oracle.decode_layered(c.graph, np.arange(0, c.M + 1, 2 * c.sz), "min", 5, llr[0])
+
+
+def test_channel_convention_against_the_counts_in_notes_txt():
+    """/root/reference/NOTES.txt holds three runs of one configuration (jpl.1K without a puncturing rate, 0 dB, a decoder
+    that passes the channel through, 256 x 1024 message bits): 29 891, 29 751 and 29 705 bit errors.  They pin the
+    channel convention of the absent tester: sigma^2 = 1 / (2 R Eb/N0) with R = k / n_tx gives Q(sqrt(2 * 1024/1408)) =
+    0.1139; the CPU-side channel of the oracle (oracle/channel.py) must produce that rate, and every one of the three
+    counts must be a plausible draw of it (tests/test_notes_pin_gpu.py does the same for the device frame source)."""
+    import math
+    from oracle import channel
+    k, n = 1024, 1408
+    p = 0.5 * math.erfc(math.sqrt(2.0 * k / n) / math.sqrt(2.0))
+    assert abs(p - 0.11390) < 2e-5
+    bits = 256 * 1024
+    sd = math.sqrt(p * (1 - p) / bits)
+    for errors in (29891, 29751, 29705):                       # NOTES.txt:3, 8, 13
+        assert abs(errors / bits - p) < 3 * sd, errors
+    assert abs(0.5 * math.erfc(1.0) - 29891 / bits) > 50 * sd   # sigma^2 = 1/(2 Eb/N0), rate not folded in: Q(sqrt 2) = 0.0786
+    F = 2048
+    cw = np.zeros((F, n), np.uint8)
+    llr = channel.frames(cw, 0.0, k, n, n, seed=20)
+    wrong = int((llr[:, :k] > 0).sum())                        # all-zero codeword: a positive LLR is a bit error
+    sd2 = math.sqrt(p * (1 - p) * F * k)
+    assert abs(wrong - p * F * k) < 4 * sd2, (wrong, p * F * k)

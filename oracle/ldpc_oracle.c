@@ -14,7 +14,7 @@
  * Two things the reference DOES hold pin the conventions around the arithmetic (not the arithmetic): NOTES.txt's three
  * bit-error counts (the channel's sigma^2, tests/test_notes_pin_gpu.py + tests/test_oracle_ext.py) and
  * codes/Gmat.m.gz + codes/X.gz (the .q parse and the rotation direction of the quasi-cyclic expansion,
- * tests/test_formats.py, tests/golden/reference_data/).
+ * tests/test_formats.py).
  *
  * What is restated (paths relative to /root/reference):
  *   src/ECC/Code/LDPC/Reference/Orig.hs:58-98   ldpc / loop / ans / ne' / lam'  (tanh rule)

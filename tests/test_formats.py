@@ -54,14 +54,14 @@ def test_qc_rejects_multi_circulant_blocks():
 
 
 def test_generator_matches_the_two_representations_the_reference_holds():
-    """tests/golden/reference_data/: the reference's codes/Gmat.m.gz (dense [I | X], Matlab text) and codes/X.gz (X in the
+    """codes/Gmat.m.gz (dense [I | X], Matlab text) and codes/X.gz (X in the
     reference's alist layout) -- two descriptions of jpl.1024.4.5's generator that the reference's own loader never reads
     for this code (it reads G.q).  This repository's `.q` big-integer reader and circulant expansion (oracle AND the C
     loader of the product) must reproduce them bit for bit: a reference-held pin of the parse, of the rotation direction
     of the quasi-cyclic expansion (shared with H.q) and of both text readers.  And H (from H.q) annihilates the
     reference's dense generator."""
     import gzip
-    here = os.path.join(os.path.dirname(__file__), "golden", "reference_data")
+    here = CODES
     dense = np.array([[int(t) for t in l.split()] for l in gzip.open(os.path.join(here, "Gmat.m.gz"), "rt").read().splitlines() if l.strip()], np.uint8)
     assert dense.shape == (1024, 1408) and np.array_equal(dense[:, :1024], np.eye(1024, dtype=np.uint8))
     X = formats.read_alist_reference(gzip.open(os.path.join(here, "X.gz"), "rt").read())

@@ -163,6 +163,7 @@ int compile_hipcc(const std::string &source, std::vector<char> &co) {
     const char *hipcc = getenv("HIPCC");
     std::string cmd = std::string(hipcc ? hipcc : "/opt/rocm/bin/hipcc") + " --genco -DLDPC_JIT -I" + d;
     for (int i = 0; i < kNumOptions; i++) cmd += std::string(" ") + kOptions[i];
+    if (const char *x = getenv("LDPC_JIT_EXTRA_OPTS")) cmd += std::string(" ") + x;   // experiments; not part of the cache key
     cmd += " -x hip " + d + "/ldpc_jit.hip -o " + d + "/out.hsaco > " + d + "/log.txt 2>&1";
     int rc = system(cmd.c_str());
     bool ok = rc == 0 && read_all(d + "/out.hsaco", co);

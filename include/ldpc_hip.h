@@ -61,7 +61,6 @@ typedef enum { LDPC_TANH = 0, LDPC_MINSUM = 1, LDPC_TANH_CM = 2 } ldpc_variant;
  *      on-chip in f32 -- so for F16 the two paths are two different (documented) decoders, each with its own
  *      emulation in oracle/emulate_f16.py, whereas for F32/F64 they agree bit for bit. */
 typedef enum { LDPC_F32 = 0, LDPC_F64 = 1, LDPC_F16 = 2 } ldpc_dtype;
-/* which kernel family a context uses */
 /* message-passing schedule.  FLOODING: the reference's (Orig.hs:81-98: all checks, then all variables).
  * LAYERED (extension, no reference counterpart): checks layer by layer, each seeing the LLRs the layers before it
  * updated in the same sweep -- about half the sweeps to converge; stopping rule: before the first sweep the
@@ -69,10 +68,13 @@ typedef enum { LDPC_F32 = 0, LDPC_F64 = 1, LDPC_F16 = 2 } ldpc_dtype;
  * (specification: oracle/ldpc_oracle.c oracle_decode_layered); a frame out of sweeps returns the channel decisions,
  * as Orig.hs:70 does.  `iters` counts sweeps. */
 typedef enum { LDPC_SCHED_FLOODING = 0, LDPC_SCHED_LAYERED = 1 } ldpc_schedule;
+/* which kernel family a context uses */
 typedef enum {
-    LDPC_PATH_AUTO = 0,  /* fused on-chip kernel when the code/variant/dtype has one, else flood */
-    LDPC_PATH_FLOOD = 1, /* generic two-kernels-per-iteration path, state in HBM, any H          */
-    LDPC_PATH_FUSED = 2  /* whole decode in one launch, state in LDS/registers (QC codes)        */
+    LDPC_PATH_AUTO = 0,  /* on-chip kernel when the code/variant/dtype has one, else the HBM path */
+    LDPC_PATH_FLOOD = 1, /* state in HBM, any H: quasi-cyclic codes one workgroup per frame and ONE launch per batch (either
+                            schedule), any other H batch-major with two kernels per iteration                              */
+    LDPC_PATH_FUSED = 2  /* whole decode in one launch, state in LDS/registers: QC codes (built-in or run-time specialised
+                            instances) and any H whose frame fits in 160 KB of LDS; flooding schedule                      */
 } ldpc_path;
 
 /* ---- library life-cycle -------------------------------------------------------------------

@@ -211,7 +211,8 @@ int ldpc_decode_trace(ldpc_ctx *ctx, int max_iters, int batch, const double *llr
 
 /* ---- dominant-kernel timing (bench.py's `roofline` object) ---------------------------------------
  * When enabled, the context brackets every launch of its dominant kernel (fused: the one decode
- * kernel; flood: the check-node kernel) with HIP events on the stream the kernel is launched on.
+ * kernel; HBM path: the one decode kernel of a QC code, the check-node kernel otherwise) with HIP events on the stream the
+ * kernel is launched on.
  * ldpc_ctx_kernel_time drains them: number of launches and their summed duration (ms) since the
  * last call.  Blocks until the recorded launches have finished. */
 int ldpc_ctx_set_timing(ldpc_ctx *ctx, int enabled);
@@ -219,15 +220,16 @@ int ldpc_ctx_kernel_time(ldpc_ctx *ctx, int *launches, double *total_ms);
 /* name of that kernel as it appears in a rocprofv3 kernel trace (substring): the kernel family before the context's
  * first decode, narrowed to the launched template instance after it */
 const char *ldpc_ctx_kernel_name(const ldpc_ctx *ctx);
-/* launch geometry of that kernel after the first decode (fused paths: threads per workgroup and frames one workgroup
- * decodes; 0/0 for the flood path, whose kernels are not frame-per-workgroup) */
+/* launch geometry of that kernel after the first decode: threads per workgroup and frames one workgroup decodes (the
+ * on-chip kernels and the frame-per-workgroup HBM kernels of QC codes); 0/0 for the batch-major HBM kernels */
 int ldpc_ctx_kernel_geometry(const ldpc_ctx *ctx, int *threads_per_workgroup, int *frames_per_workgroup);
 
 /* ---- run-time specialised kernels ------------------------------------------------------------------
  * The fused kernels take the graph as compile-time constants.  For the shipped matrices those instances are built
  * ahead of time; for any other single-circulant quasi-cyclic H (what the reference's QC decoders accept,
- * Fast/Arraylet.hs:68-79) ldpc_ctx_create compiles one with hiprtc the first time and caches the code object on
- * disk (LDPC_JIT_CACHE, default jit_cache/ next to the library).  These entry points let a host warm that cache
+ * Fast/Arraylet.hs:68-79) ldpc_ctx_create compiles one the first time -- with the ROCm tool chain (hipcc --genco in a child
+ * process) when it is installed, else in-process with hiprtc; LDPC_JIT_COMPILER=hipcc|hiprtc forces one -- and caches the
+ * code object on disk (LDPC_JIT_CACHE, default jit_cache/ next to the library).  These entry points let a host warm that cache
  * ahead of time -- they need no GPU -- and look at what would be compiled.  LDPC_JIT=0 disables the mechanism
  * (table-driven / generic kernels are used instead). */
 const char *ldpc_jit_cache_dir(void);

@@ -2,7 +2,8 @@
 """bench.py -- decoded information Mbit/s of the LDPC BP decode path on MI355X.
 
   python bench.py --gpus N --steps K --warmup W
-  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+  N > 1, either way: `python bench.py --gpus N ...` starts its own N child ranks (ecc_ldpc_amd/launch.py; the parent never
+  touches the GPU), or `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...`
 
 A step = one pass of the hot path (ldpc_decode_batch_dev) over one batch of synthetic AWGN frames
 that are already resident in HBM.  Workload at every N: BASELINE.json's metric configuration --
@@ -48,6 +49,12 @@ def main():
                     "kernel-trace average covers full-size launches only)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python3 bench.py --gpus N` by itself: this parent starts one child process per GPU and relays rank 0's line.
+        # It must happen HERE, before torch or the HIP library is imported -- the parent never initialises the GPU
+        # and nothing is re-exec'ed (ecc_ldpc_amd/launch.py).
+        raise SystemExit(self_launch(args.gpus))
+
     import numpy as np
     import torch
     import ecc_ldpc_amd as E
@@ -55,10 +62,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if args.gpus > 1 and world == 1:
-        raise SystemExit("for --gpus > 1 launch through torch.distributed.run (one process per GPU)")
     # LDPC_BENCH_REHEARSE=1: run the N > 1 code path on a box with fewer GPUs than ranks (ranks share devices,
     # gloo instead of RCCL).  For checking the launch/sharding/tally logic only; its number is not a result.
     rehearse = os.environ.get("LDPC_BENCH_REHEARSE") == "1"
@@ -143,6 +148,9 @@ def main():
     from ecc_ldpc_amd import harness
     dist_mod = dist
     elapsed = harness.max_over_ranks(t1 - t0, dev, dist_mod)
+    rank_seconds = harness.per_rank(t1 - t0, dev, dist_mod)     # one entry per rank that took part in the collective
+    ones = torch.ones(1, dtype=torch.int64, device=dev)
+    harness.all_reduce_tallies(ones, dist_mod)                 # sum of ones over the data-path backend (RCCL unless rehearsing)
     harness.all_reduce_tallies(tally, dist_mod)  # the path's only collective: 32 bytes over RCCL/xGMI
     frames_total = world * args.steps * B
     value = frames_total * k / elapsed / 1e6
@@ -169,6 +177,9 @@ def main():
                                    f"Eb/N0={args.ebn0} dB, {B} frames/GPU/step", "code_name": ecc.name, "path": dec.path,
                        "batch_per_gpu": B, "parallelism": f"frames sharded over {world} GPU(s), tallies all-reduced"},
             **({"rehearsal": "ranks share GPUs over gloo; not a measurement"} if rehearse else {}),
+            "ranks_seen": int(ones.item()), "per_rank_ms_per_step": [round(s / args.steps * 1e3, 3) for s in rank_seconds],
+            "launcher": os.environ.get("LDPC_BENCH_LAUNCHER", "external" if "WORLD_SIZE" in os.environ else "none"),
+            "collective_backend": (dist.get_backend() if dist is not None else None),
             "roofline": roofline,
             **({"roofline_hbm_model": roofline_hbm} if roofline_hbm else {}),
             "proof_of_work": pow_obj,
@@ -186,6 +197,20 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def self_launch(n):
+    """Parent of an N-rank run (see main): builds the library once if this is a fresh checkout (so the ranks do not
+    race for it; _lib.py's file lock stays as the second line), then one child per rank with the same arguments."""
+    import subprocess
+    from ecc_ldpc_amd import launch     # standard library only: no torch, no libldpc_hip.so
+    so = os.path.join(ROOT, "ecc_ldpc_amd", "libldpc_hip.so")
+    if not os.path.exists(so) and "LDPC_SO" not in os.environ:
+        rc = subprocess.call([sys.executable, os.path.join(ROOT, "ecc_ldpc_amd", "build.py")], stdout=sys.stderr)
+        if rc != 0:
+            return rc
+    return launch.launch_ranks(n, [sys.executable, os.path.abspath(__file__)] + sys.argv[1:],
+                               timeout=float(os.environ.get("LDPC_BENCH_LAUNCH_TIMEOUT", "1500")))
 
 
 def proof_of_work_layered(args, E, ecc, dec, sim, llr_t, msg_t, bits, iters_t, conv_t, sp, f16, n):

@@ -570,8 +570,12 @@ static int decode_host(ldpc_ctx *ctx, int max_iters, int batch, const void *llr,
     // compute of the other workgroups.  Measured (65 536 jpl.4096 frames, min-sum): f32 26.9 ms vs 57.9 ms through
     // the chunked copy pipeline, fp16 LLRs 24.6 vs 44.7 ms (copies issued next to the decode kernel did not overlap
     // with it on this platform: pipeline time = copy time + kernel time).
-    if (!final_lam && !trace_lam && batch > ldpc_ctx::kSmallFrames &&
-        (ctx->path == LDPC_PATH_FLOOD || ldpc::fused_reads_llr_once(*ctx->fused, max_iters))) {
+    // (Not flood_qc_kernel: it re-reads the channel LLRs from the input in every variable-node pass, N values per frame
+    // and turn, which over PCIe would be ~70 GB for 65 536 jpl.4096 frames.  The batch-major flood kernels copy the
+    // input to their own `orig` once, the layered kernel reads it once into lam.)
+    const bool reads_once = ctx->path == LDPC_PATH_FLOOD ? (!ctx->lqc || ctx->schedule == LDPC_SCHED_LAYERED)
+                                                         : ldpc::fused_reads_llr_once(*ctx->fused, max_iters);
+    if (!final_lam && !trace_lam && batch > ldpc_ctx::kSmallFrames && reads_once) {
         void *z_llr = pinned_device_ptr(llr), *z_bits = pinned_device_ptr(bits);
         if (z_llr && z_bits) {
             int32_t *z_it = (int32_t *)pinned_device_ptr(iters);

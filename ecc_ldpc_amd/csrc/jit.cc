@@ -3,23 +3,33 @@
 //              the device headers are embedded in the library at build time (jit_embed.inc, build.py)
 //   compiler : `hipcc --genco` in a child process when the tool chain is installed, else hiprtc in-process (dlopen'ed:
 //              no link-time dependency); LDPC_JIT_COMPILER=hipcc|hiprtc forces one.  See jit_compile_cached for why.
-//   cache    : <cache dir>/<hash of source + options>.hsaco, written atomically; LDPC_JIT_CACHE names the directory
-//              (default: jit_cache/ next to libldpc_hip.so if writable, else ~/.cache/ecc_ldpc_amd, else /tmp)
+//   cache    : <cache dir>/<kernel>-<hash of source + options>[.rtc].hsaco, written atomically; LDPC_JIT_CACHE names the
+//              directory (default: jit_cache/ next to libldpc_hip.so if writable, else ~/.cache/ecc_ldpc_amd, else a
+//              0700 directory of this user under /tmp); builds with LDPC_JIT_EXTRA_OPTS or LDPC_JIT_NOCACHE=1 bypass it
 #include "jit.h"
 
 #include <dlfcn.h>
+#include <errno.h>
+#include <fcntl.h>
 #include <hip/hiprtc.h>
+#include <spawn.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <sys/stat.h>
+#include <sys/wait.h>
 #include <unistd.h>
 
 #include <algorithm>
 #include <chrono>
+#include <atomic>
 #include <fstream>
+#include <map>
+#include <memory>
 #include <mutex>
 #include <sstream>
+
+extern char **environ;
 
 #include "fused_common.h"
 
@@ -105,9 +115,15 @@ void pick_cache_dir() {
         cand.push_back((p == std::string::npos ? std::string(".") : d.substr(0, p)) + "/jit_cache");
     }
     if (const char *h = getenv("HOME")) { std::string c = std::string(h) + "/.cache"; (void)mkdir(c.c_str(), 0755); cand.push_back(c + "/ecc_ldpc_amd"); }
-    cand.push_back("/tmp/ecc_ldpc_amd_jit_" + std::to_string((unsigned)getuid()));
     for (auto &c : cand)
         if (dir_writable(c)) { g_cache_dir = c; return; }
+    // last resort, a world-writable parent: the directory is trusted only if it is OURS and nobody else can write to it
+    // (code objects found there are loaded and run)
+    const std::string t = "/tmp/ecc_ldpc_amd_jit_" + std::to_string((unsigned)getuid());
+    (void)mkdir(t.c_str(), 0700);
+    struct stat st;
+    if (lstat(t.c_str(), &st) == 0 && S_ISDIR(st.st_mode) && st.st_uid == getuid() && (st.st_mode & (S_IWGRP | S_IWOTH)) == 0 &&
+        access(t.c_str(), W_OK | X_OK) == 0) { g_cache_dir = t; return; }
     g_cache_dir = "";
 }
 
@@ -160,17 +176,48 @@ int compile_hipcc(const std::string &source, std::vector<char> &co) {
     std::string d(tmpl);
     for (int i = 0; i < kJitHeaderCount; i++) { std::ofstream f(d + "/" + kJitHeaders[i].name); f << kJitHeaders[i].text; }
     { std::ofstream f(d + "/ldpc_jit.hip"); f << source; }
-    const char *hipcc = getenv("HIPCC");
-    std::string cmd = std::string(hipcc ? hipcc : "/opt/rocm/bin/hipcc") + " --genco -DLDPC_JIT -I" + d;
-    for (int i = 0; i < kNumOptions; i++) cmd += std::string(" ") + kOptions[i];
-    if (const char *x = getenv("LDPC_JIT_EXTRA_OPTS")) cmd += std::string(" ") + x;   // experiments; not part of the cache key
-    cmd += " -x hip " + d + "/ldpc_jit.hip -o " + d + "/out.hsaco > " + d + "/log.txt 2>&1";
-    int rc = system(cmd.c_str());
+    const char *hipcc_env = getenv("HIPCC");
+    const std::string hipcc = hipcc_env ? hipcc_env : "/opt/rocm/bin/hipcc";
+    std::vector<std::string> av = {hipcc, "--genco", "-DLDPC_JIT", "-I" + d};
+    for (int i = 0; i < kNumOptions; i++) av.push_back(kOptions[i]);
+    if (const char *x = getenv("LDPC_JIT_EXTRA_OPTS")) { std::istringstream is(x); std::string t; while (is >> t) av.push_back(t); }   // experiments; such builds are never cached
+    av.insert(av.end(), {"-x", "hip", d + "/ldpc_jit.hip", "-o", d + "/out.hsaco"});
+    // The tool chain runs as a CHILD with a scrubbed environment: a profiler's preload (rocprofv3 sets LD_PRELOAD /
+    // HSA_TOOLS_LIB / ROCP_*) would otherwise initialise the GPU inside hipcc, which then exec's clang -- the
+    // exec-after-GPU-init chain this pool forbids.  Nothing of this process is replaced.
+    std::vector<std::string> envs;
+    for (char **e = environ; e && *e; e++) {
+        const char *v = *e;
+        static const char *const drop[] = {"LD_PRELOAD=", "HSA_TOOLS_LIB=", "HSA_TOOLS_REPORT_LOAD_FAILURE=", "ROCP_", "ROCPROF", "ROCTRACER_", "ROCTX_", "HIP_TOOLS_LIB="};
+        bool skip = false;
+        for (const char *p : drop) if (!strncmp(v, p, strlen(p))) skip = true;
+        if (!skip) envs.push_back(v);
+    }
+    std::vector<char *> argv_c, env_c;
+    for (auto &a : av) argv_c.push_back(&a[0]);
+    argv_c.push_back(nullptr);
+    for (auto &e : envs) env_c.push_back(&e[0]);
+    env_c.push_back(nullptr);
+    const std::string logp = d + "/log.txt";
+    posix_spawn_file_actions_t fa;
+    posix_spawn_file_actions_init(&fa);
+    posix_spawn_file_actions_addopen(&fa, 0, "/dev/null", O_RDONLY, 0);
+    posix_spawn_file_actions_addopen(&fa, 1, logp.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0600);
+    posix_spawn_file_actions_adddup2(&fa, 1, 2);
+    pid_t pid = 0;
+    int rc = posix_spawn(&pid, hipcc.c_str(), &fa, nullptr, argv_c.data(), env_c.data());
+    posix_spawn_file_actions_destroy(&fa);
+    if (rc == 0) {
+        int status = 0;
+        while (waitpid(pid, &status, 0) < 0 && errno == EINTR) {}
+        rc = WIFEXITED(status) ? WEXITSTATUS(status) : 128 + (WIFSIGNALED(status) ? WTERMSIG(status) : 0);
+    } else rc = -rc;
     bool ok = rc == 0 && read_all(d + "/out.hsaco", co);
     std::string log;
     if (!ok) { std::vector<char> l; if (read_all(d + "/log.txt", l)) log.assign(l.begin(), l.begin() + std::min<size_t>(l.size(), 380)); }
-    std::string rm = "rm -rf " + d;
-    (void)!system(rm.c_str());
+    for (int i = 0; i < kJitHeaderCount; i++) (void)unlink((d + "/" + kJitHeaders[i].name).c_str());
+    for (const char *f : {"/ldpc_jit.hip", "/out.hsaco", "/log.txt"}) (void)unlink((d + f).c_str());
+    (void)rmdir(d.c_str());
     if (!ok) return set_error(LDPC_EHIP, "hipcc --genco failed (%d): %s", rc, log.c_str());
     return LDPC_OK;
 }
@@ -196,49 +243,81 @@ const char *jit_cache_dir() {
     return g_cache_dir.c_str();
 }
 
+namespace {
+std::mutex g_key_mutexes_lock;
+std::map<std::string, std::shared_ptr<std::mutex>> g_key_mutexes;   // one compilation per key per process
+std::atomic<unsigned> g_tmp_counter{0};
+}  // namespace
+
 int jit_compile_cached(const std::string &source, const std::string &kernel_name, std::vector<char> &co, bool *from_cache, double *seconds) {
     std::string keyed = source;
     for (int i = 0; i < kNumOptions; i++) { keyed += "\n//opt "; keyed += kOptions[i]; }
     for (int i = 0; i < kJitHeaderCount; i++) { keyed += "\n//hdr "; keyed += kJitHeaders[i].name; keyed += hash_hex(kJitHeaders[i].text); }
     const std::string key = hash_hex(keyed);
     const std::string dir = jit_cache_dir();
-    const std::string path = dir.empty() ? std::string() : dir + "/" + kernel_name + "-" + key + ".hsaco";
-    if (from_cache) *from_cache = false;
-    if (seconds) *seconds = 0;
-    const char *nc = getenv("LDPC_JIT_NOCACHE");
-    if (!path.empty() && !(nc && !strcmp(nc, "1")) && read_all(path, co)) {
-        if (from_cache) *from_cache = true;
-        return LDPC_OK;
-    }
-    auto t0 = std::chrono::steady_clock::now();
-    const char *which = getenv("LDPC_JIT_COMPILER");
-    const bool only_hipcc = which && !strcmp(which, "hipcc"), only_hiprtc = which && !strcmp(which, "hiprtc");
     // Two routes to the same code object.  The tool chain (`hipcc --genco`, a child process) comes first when it is
     // installed: it is the compiler the built-in instances were built and tuned with, whereas the compiler behind
     // hiprtc is whatever libamd_comgr the PROCESS has loaded -- inside Python that is the copy bundled with the torch
     // wheel, an older LLVM than /opt/rocm's (measured on the jpl.4096-shaped kernel: 571 spilled VGPRs against 29,
     // 4.8x slower).  Without a tool chain (run-time-only ROCm installs) hiprtc compiles in-process.
-    // LDPC_JIT_COMPILER=hipcc|hiprtc forces one route.
+    // LDPC_JIT_COMPILER=hipcc|hiprtc forces one route.  The route is part of the cache file's name, so an object from
+    // the slower compiler never stands in for the tool chain's once that is available.
+    const char *which = getenv("LDPC_JIT_COMPILER");
+    const bool only_hipcc = which && !strcmp(which, "hipcc"), only_hiprtc = which && !strcmp(which, "hiprtc");
     const char *hipcc_path = getenv("HIPCC") ? getenv("HIPCC") : "/opt/rocm/bin/hipcc";
     const bool have_hipcc = access(hipcc_path, X_OK) == 0;
+    const bool want_hipcc = !only_hiprtc && (only_hipcc || have_hipcc);
+    const std::string stem = dir.empty() ? std::string() : dir + "/" + kernel_name + "-" + key;
+    const std::string path_cc = stem.empty() ? stem : stem + ".hsaco", path_rtc = stem.empty() ? stem : stem + ".rtc.hsaco";
+    if (from_cache) *from_cache = false;
+    if (seconds) *seconds = 0;
+    const char *nc = getenv("LDPC_JIT_NOCACHE");
+    const char *xo = getenv("LDPC_JIT_EXTRA_OPTS");
+    // experimental builds (extra options) and LDPC_JIT_NOCACHE=1 neither read nor WRITE the cache
+    const bool use_cache = !stem.empty() && !(nc && !strcmp(nc, "1")) && !(xo && *xo);
+    std::shared_ptr<std::mutex> km;
+    {
+        std::lock_guard<std::mutex> g(g_key_mutexes_lock);
+        auto &slot = g_key_mutexes[kernel_name + key];
+        if (!slot) slot = std::make_shared<std::mutex>();
+        km = slot;
+    }
+    std::lock_guard<std::mutex> one_at_a_time(*km);   // replicas created from several threads: the first compiles, the rest read
+    if (use_cache) {
+        // a tool-chain object is always acceptable; an in-process one only when the tool chain is not the route wanted
+        if (!only_hiprtc && read_all(path_cc, co)) { if (from_cache) *from_cache = true; return LDPC_OK; }
+        if (!want_hipcc && read_all(path_rtc, co)) { if (from_cache) *from_cache = true; return LDPC_OK; }
+    }
+    auto t0 = std::chrono::steady_clock::now();
     int rc;
+    bool by_hipcc = want_hipcc;
     if (only_hiprtc) rc = compile_hiprtc(source, co);
     else if (only_hipcc) rc = compile_hipcc(source, co);
     else {
         rc = have_hipcc ? compile_hipcc(source, co) : compile_hiprtc(source, co);
         if (rc != LDPC_OK && have_hipcc) {   // tool chain present but failing: the in-process compiler
             std::string first = ldpc_last_error();
+            by_hipcc = false;
             if (compile_hiprtc(source, co) != LDPC_OK) rc = set_error(LDPC_EHIP, "%s", first.c_str()); else rc = LDPC_OK;
         }
     }
     if (seconds) *seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     if (rc != LDPC_OK) return rc;
-    if (!path.empty()) {   // atomically: concurrent ranks may compile the same kernel
-        std::string tmp = path + ".tmp" + std::to_string((long)getpid());
-        std::ofstream f(tmp, std::ios::binary);
-        f.write(co.data(), (std::streamsize)co.size());
-        f.close();
-        if (!f || rename(tmp.c_str(), path.c_str()) != 0) (void)unlink(tmp.c_str());
+    if (use_cache) {   // atomically: concurrent ranks (processes) may compile the same kernel; the temp name is unique per writer
+        const std::string &path = by_hipcc ? path_cc : path_rtc;
+        std::string tmp = path + ".tmp" + std::to_string((long)getpid()) + "." + std::to_string(g_tmp_counter.fetch_add(1));
+        int fd = open(tmp.c_str(), O_WRONLY | O_CREAT | O_EXCL, 0644);
+        if (fd >= 0) {
+            size_t off = 0;
+            bool ok = true;
+            while (off < co.size()) {
+                ssize_t w = write(fd, co.data() + off, co.size() - off);
+                if (w <= 0) { ok = false; break; }
+                off += (size_t)w;
+            }
+            ok = (close(fd) == 0) && ok;
+            if (!ok || rename(tmp.c_str(), path.c_str()) != 0) (void)unlink(tmp.c_str());
+        }
     }
     return LDPC_OK;
 }

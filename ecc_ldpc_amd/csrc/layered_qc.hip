@@ -280,8 +280,10 @@ __global__ __launch_bounds__(1024, (DCLASS <= 8 && sizeof(CT) == 4 ? LQC_WAVES_L
         if (A.step_mode) { if (r == 0) A.st_syn[frame] = any ? 0 : 1; }
         else conv = !any;
     }
-    if (A.trace && !A.step_mode)
+    if (A.trace && !A.step_mode) {   // (uniform condition)
         for (int i = r; i < g.N; i += blockDim.x) A.trace[(frame * (A.max_iters + 1)) * (size_t)g.N + i] = (double)lam[i];
+        __syncthreads();             // no wave starts layer 0 (which writes lam) while another still copies row 0
+    }
     if (!conv) {
         for (n = 1; n <= A.max_iters; n++) {
             bool odd = false, flip = false;

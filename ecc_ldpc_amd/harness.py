@@ -51,6 +51,21 @@ def max_over_ranks(seconds: float, device, dist=None) -> float:
     return float(t.item())
 
 
+def per_rank(value: float, device, dist=None) -> list:
+    """-> [value of rank 0, value of rank 1, ...] on every rank (one all-gather of a double).  Its length is the number
+    of ranks that really took part in the collective: bench.py prints it as `ranks_seen`."""
+    import torch
+    multi = dist is not None and dist.is_initialized()
+    if not multi:
+        return [float(value)]
+    if dist.get_backend() == "gloo":
+        device = "cpu"
+    mine = torch.tensor([value], dtype=torch.float64, device=device)
+    out = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, mine)
+    return [float(t.item()) for t in out]
+
+
 def summarize(tally, k: int):
     frames, ferr, berr, its = [int(v) for v in tally.tolist()]
     return {"frames": frames, "fer": ferr / max(frames, 1), "ber": berr / max(frames * k, 1), "mean_iters": its / max(frames, 1)}

@@ -274,3 +274,30 @@ def test_zero_copy_host_path_equals_staged_path(hip, name, qc, path):
         got = dec.decode_batch(pin_in.array, 50, out_bits=pin_out.array)   # page-locked -> zero-copy
         assert got[0] is pin_out.array and all(np.array_equal(x, y) for x, y in zip(got, want))
         assert 0 < int(want[2].sum()) < B                      # a mixed batch
+
+
+def test_page_locked_input_on_the_hbm_paths(hip):
+    """flood_qc_kernel re-reads the channel LLRs every turn, so a page-locked input must NOT be handed to it as
+    a zero-copy device pointer (it is staged once instead); the layered kernel and the batch-major flood kernels read the
+    input once and do take it zero-copy.  Same answers as from pageable memory in all three cases, batch > 16."""
+    import os
+    c = load("jpl.1024.4.5")
+    B = 200
+    _, llr = c.frames(B, 3.0, seed=77)
+    src = llr.astype(np.float32)
+    pin_in = hip.PinnedArray((B, c.N), np.float32); pin_in.array[:] = src
+    pin_out = hip.PinnedArray((B, c.N), np.uint8)
+    for kw, env in (({"path": "flood"}, {}), ({"path": "flood", "schedule": "layered"}, {}), ({"path": "flood"}, {"LDPC_FLOOD_QC": "0"})):
+        old = {k: os.environ.get(k) for k in env}
+        os.environ.update(env)
+        try:
+            dec = hip.Decoder(c.hip_code(hip), "min", "f32", B, **kw)
+        finally:
+            for k, v in old.items():
+                os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
+        want = dec.decode_batch(src, 50)
+        pin_out.array[:] = 9
+        got = dec.decode_batch(pin_in.array, 50, out_bits=pin_out.array)
+        assert all(np.array_equal(x, y) for x, y in zip(got, want)), (kw, env, dec.kernel_name)
+        assert 0 < int(want[2].sum()) < B
+        dec.close()

@@ -69,6 +69,71 @@ def test_both_compiler_routes_build_the_same_kernel(tmp_path, monkeypatch):
     assert names["hiprtc"] == names["hipcc"]
 
 
+_CACHE_CHILD = """
+import os, sys, threading
+sys.path.insert(0, {root!r})
+import ecc_ldpc_amd as E
+from tests.helpers import synthetic
+code = synthetic("small-2x4-sz32").hip_code(E)
+mode = sys.argv[1]
+if mode == "threads":     # replicas created from several threads of one process compile the same kernel at once
+    res = []
+    ts = [threading.Thread(target=lambda: res.append(code.jit_prepare("min"))) for _ in range(4)]
+    [t.start() for t in ts]; [t.join() for t in ts]
+    print(sum(1 for r in res if not r[1]), len(res))
+else:
+    print(code.jit_prepare("min"))
+print(sorted(os.listdir(os.environ["LDPC_JIT_CACHE"])))
+"""
+
+
+def _cache_child(tmp_path, mode, **env):
+    import subprocess
+    import sys
+    from tests.helpers import ROOT
+    e = dict(os.environ, LDPC_JIT_CACHE=str(tmp_path / "cache"), **env)
+    os.makedirs(e["LDPC_JIT_CACHE"], exist_ok=True)
+    p = subprocess.run([sys.executable, "-c", _CACHE_CHILD.format(root=ROOT), mode], env=e, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-1500:]
+    return p.stdout.strip().splitlines()
+
+
+def test_cache_is_bypassed_by_experiments_and_keyed_by_compiler_route(tmp_path):
+    """an LDPC_JIT_EXTRA_OPTS or LDPC_JIT_NOCACHE=1 build must not become the object later runs load, and an
+    object from the in-process compiler must not stand in for the tool chain's."""
+    assert _cache_child(tmp_path, "one", LDPC_JIT_NOCACHE="1")[-1] == "[]"
+    assert _cache_child(tmp_path, "one", LDPC_JIT_EXTRA_OPTS="-DLDPC_EXPERIMENT=1")[-1] == "[]"
+    files = eval(_cache_child(tmp_path, "one", LDPC_JIT_COMPILER="hiprtc")[-1])
+    assert len(files) == 1 and files[0].endswith(".rtc.hsaco")
+    out = _cache_child(tmp_path, "one")                      # default route = tool chain: compiles its own, does not load the .rtc one
+    assert "False" in out[0]
+    files = eval(out[-1])
+    assert len(files) == 2 and sum(f.endswith(".rtc.hsaco") for f in files) == 1 and not any(".tmp" in f for f in files)
+    assert "True" in _cache_child(tmp_path, "one")[0]          # and now it is cached
+
+
+def test_threads_of_one_process_compile_a_kernel_once(tmp_path):
+    out = _cache_child(tmp_path, "threads")
+    compiled, total = map(int, out[0].split())
+    assert (compiled, total) == (1, 4)
+    files = eval(out[-1])
+    assert len(files) == 1 and files[0].endswith(".hsaco") and ".tmp" not in files[0]
+
+
+def test_tool_chain_child_runs_without_a_profilers_preload(tmp_path):
+    """under rocprofv3 the environment carries LD_PRELOAD / HSA_TOOLS_LIB / ROCP_*; hipcc (which exec's clang)
+    must not inherit them.  A fake hipcc records its environment and writes a dummy object."""
+    fake = tmp_path / "hipcc"
+    fake.write_text("#!/bin/sh\nenv > %s\nwhile [ $# -gt 1 ]; do [ \"$1\" = -o ] && out=$2; shift; done\nprintf 'x' > $out\n" % (tmp_path / "env.txt"))
+    fake.chmod(0o755)
+    _cache_child(tmp_path, "one", HIPCC=str(fake), LDPC_JIT_COMPILER="hipcc", LDPC_JIT_NOCACHE="1", ROCP_FAKE_TOOL="x.so",
+                 HSA_TOOLS_REPORT_LOAD_FAILURE="1", ROCPROF_FAKE_SETTING="1", LD_PRELOAD="", LDPC_KEEP_ME="1")
+    seen = (tmp_path / "env.txt").read_text()
+    assert "LDPC_KEEP_ME=1" in seen
+    for name in ("LD_PRELOAD=", "HSA_TOOLS_", "ROCP_FAKE_TOOL", "ROCPROF_FAKE_SETTING"):   # (names with the prefixes rocprofv3 sets, harmless here)
+        assert name not in seen, name
+
+
 @pytest.mark.gpu
 def test_a_hiprtc_compiled_kernel_runs_correctly(hip, tmp_path, monkeypatch):
     """the in-process route end to end on the GPU (the other tests hit whatever the default route cached)"""

@@ -280,7 +280,8 @@ def analyse(name, lines):
 
 def demangle(names):
     try:
-        p = subprocess.run(["c++filt"] + names, capture_output=True, text=True, timeout=60)
+        p = subprocess.run(["c++filt"] + names, capture_output=True, text=True, timeout=60,
+                           env={k: v for k, v in __import__("os").environ.items() if not k.startswith(("LD_PRELOAD", "HSA_TOOLS_", "ROCP_", "ROCPROF"))})
         d = p.stdout.strip().splitlines()
         if len(d) == len(names):
             return dict(zip(names, d))
@@ -315,7 +316,11 @@ def run_on_source(source_text, include_dir, kernel_regex=None, defines=("LDPC_JI
         open(src, "w").write(source_text)
         cmd = [hipcc, "-S", "--cuda-device-only", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-w",
                "-I" + include_dir] + ["-D" + x for x in defines] + ["-x", "hip", src, "-o", asm]
-        subprocess.run(cmd, check=True, capture_output=True, timeout=600)
+        # under a profiler (rocprofv3) the environment preloads a library that initialises the GPU in every child; hipcc
+        # exec's clang, and an exec after GPU initialisation takes the box down: the tool chain gets a scrubbed environment
+        drop = ("LD_PRELOAD", "HSA_TOOLS_", "ROCP_", "ROCPROF", "ROCTRACER_", "ROCTX_", "HIP_TOOLS_LIB")
+        env = {k: v for k, v in os.environ.items() if not k.startswith(drop)}
+        subprocess.run(cmd, check=True, capture_output=True, timeout=600, env=env)
         res = run([asm], kernel_regex)
         for r in res:
             r["source"] = "generated translation unit (jit.cc)"

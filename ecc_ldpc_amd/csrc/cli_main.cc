@@ -1,6 +1,8 @@
 // ecc-ldpc-hip -- native command-line driver over the C ABI of include/ldpc_hip.h, shaped like the reference's
 // executable (main/Main.hs:38-48, NOTES.txt:2-3):
-//     ecc-ldpc-hip <Eb/N0 values ...> <code names ...> [-m<frames>] [-b<batch>] [-s<seed>] [-d<dev>[,<dev>...]] [-t<rccl|host>] [-c<codes dir>]
+//     ecc-ldpc-hip <Eb/N0 values ...> <code names ...> [-m<frames>] [-b<batch>] [-s<seed>] [-d<dev>[,<dev>...]] [-t<rccl|host>] [-c<codes dir>] [--json]
+// (--json: each row additionally as one JSON object on its own line -- value in Mbit/s, ranks, per-rank seconds, tally route:
+//  the one-process twin of bench.py's N-rank line)
 // e.g.  ecc-ldpc-hip 2 3 4 ldpc/hip-minsum/jpl.1024.4.5/50/4/5 -m262144 -d0,1,2,3,4,5,6,7
 // Code names use the reference's grammar ldpc/<decoder>/<matrix>/<max-rounds>[/x/y] (Utils.hs:82-88,100-108),
 // <decoder> in {hip-tanh, hip-minsum}[-layered][-f32|-f64|-f16].  One row per (code, Eb/N0), like eccPrinter's (NOTES.txt:3):
@@ -56,6 +58,8 @@ struct Shared {
     Barrier *bar = nullptr;
     std::mutex mu;
     uint64_t host_sum[4] = {0, 0, 0, 0};
+    std::vector<double> rank_seconds;   // each rank's own generate+decode+tally time for the current row
+    bool json = false;
     int failed = 0;
     std::string err;
 };
@@ -103,6 +107,7 @@ void rank_main(Shared &S, int r) {
             if (rc != LDPC_OK) { ok = false; fail(S, ldpc_last_error()); }
         }
         if (st) (void)hipStreamSynchronize(st);
+        S.rank_seconds[r] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         S.bar->wait();                                   // every rank's frames are decoded: the row's wall time ends here
         const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         uint64_t t[4] = {0, 0, 0, 0};
@@ -129,6 +134,15 @@ void rank_main(Shared &S, int r) {
                    (unsigned long long)t[2], f > 0 ? (double)t[2] / (f * k) : 0.0, f > 0 ? (double)t[1] / f : 0.0, f > 0 ? (double)t[3] / f : 0.0,
                    f * k / dt / 1e6, ldpc_ctx_path(ctx) == LDPC_PATH_FUSED ? "fused" : "flood",
                    P > 1 ? (S.use_rccl ? (", " + std::to_string(P) + " GPUs, rccl").c_str() : (", " + std::to_string(P) + " ranks, host sum").c_str()) : "");
+            if (S.json) {
+                std::string per;
+                for (int i = 0; i < P; i++) per += (i ? ", " : "") + std::to_string(S.rank_seconds[i]);
+                printf("{\"metric\": \"decoded info Mbit/s\", \"value\": %.2f, \"unit\": \"Mbit/s\", \"code_name\": \"%s\", \"ebn0_db\": %g, \"ranks\": %d, "
+                       "\"tally\": \"%s\", \"frames\": %llu, \"frame_errors\": %llu, \"bit_errors\": %llu, \"mean_iters\": %.3f, \"seconds\": %.6f, "
+                       "\"per_rank_seconds\": [%s], \"batch\": %d, \"path\": \"%s\", \"process_model\": \"one process, one host thread per rank\"}\n",
+                       f * k / dt / 1e6, ldpc_ecc_name(S.ecc), db, P, S.use_rccl ? "rccl" : "host", (unsigned long long)t[0], (unsigned long long)t[1],
+                       (unsigned long long)t[2], f > 0 ? (double)t[3] / f : 0.0, dt, per.c_str(), S.batch, ldpc_ctx_path(ctx) == LDPC_PATH_FUSED ? "fused" : "flood");
+            }
             fflush(stdout);
         }
         if (S.failed) break;
@@ -199,6 +213,7 @@ int main(int argc, char **argv) {
         else if (!strncmp(a, "-t", 2)) tally = a + 2;
         else if (!strncmp(a, "-H", 2)) { harness = true; sscanf(a + 2, "%d,%d,%d", &h_threads, &h_coalesce, &h_wait); }
         else if (!strncmp(a, "-c", 2)) codes_dir = a + 2;
+        else if (!strcmp(a, "--json")) S.json = true;
         else {
             char *end = nullptr;
             double v = strtod(a, &end);
@@ -206,10 +221,11 @@ int main(int argc, char **argv) {
         }
     }
     if (S.ebn0s.empty() || names.empty() || S.frames <= 0 || S.batch <= 0 || S.devs.empty() || !(tally == "auto" || tally == "rccl" || tally == "host")) {
-        fprintf(stderr, "usage: %s <Eb/N0 values ...> <code names ...> [-m<frames>] [-b<batch>] [-s<seed>] [-d<dev>[,<dev>...]] [-t<rccl|host>] [-c<codes dir>]\n", argv[0]);
+        fprintf(stderr, "usage: %s <Eb/N0 values ...> <code names ...> [-m<frames>] [-b<batch>] [-s<seed>] [-d<dev>[,<dev>...]] [-t<rccl|host>] [-c<codes dir>] [--json]\n", argv[0]);
         return 2;
     }
     const int P = (int)S.devs.size();
+    S.rank_seconds.assign(P, 0.0);
     const bool distinct = std::set<int>(S.devs.begin(), S.devs.end()).size() == S.devs.size();
     S.use_rccl = tally == "rccl" || (tally == "auto" && P > 1 && distinct);
     if (S.use_rccl && !distinct) { fprintf(stderr, "-trccl needs distinct devices (RCCL has one rank per GPU); use -thost\n"); return 2; }

@@ -15,10 +15,10 @@ KEYS = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "
         "dtype", "data", "config", "roofline"}
 
 
-def _run(cmd, env=None, only_line=True):
+def _run(cmd, env=None, only_line=True, timeout=300):
     e = dict(os.environ)
     e.update(env or {})
-    p = subprocess.run(cmd, cwd=ROOT, env=e, capture_output=True, text=True, timeout=300)
+    p = subprocess.run(cmd, cwd=ROOT, env=e, capture_output=True, text=True, timeout=timeout)
     assert p.returncode == 0, p.stderr[-2000:]
     lines = [l for l in p.stdout.splitlines() if l.strip()]
     if only_line:
@@ -60,6 +60,60 @@ def test_two_ranks_rehearsal_aggregates_over_ranks():
              env={"LDPC_BENCH_REHEARSE": "1"}, only_line=False)
     assert d["n_gpus"] == 2 and "rehearsal" in d and "cpu_baseline" not in d
     assert abs(d["value"] - 2 * 2 * 2048 * 4096 / (d["ms_per_step"] * 2e-3) / 1e6) / d["value"] < 0.02   # whole-job aggregate
+
+
+def test_bench_starts_its_own_ranks():
+    """The driver's command shape for N > 1 WITHOUT a launcher: `python3 bench.py --gpus 2 --steps 2 --warmup 1` (the headline
+    workload at its full batch).  The parent never touches the GPU; two child ranks share this box's one GPU (rehearsal:
+    gloo instead of RCCL, which refuses two ranks on one device).  One JSON line, both ranks took part in the collectives."""
+    env = {"LDPC_BENCH_REHEARSE": "1"}
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        os.environ.pop(k, None)
+    d = _run(["python3", "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1"], env=env, only_line=False, timeout=900)
+    assert d["n_gpus"] == 2 and d["ranks_seen"] == 2 and len(d["per_rank_ms_per_step"]) == 2 and d["launcher"] == "self"
+    assert d["steps"] == 2 and d["warmup"] == 1 and d["config"]["batch_per_gpu"] == 65536 and "cpu_baseline" not in d
+    assert max(d["per_rank_ms_per_step"]) == d["ms_per_step"]
+    assert abs(d["value"] - 2 * 2 * 65536 * 4096 / (d["ms_per_step"] * 2e-3) / 1e6) / d["value"] < 0.02   # whole-job aggregate
+    assert d["proof_of_work"]["ok"]
+
+
+def test_bench_starts_its_own_ranks_on_a_fresh_jit_cache(tmp_path):
+    """Two ranks that both need a run-time specialised kernel nobody has built yet (empty cache directory): they compile
+    it concurrently, each renames its own temp file into place, both load a whole code object."""
+    from tests.helpers import synthetic   # a synthetic QC shape goes through jit.cc; bench.py takes shipped codes only, so drive the library directly
+    import textwrap
+    child = tmp_path / "rank.py"
+    child.write_text(textwrap.dedent(f"""
+        import os, sys
+        sys.path.insert(0, {ROOT!r})
+        import numpy as np
+        import ecc_ldpc_amd as E
+        from tests.helpers import synthetic
+        from oracle import oracle
+        E.init(0)
+        c = synthetic("small-2x4-sz32")
+        _, llr = c.frames(32, 4.0, seed=5)
+        dec = E.Decoder(c.hip_code(E), "min", "f32", 32)
+        assert dec.kernel_name.startswith("ldpc_jit_split_")
+        bits, its, conv = dec.decode_batch(llr.astype(np.float32), 30)
+        ob, oi, oc = oracle.decode_batch(c.graph, "min", 30, llr, nthreads=2)
+        assert np.array_equal(bits, ob) and np.array_equal(conv, oc)
+        if os.environ["RANK"] == "0":
+            print("ok", sorted(os.listdir(os.environ["LDPC_JIT_CACHE"])))
+    """))
+    import io
+    from ecc_ldpc_amd import launch
+    cache = tmp_path / "cache"
+    cache.mkdir()
+    os.environ["LDPC_JIT_CACHE"] = str(cache)
+    try:
+        out, err = io.BytesIO(), io.BytesIO()
+        rc = launch.launch_ranks(2, [sys.executable, str(child)], timeout=600, stdout=out, stderr=err)
+    finally:
+        del os.environ["LDPC_JIT_CACHE"]
+    assert rc == 0, err.getvalue().decode()[-2000:]
+    files = os.listdir(cache)
+    assert out.getvalue().decode().startswith("ok") and len(files) == 1 and files[0].endswith(".hsaco")
 
 
 def test_early_exit_is_priced_by_the_iterations_run():

@@ -169,3 +169,10 @@ def test_native_cli_ranks(hip):
     assert "ranks," in " ".join(two[0]) and "rccl" not in " ".join(one[0])
     p = subprocess.run([CLI] + args + ["-d0,0", "-trccl"], capture_output=True, text=True, timeout=60)
     assert p.returncode == 2 and "distinct" in p.stderr
+    # --json: the one-process twin of bench.py's N-rank line
+    import json
+    p = subprocess.run([CLI] + args + ["-d0,0", "-thost", "--json"], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr
+    js = [json.loads(l) for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(js) == 1 and js[0]["ranks"] == 2 and js[0]["tally"] == "host" and len(js[0]["per_rank_seconds"]) == 2
+    assert js[0]["frames"] == 20000 and str(js[0]["bit_errors"]) == one[0][4] and js[0]["value"] > 0 and js[0]["unit"] == "Mbit/s"

@@ -37,6 +37,7 @@ ABI_SYMBOLS = [
     "ldpc_host_alloc", "ldpc_host_free",
     "ldpc_ctx_set_timing", "ldpc_ctx_kernel_time", "ldpc_ctx_kernel_name", "ldpc_ctx_kernel_geometry", "ldpc_jit_cache_dir", "ldpc_jit_source", "ldpc_jit_prepare",
     "ldpc_sim_create", "ldpc_sim_destroy", "ldpc_sim_generate", "ldpc_sim_tally", "ldpc_sim_encode_host",
+    "ldpc_sim_create_qc_on", "ldpc_sim_encoder", "ldpc_sim_encode_batch", "ldpc_matrix_qc_words",
     "ldpc_matrix_load", "ldpc_matrix_load_mackay", "ldpc_matrix_destroy", "ldpc_matrix_info", "ldpc_matrix_dense",
     "ldpc_matrix_qc_offsets", "ldpc_code_from_matrix",
     "ldpc_ecc_create", "ldpc_ecc_destroy", "ldpc_ecc_name", "ldpc_ecc_message_length", "ldpc_ecc_codeword_length",
@@ -196,6 +197,11 @@ def lib():
     L.ldpc_sim_generate_f16.argtypes = [vp, C.c_uint64, C.c_uint64, C.c_int, C.c_double, vp, vp, vp]
     L.ldpc_sim_tally.argtypes = [vp, C.c_int, vp, vp, vp, vp]
     L.ldpc_sim_encode_host.argtypes = [vp, u8p, u8p]
+    L.ldpc_sim_create_qc_on.restype = vp
+    L.ldpc_sim_create_qc_on.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint32), C.c_int]
+    L.ldpc_sim_encoder.argtypes = [vp]
+    L.ldpc_sim_encode_batch.argtypes = [vp, C.c_uint64, C.c_uint64, C.c_int, vp, vp, vp]
+    L.ldpc_matrix_qc_words.argtypes = [vp, C.POINTER(C.c_uint32)]
     L.ldpc_matrix_load.restype = vp
     L.ldpc_matrix_load.argtypes = [C.c_char_p, C.c_char_p]
     L.ldpc_matrix_load_mackay.restype = vp
@@ -564,6 +570,12 @@ class Matrix:
         check(lib().ldpc_matrix_dense(self._h, ptr(out, C.c_uint8)))
         return out
 
+    def qc_words(self):
+        """first-row patterns of a QC source as little-endian 32-bit words [block_rows][block_cols][ceil(sz/32)]"""
+        out = np.zeros((self.block_rows, self.block_cols, (self.sz + 31) // 32), np.uint32)
+        check(lib().ldpc_matrix_qc_words(self._h, ptr(out, C.c_uint32)))
+        return out
+
     def qc_offsets(self):
         out = np.zeros((self.block_rows, self.block_cols), np.int32)
         check(lib().ldpc_matrix_qc_offsets(self._h, ptr(out, C.c_int32)))
@@ -586,14 +598,20 @@ class Matrix:
 class Sim:
     """Device-side frame source + error tally (ldpc_sim)."""
 
-    def __init__(self, code: Code, k, n_tx, G=None, max_batch=64, _handle=None, device=None):
+    def __init__(self, code: Code, k, n_tx, G=None, max_batch=64, _handle=None, device=None, G_qc=None):
+        """G: dense generator [k][p] bytes; G_qc = (sz, words [block_rows][block_cols][sz/32] uint32): the quasi-cyclic form
+        (Matrix.qc_words), encoded by rotate-and-xor like Fast/Encoder.hs; neither: all-zero codewords"""
         self.code, self.k, self.n_tx = code, int(k), int(n_tx)
         self._owned = _handle is None
         if _handle is None:
             dev = int(device) if device is not None else lib().ldpc_current_device()
             if dev < 0:
                 raise LdpcError(ENODEVICE, "ldpc_init() has not succeeded")
-            if G is not None:
+            if G_qc is not None:
+                sz, words = G_qc
+                words = np.ascontiguousarray(words, np.uint32)
+                _handle = lib().ldpc_sim_create_qc_on(code._h, dev, int(k), int(n_tx), int(sz), words.shape[0], words.shape[1], ptr(words, C.c_uint32), int(max_batch))
+            elif G is not None:
                 G = np.ascontiguousarray(G, np.uint8)
                 assert G.shape[0] == k
                 _handle = lib().ldpc_sim_create_on(code._h, dev, int(k), int(n_tx), G.shape[1], ptr(G, C.c_uint8), int(max_batch))
@@ -607,6 +625,14 @@ class Sim:
     def generate(self, seed, first_frame, batch, ebn0_db, d_llr_ptr, d_msg_ptr=None, stream=None, llr_f16=False):
         fn = lib().ldpc_sim_generate_f16 if llr_f16 else lib().ldpc_sim_generate
         check(fn(self._h, int(seed), int(first_frame), int(batch), float(ebn0_db), d_llr_ptr, d_msg_ptr, stream))
+
+    @property
+    def encoder(self):
+        return {0: "none", 1: "dense", 2: "qc"}[lib().ldpc_sim_encoder(self._h)]
+
+    def encode_batch(self, seed, first_frame, batch, d_codewords_ptr, d_msg_ptr=None, stream=None):
+        """the encoder alone: codewords [batch][n_tx] bytes on the device"""
+        check(lib().ldpc_sim_encode_batch(self._h, int(seed), int(first_frame), int(batch), d_codewords_ptr, d_msg_ptr, stream))
 
     def tally(self, batch, d_bits_ptr, d_iters_ptr, d_tally_ptr, stream=None):
         check(lib().ldpc_sim_tally(self._h, int(batch), d_bits_ptr, d_iters_ptr, d_tally_ptr, stream))

@@ -830,8 +830,9 @@ int ldpc_jit_prepare(const ldpc_code *code, int variant, int dtype, char *kernel
 struct ldpc_sim {
     ldpc::SimDev dev{};
     int p = 0, max_batch = 0, device = 0;
-    std::vector<uint32_t> gt_host;
-    uint32_t *d_gt = nullptr, *d_msgw = nullptr;
+    std::vector<uint32_t> gt_host;     // dense generator, packed columns (host encode)
+    std::vector<uint32_t> qc_host;     // quasi-cyclic generator: [brows][bcols][W] first-row words
+    uint32_t *d_gt = nullptr, *d_msgw = nullptr, *d_rot = nullptr, *d_parw = nullptr;
 };
 extern "C" {
 
@@ -839,6 +840,8 @@ void ldpc_sim_destroy(ldpc_sim *sim) {
     if (!sim) return;
     (void)hipSetDevice(sim->device);
     hipFree(sim->d_gt);
+    hipFree(sim->d_rot);
+    hipFree(sim->d_parw);
     hipFree(sim->d_msgw);
     delete sim;
 }
@@ -849,16 +852,23 @@ ldpc_sim *ldpc_sim_create(const ldpc_code *code, int k, int n_tx, int p, const u
     return ldpc_sim_create_on(code, device, k, n_tx, p, G, max_batch);
 }
 
+static ldpc_sim *sim_new(const ldpc_code *code, int device, int k, int n_tx, int max_batch) {
+    if (check_device(device) != LDPC_OK) return nullptr;
+    ldpc_sim *s = new (std::nothrow) ldpc_sim();
+    if (!s) { set_error(LDPC_ENOMEM, "out of host memory"); return nullptr; }
+    s->device = device; s->max_batch = max_batch;
+    s->dev.N = code->N; s->dev.k = k; s->dev.n_tx = n_tx; s->dev.kwords = (k + 31) / 32; s->dev.gt = nullptr; s->dev.qc_rot = nullptr;
+    return s;
+}
+
 ldpc_sim *ldpc_sim_create_on(const ldpc_code *code, int device, int k, int n_tx, int p, const uint8_t *G, int max_batch) {
     if (!code || k <= 0 || n_tx < k || n_tx > code->N || max_batch <= 0 || (G && (p <= 0 || k + p < n_tx))) {
         set_error(LDPC_EINVAL, "ldpc_sim_create: bad arguments (k=%d n_tx=%d p=%d N=%d)", k, n_tx, p, code ? code->N : -1);
         return nullptr;
     }
-    if (check_device(device) != LDPC_OK) return nullptr;
-    ldpc_sim *s = new (std::nothrow) ldpc_sim();
-    if (!s) { set_error(LDPC_ENOMEM, "out of host memory"); return nullptr; }
-    s->device = device; s->p = G ? p : 0; s->max_batch = max_batch;
-    s->dev.N = code->N; s->dev.k = k; s->dev.n_tx = n_tx; s->dev.kwords = (k + 31) / 32; s->dev.gt = nullptr;
+    ldpc_sim *s = sim_new(code, device, k, n_tx, max_batch);
+    if (!s) return nullptr;
+    s->p = G ? p : 0;
     hipError_t e = hipSetDevice(device);
     if (e == hipSuccess && G) {
         s->gt_host.assign((size_t)p * s->dev.kwords, 0u);
@@ -881,12 +891,57 @@ ldpc_sim *ldpc_sim_create_on(const ldpc_code *code, int device, int k, int n_tx,
     return s;
 }
 
-static int sim_generate_any(ldpc_sim *sim, uint64_t seed, uint64_t first_frame, int batch, double ebn0_db, void *d_llr,
-                            int llr_f16, uint8_t *d_msg, void *stream) {
-    if (!sim || !d_llr || batch < 0 || batch > sim->max_batch) return set_error(LDPC_EINVAL, "ldpc_sim_generate: bad arguments");
+// The generator in the reference's quasi-cyclic form (Fast/Encoder.hs:26-40: sz in {32, 64, 128, 256}, one machine word
+// of sz bits per circulant = the integer of the .q file, bit b = first-row entry of column b).
+ldpc_sim *ldpc_sim_create_qc_on(const ldpc_code *code, int device, int k, int n_tx, int sz, int block_rows, int block_cols,
+                                const uint32_t *circ, int max_batch) {
+    if (!code || !circ || sz <= 0 || block_rows <= 0 || block_cols <= 0 || max_batch <= 0 || k != sz * block_rows || n_tx < k || n_tx > code->N ||
+        (long)k + (long)sz * block_cols < n_tx) {
+        set_error(LDPC_EINVAL, "ldpc_sim_create_qc: bad arguments (k=%d n_tx=%d sz=%d blocks %dx%d N=%d)", k, n_tx, sz, block_rows, block_cols, code ? code->N : -1);
+        return nullptr;
+    }
+    if (sz != 32 && sz != 64 && sz != 128 && sz != 256) {   // Fast/Encoder.hs:33 "unsupported size for fast encoder"
+        set_error(LDPC_EUNSUPPORTED, "unsupported size for fast encoder : %d (32, 64, 128, 256; give the dense generator to ldpc_sim_create instead)", sz);
+        return nullptr;
+    }
+    ldpc_sim *s = sim_new(code, device, k, n_tx, max_batch);
+    if (!s) return nullptr;
+    const int W = sz / 32, CB = 16 / W, ncg = (block_cols + CB - 1) / CB;
+    s->p = sz * block_cols;
+    s->qc_host.assign(circ, circ + (size_t)block_rows * block_cols * W);
+    s->dev.qc_w = W; s->dev.qc_brows = block_rows; s->dev.qc_bcols = block_cols; s->dev.qc_ncg = ncg; s->dev.pwords = block_cols * W;
+    // rot[cg][r][b][c in group][w] = word w of rotateL(g[r][c], b)
+    std::vector<uint32_t> rot((size_t)ncg * block_rows * 32 * 16, 0u);
+    for (int bc = 0; bc < block_cols; bc++)
+        for (int r = 0; r < block_rows; r++) {
+            const uint32_t *g = &circ[((size_t)r * block_cols + bc) * W];
+            for (int b = 0; b < 32; b++)
+                for (int w = 0; w < W; w++) {
+                    const uint32_t lo = g[w], hi = g[(w + W - 1) % W];
+                    rot[(((size_t)(bc / CB) * block_rows + r) * 32 + b) * 16 + (bc % CB) * W + w] = b ? ((lo << b) | (hi >> (32 - b))) : lo;
+                }
+        }
+    hipError_t e = hipSetDevice(device);
+    if (e == hipSuccess) e = hipMalloc((void **)&s->d_rot, rot.size() * 4);
+    if (e == hipSuccess) e = hipMemcpy(s->d_rot, rot.data(), rot.size() * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMalloc((void **)&s->d_parw, (size_t)max_batch * s->dev.pwords * 4);
+    if (e == hipSuccess) e = hipMalloc((void **)&s->d_msgw, (size_t)max_batch * s->dev.kwords * 4);
+    s->dev.qc_rot = s->d_rot;
+    if (e != hipSuccess) { set_error(LDPC_EHIP, "ldpc_sim_create_qc: %s", hipGetErrorString(e)); ldpc_sim_destroy(s); return nullptr; }
+    return s;
+}
+
+int ldpc_sim_encoder(const ldpc_sim *sim) {
+    if (!sim) return set_error(LDPC_EINVAL, "null sim");
+    return sim->dev.qc_rot ? LDPC_ENCODER_QC : (sim->dev.gt ? LDPC_ENCODER_DENSE : LDPC_ENCODER_NONE);
+}
+
+static int sim_generate_any(ldpc_sim *sim, uint64_t seed, uint64_t first_frame, int batch, double ebn0_db, void *d_out,
+                            int out_fmt, uint8_t *d_msg, void *stream) {
+    if (!sim || !d_out || batch < 0 || batch > sim->max_batch) return set_error(LDPC_EINVAL, "ldpc_sim_generate: bad arguments");
     if (batch == 0) return LDPC_OK;
     HIPCHK(hipSetDevice(sim->device));
-    return ldpc::sim_generate(sim->dev, sim->d_msgw, (hipStream_t)stream, seed, first_frame, batch, ebn0_db, d_llr, llr_f16, d_msg);
+    return ldpc::sim_generate(sim->dev, sim->d_msgw, sim->d_parw, (hipStream_t)stream, seed, first_frame, batch, ebn0_db, d_out, out_fmt, d_msg);
 }
 
 int ldpc_sim_generate(ldpc_sim *sim, uint64_t seed, uint64_t first_frame, int batch, double ebn0_db, float *d_llr,
@@ -897,6 +952,10 @@ int ldpc_sim_generate(ldpc_sim *sim, uint64_t seed, uint64_t first_frame, int ba
 int ldpc_sim_generate_f16(ldpc_sim *sim, uint64_t seed, uint64_t first_frame, int batch, double ebn0_db, uint16_t *d_llr,
                           uint8_t *d_msg, void *stream) {
     return sim_generate_any(sim, seed, first_frame, batch, ebn0_db, d_llr, 1, d_msg, stream);
+}
+
+int ldpc_sim_encode_batch(ldpc_sim *sim, uint64_t seed, uint64_t first_frame, int batch, uint8_t *d_codewords, uint8_t *d_msg, void *stream) {
+    return sim_generate_any(sim, seed, first_frame, batch, 0.0, d_codewords, 2, d_msg, stream);
 }
 
 int ldpc_sim_tally(ldpc_sim *sim, int batch, const uint8_t *d_bits, const int32_t *d_iters, uint64_t *d_tally, void *stream) {
@@ -911,6 +970,28 @@ int ldpc_sim_encode_host(const ldpc_sim *sim, const uint8_t *msg, uint8_t *parit
     const int kw = sim->dev.kwords;
     std::vector<uint32_t> mw((size_t)kw, 0u);
     for (int r = 0; r < sim->dev.k; r++) if (msg[r]) mw[r >> 5] |= 1u << (r & 31);
+    if (!sim->qc_host.empty()) {
+        // Fast/Encoder.hs:42-63 word by word: res[col] = XOR_row mulWord(v'[row], g[row][col]), mulWord = rotate-and-xor
+        // over the set bits of the message word
+        const int W = sim->dev.qc_w, R = sim->dev.qc_brows, Cc = sim->dev.qc_bcols, sz = 32 * W;
+        std::vector<uint32_t> res((size_t)W), rotd((size_t)W);
+        for (int c = 0; c < Cc; c++) {
+            std::fill(res.begin(), res.end(), 0u);
+            for (int r = 0; r < R; r++) {
+                const uint32_t *g = &sim->qc_host[((size_t)r * Cc + c) * W];
+                for (int n = 0; n < sz; n++) {
+                    if (!((mw[(size_t)r * W + (n >> 5)] >> (n & 31)) & 1u)) continue;
+                    const int a = n >> 5, b = n & 31;
+                    for (int w = 0; w < W; w++) {
+                        const uint32_t lo = g[(w - a + W) % W], hi = g[(w - a - 1 + 2 * W) % W];
+                        res[w] ^= b ? ((lo << b) | (hi >> (32 - b))) : lo;
+                    }
+                }
+            }
+            for (int j = 0; j < sz; j++) parity[(size_t)c * sz + j] = (uint8_t)((res[j >> 5] >> (j & 31)) & 1u);
+        }
+        return LDPC_OK;
+    }
     for (int j = 0; j < sim->p; j++) {
         uint32_t acc = 0;
         for (int w = 0; w < kw; w++) acc ^= mw[w] & sim->gt_host[(size_t)j * kw + w];

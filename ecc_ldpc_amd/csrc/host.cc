@@ -294,6 +294,21 @@ int ldpc_matrix_dense(const ldpc_matrix *m, uint8_t *out) {
     return LDPC_OK;
 }
 
+// Fast/Encoder.hs:38-39 `fmap fromIntegral m`: the Integer of each block as sz-bit machine word(s)
+int ldpc_matrix_qc_words(const ldpc_matrix *m, uint32_t *out) {
+    if (!m || !out) return set_error(LDPC_EINVAL, "null argument");
+    if (m->sz == 0) return set_error(LDPC_EUNSUPPORTED, "can not load %s as QuasiCyclic", m->source.c_str());
+    const int W = (m->sz + 31) / 32;
+    for (size_t i = 0; i < m->blocks.size(); i++)
+        for (int w = 0; w < W; w++) {
+            uint32_t v = (size_t)w < m->blocks[i].size() ? m->blocks[i][w] : 0u;
+            const int rem = m->sz - 32 * w;               // fromIntegral truncates to the word size
+            if (rem < 32) v &= (1u << rem) - 1u;
+            out[i * W + w] = v;
+        }
+    return LDPC_OK;
+}
+
 // Fast/Arraylet.hs:68-79 initMatrixlet / GPU/CUDA/Arraylet2.hs:299-331: rotation table, -1 = empty;
 // a block with more than one circulant is an error there and LDPC_EUNSUPPORTED here.
 int ldpc_matrix_qc_offsets(const ldpc_matrix *m, int32_t *offsets) {
@@ -506,11 +521,23 @@ ldpc_ecc *ldpc_ecc_create_replicas(const char *codes_dir, const char *code_name,
             const char *pe = getenv("LDPC_HIP_PATH");
             if (pe && !strcmp(pe, "flood")) path = LDPC_PATH_FLOOD;
             else if (pe && !strcmp(pe, "fused")) path = LDPC_PATH_FUSED;
+            // encoder: a quasi-cyclic G of a word size the reference's fast encoder takes (Fast/Encoder.hs:28-33) is encoded
+            // from its circulants (rotate-and-xor, sim.hip); anything else from the expanded matrix (Orig.hs:25-26).
+            // LDPC_SIM_ENCODER=dense forces the expanded form (A/B measurements, tests).
             std::vector<uint8_t> gd;
+            std::vector<uint32_t> gq;
+            const char *enc_env = getenv("LDPC_SIM_ENCODER");
+            const bool g_qc = g && g->sz > 0 && (g->sz == 32 || g->sz == 64 || g->sz == 128 || g->sz == 256) && g->rows == e->message_length &&
+                              !(enc_env && !strcmp(enc_env, "dense"));
             if (g) {
-                gd.resize((size_t)g->rows * g->cols);
-                if (ldpc_matrix_dense(g, gd.data()) != LDPC_OK) goto fail;
                 e->parity_len = g->cols;
+                if (g_qc) {
+                    gq.resize((size_t)g->brows * g->bcols * (g->sz / 32));
+                    if (ldpc_matrix_qc_words(g, gq.data()) != LDPC_OK) goto fail;
+                } else {
+                    gd.resize((size_t)g->rows * g->cols);
+                    if (ldpc_matrix_dense(g, gd.data()) != LDPC_OK) goto fail;
+                }
             }
             for (int i = 0; i < n_replicas; i++) {
                 std::unique_ptr<ldpc_ecc_replica> r(new ldpc_ecc_replica());
@@ -523,7 +550,8 @@ ldpc_ecc *ldpc_ecc_create_replicas(const char *codes_dir, const char *code_name,
                 e->reps.push_back(std::move(r));      // owned by the record from here on (ldpc_ecc_destroy frees it)
                 if (!rp->ctx) goto fail;
                 rp->device = ldpc_ctx_device(rp->ctx);
-                rp->sim = ldpc_sim_create_on(e->code, rp->device, e->message_length, e->codeword_length, g ? g->cols : 0, g ? gd.data() : nullptr, max_batch);
+                rp->sim = g_qc ? ldpc_sim_create_qc_on(e->code, rp->device, e->message_length, e->codeword_length, g->sz, g->brows, g->bcols, gq.data(), max_batch)
+                               : ldpc_sim_create_on(e->code, rp->device, e->message_length, e->codeword_length, g ? g->cols : 0, g ? gd.data() : nullptr, max_batch);
                 if (!rp->sim) goto fail;
                 rp->llr_buf.assign((size_t)e->unpunctured_length, 0.0);
                 rp->bits_buf.assign((size_t)e->unpunctured_length, 0);

@@ -51,11 +51,90 @@ __global__ void sim_msg_kernel(uint32_t *msgw, int kwords, int k, uint64_t seed,
     msgw[i] = v;
 }
 
+// Quasi-cyclic encoder, the reference's formulation (Fast/Encoder.hs:42-63): the message is cut into sz-bit words v'[r],
+// the parity word of block column c is  XOR_r mulWord(v'[r], g[r][c]),  mulWord(w1, w2) = XOR over the set bits n of w1 of
+// rotateL(w2, n).  Here: LANE = FRAME, a wave = 64 frames x one group of 16/W block columns (W = sz/32 machine words per
+// circulant).  The generator is never expanded: for n = 32a + b, word w of rotateL(g, n) is word (w - a) mod W of
+// rotateL(g, b), so a table of the 32 bit-rotations of every circulant (scalar loads: 16 words per (r, b), the same for
+// all lanes) is all that is read -- 32 x 12 x 32 x 4 words = 196 KB for jpl.4096 instead of the 786 KB dense k x p matrix,
+// and it grows with k + p, not k * p.  Per message bit and parity word: one v_bitop3 (acc ^= mask & T), the mask (0 / -1
+// from bit b of the lane's message word) shared by the 16/W columns of the group.
+// The four waves of a workgroup share the 64 frames and the column group and split the block rows; their partial parity
+// words meet in LDS (XOR is associative: any split gives the same bits).  4x the waves of a one-wave version: the scalar
+// table loads of one wave hide behind the XORs of the others (jpl.4096, 65 536 frames: 0.91 -> see profiles/r03_encoder_rate.txt).
+constexpr int kQcRowSplit = 4;
+template <int W>
+__global__ __launch_bounds__(64 * kQcRowSplit) void sim_parity_qc_kernel(const uint32_t *__restrict__ rot, int brows, int bcols, const uint32_t *__restrict__ msgw,
+                                                                         uint32_t *__restrict__ parw, int kwords, int pwords, int batch) {
+    constexpr int CB = 16 / W;
+    __shared__ uint32_t part[kQcRowSplit - 1][16][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int f = blockIdx.x * 64 + lane;
+    const int cg = blockIdx.y;
+    const bool live = f < batch;
+    const int rchunk = (brows + kQcRowSplit - 1) / kQcRowSplit;
+    const int r_begin = __builtin_amdgcn_readfirstlane(wave * rchunk), r_end = min(brows, r_begin + rchunk);
+    const uint32_t *mw = msgw + (size_t)(live ? f : 0) * kwords;
+    const uint32_t *t = rot + (size_t)cg * brows * (32 * 16);
+    uint32_t acc[CB][W];
+#pragma unroll
+    for (int c = 0; c < CB; c++)
+#pragma unroll
+        for (int w = 0; w < W; w++) acc[c][w] = 0u;
+    for (int r = r_begin; r < r_end; r++) {
+        uint32_t v[W];
+#pragma unroll
+        for (int a = 0; a < W; a++) v[a] = mw[r * W + a];
+#pragma unroll
+        for (int b0 = 0; b0 < 32; b0 += 4) {
+            uint32_t T[4][16];       // four rotations' worth of table in flight (64 SGPRs): one wait per 4 x W masked regions
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+#pragma unroll
+                for (int i = 0; i < 16; i++) T[q][i] = t[(r * 32 + b0 + q) * 16 + i];   // uniform address: scalar loads
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+#pragma unroll
+                for (int a = 0; a < W; a++)
+                    if ((v[a] >> (b0 + q)) & 1u) {   // the lanes (frames) whose message bit 32a + b of this block row is set: EXEC mask, one v_xor per word
+                        asm volatile("" ::: "memory");   // keeps this a real EXEC-masked region (otherwise: v_cndmask + v_xor per word)
+#pragma unroll
+                        for (int c = 0; c < CB; c++)
+#pragma unroll
+                            for (int w = 0; w < W; w++) acc[c][w] ^= T[q][c * W + ((w - a) & (W - 1))];
+                    }
+        }
+    }
+    if (wave > 0) {
+#pragma unroll
+        for (int c = 0; c < CB; c++)
+#pragma unroll
+            for (int w = 0; w < W; w++) part[wave - 1][c * W + w][lane] = acc[c][w];
+    }
+    __syncthreads();
+    if (wave > 0 || !live) return;
+#pragma unroll
+    for (int c = 0; c < CB; c++)
+#pragma unroll
+        for (int w = 0; w < W; w++)
+#pragma unroll
+            for (int q = 0; q < kQcRowSplit - 1; q++) acc[c][w] ^= part[q][c * W + w][lane];
+#pragma unroll
+    for (int c = 0; c < CB; c++) {
+        const int bc = cg * CB + c;
+        if (bc < bcols) {
+#pragma unroll
+            for (int w = 0; w < W; w++) parw[(size_t)f * pwords + bc * W + w] = acc[c][w];
+        }
+    }
+}
+
 // one thread per (frame, group of four consecutive positions n = 4g .. 4g+3): ONE Philox call feeds both
 // Box-Muller pairs (r0,r1 -> cos and sin branch, r2,r3 likewise), i.e. four normals -- the generator is bound by
 // Philox's quarter-rate 32x32 multiplies, and the first version spent a whole call per sample.
+// OT = float / __half: LLRs [batch][N]; OT = uint8_t: the codeword itself, bytes [batch][n_tx], no channel (the encoder alone)
 template <typename OT, bool VEC>
-__global__ __launch_bounds__(256) void sim_frame_kernel(SimDev s, const uint32_t *__restrict__ msgw, OT *__restrict__ llr,
+__global__ __launch_bounds__(256) void sim_frame_kernel(SimDev s, const uint32_t *__restrict__ msgw, const uint32_t *__restrict__ parw, OT *__restrict__ llr,
                                                         uint8_t *__restrict__ msg_bytes, uint64_t seed, uint64_t first_frame,
                                                         int batch, float sigma, float llr_scale) {
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
@@ -63,8 +142,9 @@ __global__ __launch_bounds__(256) void sim_frame_kernel(SimDev s, const uint32_t
     const int n0 = 4 * g;
     if (n0 >= s.N || f >= batch) return;
     const uint32_t *mw = msgw + (size_t)f * s.kwords;
+    constexpr bool kBytes = sizeof(OT) == 1;
     float z[4] = {0.f, 0.f, 0.f, 0.f};
-    if (n0 < s.n_tx) {
+    if (!kBytes && n0 < s.n_tx) {
         uint32_t r[4];
         Philox::gen(seed, first_frame + f, (uint32_t)g, 1u, r);
         // Box-Muller on two 32-bit uniforms (u1 in (0,1]); both branches of each pair are used
@@ -79,7 +159,7 @@ __global__ __launch_bounds__(256) void sim_frame_kernel(SimDev s, const uint32_t
     // parity bits of the group: bit j = <msg, column j of G> over GF(2); a group that lies inside the parity part
     // on a 4-aligned column reads its four columns with one 16-byte load per message word
     uint32_t pacc[4] = {0u, 0u, 0u, 0u};
-    if (s.gt && n0 + 3 >= s.k && n0 < s.n_tx) {
+    if (s.gt && !s.qc_rot && n0 + 3 >= s.k && n0 < s.n_tx) {
         const int j0 = n0 - s.k;
         if (j0 >= 0 && (j0 & 3) == 0) {
             const uint4 *col = reinterpret_cast<const uint4 *>(s.gt + j0);
@@ -110,6 +190,9 @@ __global__ __launch_bounds__(256) void sim_frame_kernel(SimDev s, const uint32_t
             if (n < s.k) {
                 bit = (mw[n >> 5] >> (n & 31)) & 1u;
                 if (msg_bytes) msg_bytes[(size_t)f * s.k + n] = (uint8_t)bit;
+            } else if (s.qc_rot) {
+                const int j = n - s.k;         // packed by sim_parity_qc_kernel
+                bit = (parw[(size_t)f * s.pwords + (j >> 5)] >> (j & 31)) & 1u;
             } else {
                 bit = __popc(pacc[i]) & 1u;   // (no generator: pacc = 0, the all-zero codeword)
             }
@@ -118,8 +201,14 @@ __global__ __launch_bounds__(256) void sim_frame_kernel(SimDev s, const uint32_t
             msg_bytes[(size_t)f * s.k + n] = (uint8_t)((mw[n >> 5] >> (n & 31)) & 1u);
         }
     }
+    if constexpr (kBytes) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) if (n0 + i < s.n_tx) llr[(size_t)f * s.n_tx + n0 + i] = out[i] > 0.f ? 1 : 0;   // (sigma = 0: out = +-scale)
+        return;
+    }
     OT *dst = llr + (size_t)f * s.N + n0;
-    if constexpr (sizeof(OT) == 2) {
+    if constexpr (kBytes) {
+    } else if constexpr (sizeof(OT) == 2) {
         __half h[4];
 #pragma unroll
         for (int i = 0; i < 4; i++) h[i] = __float2half_rn(fminf(fmaxf(out[i], -65504.f), 65504.f));  // = round_f16
@@ -159,23 +248,37 @@ __global__ __launch_bounds__(256) void sim_tally_kernel(SimDev s, const uint32_t
     }
 }
 
-int sim_generate(const SimDev &s, uint32_t *msgw, hipStream_t st, uint64_t seed, uint64_t first_frame, int batch,
-                 double ebn0_db, void *d_llr, int llr_f16, uint8_t *d_msg) {
+int sim_generate(const SimDev &s, uint32_t *msgw, uint32_t *parw, hipStream_t st, uint64_t seed, uint64_t first_frame, int batch,
+                 double ebn0_db, void *d_out, int out_fmt, uint8_t *d_msg) {
     const double R = (double)s.k / (double)s.n_tx;
     const double sigma2 = 1.0 / (2.0 * R * pow(10.0, ebn0_db / 10.0));
     size_t nw = (size_t)batch * s.kwords;
-    hipLaunchKernelGGL(sim_msg_kernel, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, st, msgw, s.kwords, s.k, seed, first_frame, batch, s.gt ? 0 : 1);
-    const int groups = (s.N + 3) / 4;
+    hipLaunchKernelGGL(sim_msg_kernel, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, st, msgw, s.kwords, s.k, seed, first_frame, batch, (s.gt || s.qc_rot) ? 0 : 1);
+    if (s.qc_rot) {
+        const dim3 pg((batch + 63) / 64, s.qc_ncg);
+#define LDPC_QC_PARITY(W_) hipLaunchKernelGGL((sim_parity_qc_kernel<W_>), pg, dim3(64 * kQcRowSplit), 0, st, s.qc_rot, s.qc_brows, s.qc_bcols, msgw, parw, s.kwords, s.pwords, batch)
+        switch (s.qc_w) {
+            case 1: LDPC_QC_PARITY(1); break;
+            case 2: LDPC_QC_PARITY(2); break;
+            case 4: LDPC_QC_PARITY(4); break;
+            case 8: LDPC_QC_PARITY(8); break;
+            default: return set_error(LDPC_EUNSUPPORTED, "quasi-cyclic encoder: circulant size %d", 32 * s.qc_w);
+        }
+#undef LDPC_QC_PARITY
+    }
+    const int groups = ((out_fmt == 2 ? s.n_tx : s.N) + 3) / 4;
     const dim3 grid((groups + 255) / 256, batch);
     const float sg = (float)sqrt(sigma2), sc = (float)(2.0 / sigma2);
     // 16-byte (f32) / 8-byte (fp16) vector stores when every row starts aligned
-    const bool vec = (s.N % 4 == 0) && ((uintptr_t)d_llr % 16 == 0);
-    if (llr_f16) {
-        if (vec) hipLaunchKernelGGL((sim_frame_kernel<__half, true>), grid, dim3(256), 0, st, s, msgw, (__half *)d_llr, d_msg, seed, first_frame, batch, sg, sc);
-        else hipLaunchKernelGGL((sim_frame_kernel<__half, false>), grid, dim3(256), 0, st, s, msgw, (__half *)d_llr, d_msg, seed, first_frame, batch, sg, sc);
+    const bool vec = (s.N % 4 == 0) && ((uintptr_t)d_out % 16 == 0);
+    if (out_fmt == 2) {
+        hipLaunchKernelGGL((sim_frame_kernel<uint8_t, false>), grid, dim3(256), 0, st, s, msgw, parw, (uint8_t *)d_out, d_msg, seed, first_frame, batch, 0.f, 1.f);
+    } else if (out_fmt == 1) {
+        if (vec) hipLaunchKernelGGL((sim_frame_kernel<__half, true>), grid, dim3(256), 0, st, s, msgw, parw, (__half *)d_out, d_msg, seed, first_frame, batch, sg, sc);
+        else hipLaunchKernelGGL((sim_frame_kernel<__half, false>), grid, dim3(256), 0, st, s, msgw, parw, (__half *)d_out, d_msg, seed, first_frame, batch, sg, sc);
     } else {
-        if (vec) hipLaunchKernelGGL((sim_frame_kernel<float, true>), grid, dim3(256), 0, st, s, msgw, (float *)d_llr, d_msg, seed, first_frame, batch, sg, sc);
-        else hipLaunchKernelGGL((sim_frame_kernel<float, false>), grid, dim3(256), 0, st, s, msgw, (float *)d_llr, d_msg, seed, first_frame, batch, sg, sc);
+        if (vec) hipLaunchKernelGGL((sim_frame_kernel<float, true>), grid, dim3(256), 0, st, s, msgw, parw, (float *)d_out, d_msg, seed, first_frame, batch, sg, sc);
+        else hipLaunchKernelGGL((sim_frame_kernel<float, false>), grid, dim3(256), 0, st, s, msgw, parw, (float *)d_out, d_msg, seed, first_frame, batch, sg, sc);
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return set_error(LDPC_EHIP, "sim_generate: %s", hipGetErrorString(e));

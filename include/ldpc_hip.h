@@ -252,6 +252,20 @@ typedef struct ldpc_sim ldpc_sim;
 ldpc_sim *ldpc_sim_create(const ldpc_code *code, int k, int n_tx, int p, const uint8_t *G, int max_batch);
 ldpc_sim *ldpc_sim_create_on(const ldpc_code *code, int device, int k, int n_tx, int p, const uint8_t *G, int max_batch);
 void ldpc_sim_destroy(ldpc_sim *sim);
+/* The generator in QUASI-CYCLIC form, encoded the way the reference's fast encoder does it (Fast/Encoder.hs:26-63:
+ * the message cut into sz-bit words, parity word of block column c = XOR over block rows of mulWord = rotate-and-xor
+ * over the set message bits).  circ [block_rows][block_cols][sz/32] = the integers of G.q as little-endian 32-bit words
+ * (bit b = first-row entry of column b, QuasiCyclic.hs:19-25; ldpc_matrix_qc_words); k = sz * block_rows, parity length
+ * sz * block_cols >= n_tx - k.  sz must be 32, 64, 128 or 256 as in the reference (Encoder.hs:28-33: LDPC_EUNSUPPORTED
+ * otherwise -- use the dense form).  The device table is the 32 bit-rotations of each circulant
+ * (block_rows * block_cols * sz words), never the expanded k x p matrix. */
+ldpc_sim *ldpc_sim_create_qc_on(const ldpc_code *code, int device, int k, int n_tx, int sz, int block_rows, int block_cols,
+                                const uint32_t *circ, int max_batch);
+enum { LDPC_ENCODER_NONE = 0, LDPC_ENCODER_DENSE = 1, LDPC_ENCODER_QC = 2 };
+int ldpc_sim_encoder(const ldpc_sim *sim);    /* which of the three this frame source encodes with */
+/* the encoder alone: codewords [batch][n_tx] bytes (device) of the same messages ldpc_sim_generate would use (message
+ * bits of frame f depend on (seed, f) only); d_msg [batch][k] may be NULL.  Enqueued on `stream`. */
+int ldpc_sim_encode_batch(ldpc_sim *sim, uint64_t seed, uint64_t first_frame, int batch, uint8_t *d_codewords, uint8_t *d_msg, void *stream);
 /* frames [first_frame, first_frame+batch) of the stream identified by `seed`, at Eb/N0 (dB):
  * d_llr [batch][N] float32 (device), d_msg [batch][k] bytes (device, may be NULL).  Enqueued on
  * `stream` (NULL = the HIP default stream -- NOT a context's stream), not synchronised: pass the same
@@ -285,6 +299,9 @@ void ldpc_matrix_destroy(ldpc_matrix *m);
 /* rows/cols of the EXPANDED matrix (getNRows/getNCols, Loader.hs:31-46); qc_sz = 0 if not .q */
 int ldpc_matrix_info(const ldpc_matrix *m, int *rows, int *cols, int *qc_sz, int *block_rows, int *block_cols);
 int ldpc_matrix_dense(const ldpc_matrix *m, uint8_t *out /* rows*cols bytes 0/1 */);  /* QuasiCyclic.hs:19-25 */
+/* a QC source's first-row patterns as little-endian 32-bit words: out [block_rows][block_cols][ceil(sz/32)]
+ * (what Fast/Encoder.hs:38-39 converts the Integers of G.q to) */
+int ldpc_matrix_qc_words(const ldpc_matrix *m, uint32_t *out);
 /* rotation table of a .q matrix, -1 = empty block (Fast/Arraylet.hs:68-79); LDPC_EUNSUPPORTED for
  * a block holding more than one circulant (the reference errors there too). */
 int ldpc_matrix_qc_offsets(const ldpc_matrix *m, int32_t *offsets /* block_rows*block_cols */);

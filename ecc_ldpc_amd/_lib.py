@@ -37,7 +37,7 @@ ABI_SYMBOLS = [
     "ldpc_host_alloc", "ldpc_host_free",
     "ldpc_ctx_set_timing", "ldpc_ctx_kernel_time", "ldpc_ctx_kernel_name", "ldpc_ctx_kernel_geometry", "ldpc_jit_cache_dir", "ldpc_jit_source", "ldpc_jit_prepare",
     "ldpc_sim_create", "ldpc_sim_destroy", "ldpc_sim_generate", "ldpc_sim_tally", "ldpc_sim_encode_host",
-    "ldpc_sim_create_qc_on", "ldpc_sim_encoder", "ldpc_sim_encode_batch", "ldpc_matrix_qc_words",
+    "ldpc_sim_create_qc_on", "ldpc_sim_encoder", "ldpc_sim_encode_batch", "ldpc_matrix_qc_words", "ldpc_matrix_rank",
     "ldpc_matrix_load", "ldpc_matrix_load_mackay", "ldpc_matrix_destroy", "ldpc_matrix_info", "ldpc_matrix_dense",
     "ldpc_matrix_qc_offsets", "ldpc_code_from_matrix",
     "ldpc_ecc_create", "ldpc_ecc_destroy", "ldpc_ecc_name", "ldpc_ecc_message_length", "ldpc_ecc_codeword_length",
@@ -202,6 +202,7 @@ def lib():
     L.ldpc_sim_encoder.argtypes = [vp]
     L.ldpc_sim_encode_batch.argtypes = [vp, C.c_uint64, C.c_uint64, C.c_int, vp, vp, vp]
     L.ldpc_matrix_qc_words.argtypes = [vp, C.POINTER(C.c_uint32)]
+    L.ldpc_matrix_rank.argtypes = [vp]
     L.ldpc_matrix_load.restype = vp
     L.ldpc_matrix_load.argtypes = [C.c_char_p, C.c_char_p]
     L.ldpc_matrix_load_mackay.restype = vp
@@ -569,6 +570,13 @@ class Matrix:
         out = np.zeros((self.rows, self.cols), np.uint8)
         check(lib().ldpc_matrix_dense(self._h, ptr(out, C.c_uint8)))
         return out
+
+    def rank(self):
+        """rank over GF(2) of the expanded matrix"""
+        r = lib().ldpc_matrix_rank(self._h)
+        if r < 0:
+            raise LdpcError(r, last_error())
+        return r
 
     def qc_words(self):
         """first-row patterns of a QC source as little-endian 32-bit words [block_rows][block_cols][ceil(sz/32)]"""

@@ -334,6 +334,7 @@ __global__ __launch_bounds__(256) void flood_vn_kernel(FloodDev d, const ST *__r
     } else {
         acc = vn_sum_pred<ST, 8>(d, msg, qe, deg, b, acc);
     }
+    if (d.saturate) acc = sat_lam<CT, LDPC_V_MINSUM>(acc);   // (uniform; min-sum below f64 only: ldpc_math.h)
     Store<ST>::st(lam + (size_t)col * d.Bp + b, acc);
 }
 

@@ -42,13 +42,16 @@ struct CsrArgs {
     const double *st_lam, *st_ne_in;
     double *st_ne_out;
     uint8_t *st_syn;
+    int *work_counter;    // batched kernel, persistent workgroups: next frame to take = gridDim.x + atomicAdd(work_counter, 1)
 };
 
 // RPT / CPT > 0: the thread's column indices (RPT rows x DMAX) and message slots (CPT columns x CDMAX)
 // are loaded into registers ONCE before the turn loop; 0: re-read from global memory every turn.
 constexpr int kCdMax = 8;  // column degree bound of the register-cached variant
-template <typename CT, int VARIANT, int DMAX, int RPT, int CPT>
-__global__ __launch_bounds__(kCsrThreads) void fused_csr_kernel(CsrArgs A) {
+// THREADS: 256, or 1024 for frames whose state leaves room for ONE workgroup per CU anyway (codes/1920.1280.A: 150 KB): 16 waves
+// per CU instead of 4 to cover the LDS round trips.
+template <typename CT, int VARIANT, int DMAX, int RPT, int CPT, int THREADS = kCsrThreads>
+__global__ __launch_bounds__(THREADS) void fused_csr_kernel(CsrArgs A) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     CT *lam = reinterpret_cast<CT *>(smem);
     CT *orig = lam + A.N;
@@ -58,12 +61,12 @@ __global__ __launch_bounds__(kCsrThreads) void fused_csr_kernel(CsrArgs A) {
     const int M = A.M, N = A.N;
     const size_t fN = (size_t)frame * N, fE = (size_t)frame * A.E;
 
-    for (int n = tid; n < N; n += kCsrThreads) {
+    for (int n = tid; n < N; n += THREADS) {
         CT v = maybe_round_f16<CT>(load_llr<CT>(A.llr, fN + n, A.llr_fmt), A.llr_round16);
         orig[n] = v;
         lam[n] = A.step_mode ? (CT)A.st_lam[fN + n] : v;
     }
-    for (int m = tid; m < M; m += kCsrThreads) {
+    for (int m = tid; m < M; m += THREADS) {
         const int e0 = A.row_ptr[m], deg = A.row_ptr[m + 1] - e0;
 #pragma unroll
         for (int k = 0; k < DMAX; k++) msg[k * M + m] = (A.step_mode && k < deg) ? (CT)A.st_ne_in[fE + e0 + k] : CT(0);  // Orig.hs:64-65
@@ -77,14 +80,14 @@ __global__ __launch_bounds__(kCsrThreads) void fused_csr_kernel(CsrArgs A) {
     if constexpr (kCached) {
 #pragma unroll
         for (int i = 0; i < RPT; i++) {
-            const int m = tid + i * kCsrThreads;
+            const int m = tid + i * THREADS;
             rdeg[i] = (m < M) ? A.row_ptr[m + 1] - A.row_ptr[m] : 0;
 #pragma unroll
             for (int k = 0; k < DMAX; k++) rcol[i][k] = (m < M) ? A.ell_col[k * M + m] : -1;
         }
 #pragma unroll
         for (int i = 0; i < CPT; i++) {
-            const int c = tid + i * kCsrThreads;
+            const int c = tid + i * THREADS;
 #pragma unroll
             for (int j = 0; j < kCdMax; j++) cslot[i][j] = (c < N && j < A.cdmax) ? A.csc_slot[j * N + c] : -1;
         }
@@ -126,7 +129,7 @@ __global__ __launch_bounds__(kCsrThreads) void fused_csr_kernel(CsrArgs A) {
     for (int n = 0;; n++) {
         if (A.trace) {
             LDPC_COLD_PATH();
-            for (int c = tid; c < N; c += kCsrThreads) A.trace[((size_t)frame * (A.max_iters + 1) + n) * N + c] = (double)lam[c];
+            for (int c = tid; c < N; c += THREADS) A.trace[((size_t)frame * (A.max_iters + 1) + n) * N + c] = (double)lam[c];
         }
         const bool last = n >= turns;
         // ---- rows: syndrome + check-node update
@@ -134,11 +137,11 @@ __global__ __launch_bounds__(kCsrThreads) void fused_csr_kernel(CsrArgs A) {
         if constexpr (kCached) {
 #pragma unroll
             for (int i = 0; i < RPT; i++) {
-                const int m = tid + i * kCsrThreads;
+                const int m = tid + i * THREADS;
                 if (m < M) unsat |= do_row(m, rdeg[i], [&](int k) { return rcol[i][k]; }, last);
             }
         } else {
-            for (int m = tid; m < M; m += kCsrThreads)
+            for (int m = tid; m < M; m += THREADS)
                 unsat |= do_row(m, A.row_ptr[m + 1] - A.row_ptr[m], [&](int k) { return A.ell_col[k * M + m]; }, last);
         }
         const int any_unsat = __syncthreads_or(unsat);  // also: every message written, every lam read
@@ -153,17 +156,17 @@ __global__ __launch_bounds__(kCsrThreads) void fused_csr_kernel(CsrArgs A) {
         if constexpr (kCached) {
 #pragma unroll
             for (int i = 0; i < CPT; i++) {
-                const int c = tid + i * kCsrThreads;
+                const int c = tid + i * THREADS;
                 if (c < N) {
                     CT acc = orig[c];
 #pragma unroll
                     for (int j = 0; j < kCdMax; j++)
                         if (cslot[i][j] >= 0) acc = msg[cslot[i][j]] + acc;
-                    lam[c] = acc;
+                    lam[c] = sat_lam<CT, VARIANT>(acc);
                 }
             }
         } else {
-            for (int c = tid; c < N; c += kCsrThreads) {
+            for (int c = tid; c < N; c += THREADS) {
                 CT acc = orig[c];
                 if (A.cdmax <= kCdMax) {   // slots first, then the message reads, then the sum (descending rows)
                     int slot[kCdMax];
@@ -176,12 +179,21 @@ __global__ __launch_bounds__(kCsrThreads) void fused_csr_kernel(CsrArgs A) {
                     for (int j = 0; j < kCdMax; j++)
                         if (slot[j] >= 0) acc = v[j] + acc;
                 } else {
-                    for (int j = 0; j < A.cdmax; j++) {
-                        const int slot = A.csc_slot[j * N + c];
-                        if (slot >= 0) acc = msg[slot] + acc;
+                    // heavier columns (codes/1920.1280.A: weight 18), eight edges at a time: slots, then the message reads, then
+                    // the additions in the same order as one edge after the other
+                    for (int j0 = 0; j0 < A.cdmax; j0 += kCdMax) {
+                        int slot[kCdMax];
+                        CT v[kCdMax];
+#pragma unroll
+                        for (int j = 0; j < kCdMax; j++) slot[j] = (j0 + j < A.cdmax) ? A.csc_slot[(j0 + j) * N + c] : -1;
+#pragma unroll
+                        for (int j = 0; j < kCdMax; j++) v[j] = msg[slot[j] < 0 ? 0 : slot[j]];
+#pragma unroll
+                        for (int j = 0; j < kCdMax; j++)
+                            if (slot[j] >= 0) acc = v[j] + acc;
                     }
                 }
-                lam[c] = acc;
+                lam[c] = sat_lam<CT, VARIANT>(acc);
             }
         }
         __syncthreads();
@@ -189,14 +201,14 @@ __global__ __launch_bounds__(kCsrThreads) void fused_csr_kernel(CsrArgs A) {
     }
 
     if (A.step_mode) {
-        for (int c = tid; c < N; c += kCsrThreads) A.final_lam[fN + c] = (double)lam[c];
-        for (int m = tid; m < M; m += kCsrThreads) {
+        for (int c = tid; c < N; c += THREADS) A.final_lam[fN + c] = (double)lam[c];
+        for (int m = tid; m < M; m += THREADS) {
             const int e0 = A.row_ptr[m], deg = A.row_ptr[m + 1] - e0;
             for (int k = 0; k < deg; k++) A.st_ne_out[fE + e0 + k] = (double)msg[k * M + m];
         }
         return;
     }
-    for (int c = tid; c < N; c += kCsrThreads) {
+    for (int c = tid; c < N; c += THREADS) {
         CT v = converged ? lam[c] : orig[c];
         A.bits[fN + c] = v > CT(0) ? 1 : 0;
         if (A.final_lam) A.final_lam[fN + c] = (double)v;
@@ -225,18 +237,18 @@ __global__ __launch_bounds__(THREADS, (DMAX <= 8 ? (THREADS > 256 ? 6 : 4) : 1))
     static_assert(sizeof(CT) == 4 && DMAX % 2 == 0 && CD % 2 == 0, "pairs of 16-bit offsets");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
-    const int frame = blockIdx.x;
     const int M = A.M, N = A.N;
-    const size_t fN = (size_t)frame * N, fE = (size_t)frame * A.E;
     CT *lam = reinterpret_cast<CT *>(smem);
     CT *msg = lam + N;  // [DMAX][M]
     const uint32_t off_inf = (uint32_t)(N + DMAX * M) * 4u, off_zero = off_inf + 4u, off_msg = (uint32_t)N * 4u;
     auto lds_at = [&](uint32_t byte_off) -> CT { return *reinterpret_cast<const CT *>(smem + byte_off); };
 
-    // ---- this thread's share of the graph, its channel LLRs and its messages: registers
+    // ---- this thread's share of the graph: registers, loaded ONCE per workgroup.  The workgroup is persistent: it decodes
+    // frames blockIdx.x, blockIdx.x + gridDim.x, ... one after the other (r03: the per-frame prologue -- three dependent
+    // global loads deep: position -> row -> row_ptr -> indices -- was ~10 us per frame, 40 % of the launch at 4 dB where a
+    // frame takes 4.7 turns; profiles/r03_mackay_f32_tanh_4dB_*).
     uint32_t rpack[RPT][DMAX / 2], cpack[CPT][CD / 2];
     int rdeg[RPT];
-    CT mreg[RPT][DMAX], oreg[CPT];
 #pragma unroll
     for (int i = 0; i < RPT; i++) {
         const int m = tid + i * THREADS;                 // a row POSITION; the row behind it:
@@ -248,7 +260,6 @@ __global__ __launch_bounds__(THREADS, (DMAX <= 8 ? (THREADS > 256 ? 6 : 4) : 1))
             const int col = (m < M) ? A.ell_col[k * M + m] : -1;   // a column POSITION
             const uint32_t off = col < 0 ? off_inf : (uint32_t)col * 4u;
             if (k & 1) rpack[i][k / 2] |= off << 16; else rpack[i][k / 2] = off;
-            mreg[i][k] = (A.step_mode && k < rdeg[i]) ? (CT)A.st_ne_in[fE + e0 + k] : CT(0);  // Orig.hs:64-65
         }
     }
 #pragma unroll
@@ -260,16 +271,44 @@ __global__ __launch_bounds__(THREADS, (DMAX <= 8 ? (THREADS > 256 ? 6 : 4) : 1))
             const uint32_t off = slot < 0 ? off_zero : off_msg + (uint32_t)slot * 4u;
             if (j & 1) cpack[i][j / 2] |= off << 16; else cpack[i][j / 2] = off;
         }
-        oreg[i] = CT(0);
-        if (c < N) {
-            const int col = A.col_of_pos[c];
-            oreg[i] = maybe_round_f16<CT>(load_llr<CT>(A.llr, fN + col, A.llr_fmt), A.llr_round16);
-            lam[c] = A.step_mode ? (CT)A.st_lam[fN + col] : oreg[i];
-        }
     }
     if (tid == 0) {
         *reinterpret_cast<CT *>(smem + off_inf) = CT(INFINITY);
         *reinterpret_cast<CT *>(smem + off_zero) = CT(0);
+    }
+
+    // frames are taken from a shared counter, not by a fixed stride: below the waterfall the turns per frame spread from a
+    // few to max_iters, and 85 frames per workgroup do not average that out (measured with a fixed stride at 1 dB: +15 % time)
+    int *next_frame = reinterpret_cast<int *>(smem + off_zero + 4u);
+    for (int frame = blockIdx.x; frame < A.batch;) {
+    const size_t fN = (size_t)frame * N, fE = (size_t)frame * A.E;
+    CT mreg[RPT][DMAX], oreg[CPT];
+    int colreg[CPT];   // (re-read per frame, one coalesced load: kept across frames it costs the turn loop four registers)
+#pragma unroll
+    for (int i = 0; i < CPT; i++) colreg[i] = (tid + i * THREADS < N) ? A.col_of_pos[tid + i * THREADS] : 0;
+#pragma unroll
+    for (int i = 0; i < RPT; i++)
+#pragma unroll
+        for (int k = 0; k < DMAX; k++) mreg[i][k] = CT(0);   // Orig.hs:64-65
+    if (A.step_mode) {
+        LDPC_COLD_PATH();
+#pragma unroll
+        for (int i = 0; i < RPT; i++) {
+            const int m = tid + i * THREADS;
+            const int e0 = (m < M) ? A.row_ptr[A.row_of_pos[m]] : 0;
+#pragma unroll
+            for (int k = 0; k < DMAX; k++)
+                if (k < rdeg[i]) mreg[i][k] = (CT)A.st_ne_in[fE + e0 + k];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < CPT; i++) {
+        const int c = tid + i * THREADS;
+        oreg[i] = CT(0);
+        if (c < N) {
+            oreg[i] = maybe_round_f16<CT>(load_llr<CT>(A.llr, fN + colreg[i], A.llr_fmt), A.llr_round16);
+            lam[c] = A.step_mode ? (CT)A.st_lam[fN + colreg[i]] : oreg[i];
+        }
     }
     __syncthreads();
 
@@ -277,6 +316,7 @@ __global__ __launch_bounds__(THREADS, (DMAX <= 8 ? (THREADS > 256 ? 6 : 4) : 1))
     int n_done = 0;
     const int turns = A.step_mode ? 1 : A.max_iters;
     for (int n = 0;; n++) {
+        LDPC_TURN_LOOP();
         if (A.trace) {
             LDPC_COLD_PATH();
             for (int c = tid; c < N; c += THREADS) A.trace[((size_t)frame * (A.max_iters + 1) + n) * N + A.col_of_pos[c]] = (double)lam[c];
@@ -341,7 +381,7 @@ __global__ __launch_bounds__(THREADS, (DMAX <= 8 ? (THREADS > 256 ? 6 : 4) : 1))
             CT acc = oreg[i];
 #pragma unroll
             for (int j = 0; j < CD; j++) acc = v[i][j] + acc;   // absent slots add 0 (they follow the present ones)
-            if (c < N) lam[c] = acc;
+            if (c < N) lam[c] = sat_lam<CT, VARIANT>(acc);
         }
         __syncthreads();
         if (A.step_mode) break;
@@ -359,21 +399,25 @@ __global__ __launch_bounds__(THREADS, (DMAX <= 8 ? (THREADS > 256 ? 6 : 4) : 1))
                     if (k < rdeg[i]) A.st_ne_out[fE + e0 + k] = (double)mreg[i][k];
             }
         }
-        return;
-    }
+    } else {
 #pragma unroll
-    for (int i = 0; i < CPT; i++) {
-        const int c = tid + i * THREADS;
-        if (c < N) {
-            const int col = A.col_of_pos[c];
-            CT vv = converged ? lam[c] : oreg[i];
-            A.bits[fN + col] = vv > CT(0) ? 1 : 0;
-            if (A.final_lam) A.final_lam[fN + col] = (double)vv;
+        for (int i = 0; i < CPT; i++) {
+            const int c = tid + i * THREADS;
+            if (c < N) {
+                const int col = A.col_of_pos[c];
+                CT vv = converged ? lam[c] : oreg[i];
+                A.bits[fN + col] = vv > CT(0) ? 1 : 0;
+                if (A.final_lam) A.final_lam[fN + col] = (double)vv;
+            }
+        }
+        if (tid == 0) {
+            if (A.iters) A.iters[frame] = n_done;
+            if (A.conv) A.conv[frame] = converged ? 1 : 0;
         }
     }
-    if (tid == 0) {
-        if (A.iters) A.iters[frame] = n_done;
-        if (A.conv) A.conv[frame] = converged ? 1 : 0;
+    if (tid == 0) *next_frame = A.work_counter ? (int)gridDim.x + atomicAdd(A.work_counter, 1) : frame + (int)gridDim.x;
+    __syncthreads();   // also: every lam read of this frame is done before the next frame's LLRs are written over it
+    frame = *next_frame;
     }
 }
 
@@ -384,11 +428,12 @@ struct CsrState {
     int32_t *d_ell = nullptr, *d_csc = nullptr, *d_row_ptr = nullptr;
     // batched kernel: the same tables in POSITION space (conflict-aware placement of rows and columns in LDS)
     int32_t *d_ell_b = nullptr, *d_csc_b = nullptr, *d_row_of_pos = nullptr, *d_col_of_pos = nullptr;
+    int *d_counter = nullptr;     // work counter of the persistent batched kernel
     KernelTimer *timer = nullptr;
     LaunchInfo info;
 };
 
-static int pick_dmax(int maxdeg) { return maxdeg <= 4 ? 4 : maxdeg <= 8 ? 8 : maxdeg <= 20 ? 20 : maxdeg <= 32 ? 32 : 0; }
+static int pick_dmax(int maxdeg) { return maxdeg <= 4 ? 4 : maxdeg <= 6 ? 6 : maxdeg <= 8 ? 8 : maxdeg <= 20 ? 20 : maxdeg <= 32 ? 32 : 0; }
 static size_t csr_lds_bytes(const ldpc_code &c, int dtype) {
     const int dm = pick_dmax(c.max_row_deg);
     return ((size_t)2 * c.N + (size_t)dm * c.M) * (dtype == LDPC_F64 ? 8 : 4);
@@ -526,14 +571,14 @@ const char *fused_csr_why_not(const ldpc_code &c, int variant, int dtype) {
 void fused_csr_destroy(CsrState *s) {
     if (!s) return;
     (void)hipFree(s->d_ell); (void)hipFree(s->d_csc); (void)hipFree(s->d_row_ptr);
-    (void)hipFree(s->d_ell_b); (void)hipFree(s->d_csc_b); (void)hipFree(s->d_row_of_pos); (void)hipFree(s->d_col_of_pos);
+    (void)hipFree(s->d_ell_b); (void)hipFree(s->d_csc_b); (void)hipFree(s->d_row_of_pos); (void)hipFree(s->d_col_of_pos); (void)hipFree(s->d_counter);
     delete s;
 }
 
 // which batched instance (if any) serves this shape: 0 = none (row-by-row kernel)
 static int batched_shape(const CsrState &s) {
     const int rpt = (s.M + kCsrThreads - 1) / kCsrThreads, cpt = (s.N + kCsrThreads - 1) / kCsrThreads;
-    if (((size_t)s.N + (size_t)s.dmax * s.M + 2) * 4 > 65536) return 0;   // 16-bit LDS byte offsets
+    if (((size_t)s.N + (size_t)s.dmax * s.M + 3) * 4 > 65536) return 0;   // 16-bit LDS byte offsets
     if (s.dmax == 4 && rpt <= 6 && cpt <= 8 && s.cdmax <= 4) return 1;
     if (s.dmax == 8 && rpt <= 2 && cpt <= 4 && s.cdmax <= 8) return 2;
     if (s.dmax == 20 && rpt <= 2 && cpt <= 6 && s.cdmax <= 8) return 3;
@@ -608,9 +653,9 @@ const char *fused_csr_kernel_name(const CsrState &s) {
 }
 void fused_csr_set_round16(CsrState *s, int on) { if (s) s->round16 = on; }
 
-template <typename CT, int VARIANT, int DMAX, int RPT, int CPT>
+template <typename CT, int VARIANT, int DMAX, int RPT, int CPT, int THREADS = kCsrThreads>
 static int launch_csr(CsrState &s, hipStream_t st, CsrArgs &a) {
-    auto kern = fused_csr_kernel<CT, VARIANT, DMAX, RPT, CPT>;
+    auto kern = fused_csr_kernel<CT, VARIANT, DMAX, RPT, CPT, THREADS>;
     const size_t lds = ((size_t)2 * s.N + (size_t)DMAX * s.M) * sizeof(CT);
     static size_t attr_set = 0;
     if (lds > 64 * 1024 && lds > attr_set) {
@@ -619,11 +664,11 @@ static int launch_csr(CsrState &s, hipStream_t st, CsrArgs &a) {
         attr_set = lds;
     }
     if (!a.step_mode) {
-        snprintf(s.info.name, sizeof(s.info.name), "ldpc::fused_csr_kernel<%s, %d, %d, %d, %d>", sizeof(CT) == 8 ? "double" : "float", VARIANT, DMAX, RPT, CPT);
-        s.info.threads = kCsrThreads; s.info.frames_per_wg = 1;
+        snprintf(s.info.name, sizeof(s.info.name), "ldpc::fused_csr_kernel<%s, %d, %d, %d, %d, %d>", sizeof(CT) == 8 ? "double" : "float", VARIANT, DMAX, RPT, CPT, THREADS);
+        s.info.threads = THREADS; s.info.frames_per_wg = 1;
     }
     if (s.timer && !a.step_mode) s.timer->begin(st);
-    hipLaunchKernelGGL(kern, dim3(a.batch), dim3(kCsrThreads), lds, st, a);
+    hipLaunchKernelGGL(kern, dim3(a.batch), dim3(THREADS), lds, st, a);
     if (s.timer && !a.step_mode) s.timer->end(st);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return set_error(LDPC_EHIP, "fused_csr launch: %s", hipGetErrorString(e));
@@ -633,13 +678,31 @@ static int launch_csr(CsrState &s, hipStream_t st, CsrArgs &a) {
 template <typename CT, int VARIANT, int DMAX, int RPT, int CPT, int CD, int THREADS = kCsrThreads>
 static int launch_csr_batched(CsrState &s, hipStream_t st, CsrArgs &a) {
     auto kern = fused_csr_batched_kernel<CT, VARIANT, DMAX, RPT, CPT, CD, THREADS>;
-    const size_t lds = ((size_t)s.N + (size_t)DMAX * s.M + 2) * sizeof(CT);   // lam, messages, the +inf and 0 cells; <= 64 KB
+    const size_t lds = ((size_t)s.N + (size_t)DMAX * s.M + 3) * sizeof(CT);   // lam, messages, the +inf and 0 cells, the next-frame cell; <= 64 KB
     if (!a.step_mode) {
         snprintf(s.info.name, sizeof(s.info.name), "ldpc::fused_csr_batched_kernel<%s, %d, %d, %d, %d, %d, %d>", sizeof(CT) == 8 ? "double" : "float", VARIANT, DMAX, RPT, CPT, CD, THREADS);
         s.info.threads = THREADS; s.info.frames_per_wg = 1;
     }
+    // persistent workgroups: as many as are resident at once (LDPC_CSR_PERSIST=0: one workgroup per frame)
+    static int resident = 0;
+    if (!resident) {
+        int per_cu = 0, dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess &&
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)kern, THREADS, lds) == hipSuccess && per_cu > 0)
+            resident = per_cu * prop.multiProcessorCount;
+        else { (void)hipGetLastError(); resident = 256 * 2; }
+    }
+    const char *pz = getenv("LDPC_CSR_PERSIST");
+    const int grid = (pz && !strcmp(pz, "0")) ? a.batch : std::min(a.batch, resident);
+    a.work_counter = nullptr;
+    if (grid < a.batch) {
+        if (!s.d_counter && hipMalloc((void **)&s.d_counter, sizeof(int)) != hipSuccess) { (void)hipGetLastError(); s.d_counter = nullptr; }
+        const char *dz = getenv("LDPC_CSR_DYNAMIC");   // =0: fixed stride (A/B)
+        if (s.d_counter && !(dz && !strcmp(dz, "0")) && hipMemsetAsync(s.d_counter, 0, sizeof(int), st) == hipSuccess) a.work_counter = s.d_counter;
+    }
     if (s.timer && !a.step_mode) s.timer->begin(st);
-    hipLaunchKernelGGL(kern, dim3(a.batch), dim3(THREADS), lds, st, a);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(THREADS), lds, st, a);
     if (s.timer && !a.step_mode) s.timer->end(st);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return set_error(LDPC_EHIP, "fused_csr (batched) launch: %s", hipGetErrorString(e));
@@ -678,6 +741,13 @@ static int dispatch_dmax(CsrState &s, hipStream_t st, CsrArgs &a) {
         case 4:
             if (cache_ok && rpt <= 6) return launch_csr<CT, VARIANT, 4, 6, 8>(s, st, a);
             return launch_csr<CT, VARIANT, 4, 0, 0>(s, st, a);
+        case 6:
+            // codes/1920.1280.A (5760 x 1920, row weights 4 and 6, column weights 14 and 18): (2N + 6M) * 4 B = 150 KB of LDS per
+            // frame, one workgroup per CU -- so a wide one (LDPC_CSR_WIDE=0: 256 threads)
+            if constexpr (sizeof(CT) == 4) {
+                if (s.want_wide && ((size_t)2 * s.N + (size_t)6 * s.M) * 4 > 80 * 1024) return launch_csr<CT, VARIANT, 6, 0, 0, 1024>(s, st, a);
+            }
+            return launch_csr<CT, VARIANT, 6, 0, 0>(s, st, a);
         case 8:
             if (cache_ok && rpt <= 2) return launch_csr<CT, VARIANT, 8, 2, 8>(s, st, a);
             return launch_csr<CT, VARIANT, 8, 0, 0>(s, st, a);

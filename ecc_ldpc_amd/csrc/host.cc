@@ -294,6 +294,34 @@ int ldpc_matrix_dense(const ldpc_matrix *m, uint8_t *out) {
     return LDPC_OK;
 }
 
+// rank over GF(2) of the expanded matrix (Gaussian elimination on 64-bit packed rows).  A parity-check matrix given
+// alone defines a code of cols - rank message bits: codes/1920.1280.A lists 5760 checks of rank 1280 for 1920 bits.
+int ldpc_matrix_rank(const ldpc_matrix *m) {
+    if (!m) return set_error(LDPC_EINVAL, "null matrix");
+    try {
+        std::vector<uint8_t> d((size_t)m->rows * m->cols);
+        if (ldpc_matrix_dense(m, d.data()) != LDPC_OK) return ldpc_last_error_code();
+        const size_t W = ((size_t)m->cols + 63) / 64;
+        std::vector<uint64_t> a((size_t)m->rows * W, 0);
+        for (int r = 0; r < m->rows; r++)
+            for (int c = 0; c < m->cols; c++)
+                if (d[(size_t)r * m->cols + c]) a[(size_t)r * W + (c >> 6)] |= 1ull << (c & 63);
+        int rank = 0;
+        for (int c = 0; c < m->cols && rank < m->rows; c++) {
+            const size_t w = (size_t)c >> 6;
+            const uint64_t bit = 1ull << (c & 63);
+            int piv = -1;
+            for (int r = rank; r < m->rows; r++) if (a[(size_t)r * W + w] & bit) { piv = r; break; }
+            if (piv < 0) continue;
+            if (piv != rank) for (size_t i = 0; i < W; i++) std::swap(a[(size_t)piv * W + i], a[(size_t)rank * W + i]);
+            for (int r = rank + 1; r < m->rows; r++)
+                if (a[(size_t)r * W + w] & bit) for (size_t i = w; i < W; i++) a[(size_t)r * W + i] ^= a[(size_t)rank * W + i];
+            rank++;
+        }
+        return rank;
+    } catch (...) { return set_error(LDPC_ENOMEM, "out of host memory"); }
+}
+
 // Fast/Encoder.hs:38-39 `fmap fromIntegral m`: the Integer of each block as sz-bit machine word(s)
 int ldpc_matrix_qc_words(const ldpc_matrix *m, uint32_t *out) {
     if (!m || !out) return set_error(LDPC_EINVAL, "null argument");
@@ -494,7 +522,16 @@ ldpc_ecc *ldpc_ecc_create_replicas(const char *codes_dir, const char *code_name,
             }
         }
         e = new ldpc_ecc();
-        e->message_length = standalone ? h->cols - h->rows : g->rows;
+        // no generator: k = cols - rank(H); rows < cols is taken as full rank (every shipped H of that shape is), a matrix with
+        // at least as many rows as columns (codes/1920.1280.A: redundant checks) has its rank computed
+        int k_alone = standalone ? h->cols - h->rows : 0;
+        if (standalone && h->rows >= h->cols) {
+            const int rk = ldpc_matrix_rank(h);
+            if (rk < 0) goto fail;
+            k_alone = h->cols - rk;
+            if (k_alone <= 0) { set_error(LDPC_EFORMAT, "%s has rank %d over GF(2): no message bits", xs[2].c_str(), rk); goto fail; }
+        }
+        e->message_length = standalone ? k_alone : g->rows;
         e->unpunctured_length = h->cols;
         e->max_iters = atoi(xs[3].c_str());
         e->variant = variant; e->dtype = dtype;

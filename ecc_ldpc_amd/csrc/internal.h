@@ -21,6 +21,7 @@ struct FloodDev {
     int M, N, E, Bp;
     int wide_rows;           // rows of weight 9..32 go to the padded-register CN instance (0: O(d^2) fallback, A/B)
     int cm_order;            // arraylet-cm column sum: orig + foldr1 (+) (CachedMult.hs:261-262) instead of foldr (+) orig
+    int saturate;            // min-sum below f64: a column's new LLR is kept within +-2^100 (ldpc_math.h sat_lam)
     const int32_t *row_ptr;  // [M+1]
     const int32_t *col_idx;  // [E]   CSR, ascending column inside a row
     const int32_t *col_ptr;  // [N+1]

@@ -40,6 +40,9 @@ namespace ldpc { enum { LLR_F32 = 0, LLR_F64 = 1, LLR_F16 = 2 }; }
 // snapshot, ...).  Emits only an assembler comment; tools/isa_histogram.py reads it from the compiler's .s output to
 // tell the ordinary turn of the loop from the rare ones when it counts instructions.
 #define LDPC_COLD_PATH() asm volatile("; ldpc.cold")
+// first statement of the body of the BP iteration loop when that loop is nested in another (a persistent workgroup's loop over
+// frames): tools/isa_histogram.py then prices the innermost loop around this marker instead of the outermost loop
+#define LDPC_TURN_LOOP() asm volatile("; ldpc.turnloop")
 
 #define LDPC_V_TANH 0
 #define LDPC_V_MINSUM 1
@@ -102,6 +105,23 @@ __device__ __forceinline__ float round_f16(float v) {
 }
 template <typename CT> __device__ __forceinline__ CT maybe_round_f16(CT v, int on) {
     if constexpr (sizeof(CT) == 4) return on ? round_f16(v) : v;
+    else return v;
+}
+
+// ---------------------------------------------------------------- LLR range of the any-H min-sum kernels below f64
+// Flooding min-sum is homogeneous: on a graph with heavy columns the LLRs of a frame that does not converge grow by up to
+// 3/4 (column weight - 1) per turn -- codes/1920.1280.A (weight 18): x6 per turn measured, 3e9 after 12 turns, past
+// FLT_MAX before turn 50.  The reference's Double never gets there (1e39 after 50 turns); a float does, and then
+// inf - inf = NaN, hard(NaN) = False on every bit, an all-zero "codeword" whose syndrome is zero: a frame the reference
+// reports as failed would come back "converged".  So the kernels that take ANY matrix (fused_csr.hip, flood.hip) keep a
+// column's new LLR within +-2^100 in their f32 / f16-storage min-sum instances: then |t| = |lam - ne| <= 2^101, every
+// message <= 3/4 * 2^101 and a column sum of any weight below 2^20 stays finite.  Nothing changes while |lam| < 2^100
+// (1.3e30); beyond it the float trajectory leaves the Double one, as it would have anyway.  The tanh rule needs none
+// of this (|ne'| <= 37.43, atanh' Utils.hs:113-117), nor does f64 (parity mode: the reference's arithmetic, overflow and all).
+constexpr float kLamSat = 1.2676506002282294e30f;   // 2^100
+template <typename CT, int VARIANT>
+__device__ __forceinline__ CT sat_lam(CT v) {
+    if constexpr (VARIANT == LDPC_V_MINSUM && sizeof(CT) == 4) return __builtin_amdgcn_fmed3f(v, -kLamSat, kLamSat);
     else return v;
 }
 

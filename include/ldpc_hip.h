@@ -299,6 +299,9 @@ void ldpc_matrix_destroy(ldpc_matrix *m);
 /* rows/cols of the EXPANDED matrix (getNRows/getNCols, Loader.hs:31-46); qc_sz = 0 if not .q */
 int ldpc_matrix_info(const ldpc_matrix *m, int *rows, int *cols, int *qc_sz, int *block_rows, int *block_cols);
 int ldpc_matrix_dense(const ldpc_matrix *m, uint8_t *out /* rows*cols bytes 0/1 */);  /* QuasiCyclic.hs:19-25 */
+/* rank over GF(2) of the expanded matrix (a stand-alone parity-check matrix defines cols - rank message bits:
+ * codes/1920.1280.A holds 5760 checks of rank 1280); negative = LDPC_E* */
+int ldpc_matrix_rank(const ldpc_matrix *m);
 /* a QC source's first-row patterns as little-endian 32-bit words: out [block_rows][block_cols][ceil(sz/32)]
  * (what Fast/Encoder.hs:38-39 converts the Integers of G.q to) */
 int ldpc_matrix_qc_words(const ldpc_matrix *m, uint32_t *out);

@@ -75,6 +75,28 @@ def read_alist_mackay(text: str) -> np.ndarray:
     return H
 
 
+def gf2_rank(H: np.ndarray) -> int:
+    """rank over GF(2) (Gaussian elimination on bit-packed rows): the message length of a code given by a parity-check
+    matrix alone is cols - rank -- codes/1920.1280.A lists 5760 checks of rank 1280 for 1920 bits"""
+    A = np.packbits(np.asarray(H, np.uint8), axis=1)
+    rows, rank = A.shape[0], 0
+    for col in range(H.shape[1]):
+        byte, bit = col >> 3, 0x80 >> (col & 7)
+        hit = np.flatnonzero(A[rank:, byte] & bit)
+        if hit.size == 0:
+            continue
+        piv = rank + int(hit[0])
+        if piv != rank:
+            A[[rank, piv]] = A[[piv, rank]]
+        elim = np.flatnonzero(A[:, byte] & bit)
+        elim = elim[elim != rank]
+        A[elim] ^= A[rank]
+        rank += 1
+        if rank == rows:
+            break
+    return rank
+
+
 def read_matlab_bits(text: str) -> np.ndarray:
     """Data/BitMatrix/Matlab.hs:20-26: lines of '0'/'1' words."""
     rows = [[int(w) for w in line.split()] for line in text.splitlines() if line.strip()]

@@ -18,6 +18,7 @@ CODE_PARAMS = {
     "jpl.1024.4.5": (1024, 1280),
     "jpl.4096.4.5": (4096, 5120),
     "1920.1280.3.303": (640, 1920),
+    "1920.1280.A": (640, 1920),          # 5760 redundant checks of rank 1280
 }
 
 
@@ -38,7 +39,7 @@ class LoadedCode:
         elif name == "moon.7.13":
             self.H = formats.read_alist_reference(open(os.path.join(d, "H.alist")).read())
             self.G = formats.read_alist_reference(open(os.path.join(d, "G.alist")).read())
-        elif name == "1920.1280.3.303":
+        elif name in ("1920.1280.3.303", "1920.1280.A"):
             self.H = formats.read_alist_mackay(open(d).read())
         else:
             raise KeyError(name)

@@ -17,6 +17,11 @@ run --steps 3 --warmup 1 --batch 65536 --ebn0 3                                 
 for db in 1 2 3 4; do run --steps 3 --warmup 1 --code 1920.1280.3.303 --rate none --variant tanh --ebn0 $db; done   # configs[2], generic on-chip kernel
 LDPC_HIP_PATH=flood run --steps 3 --warmup 1 --code 1920.1280.3.303 --rate none --variant tanh --ebn0 1
 run --steps 3 --warmup 1 --code 1920.1280.3.303 --rate none --variant minsum --ebn0 1
+# the same code through its 5760 redundant checks (codes/1920.1280.A, E = 32 000): on-chip (150 KB of LDS per frame) and from HBM
+for v in tanh minsum; do
+  LDPC_HIP_PATH=fused run --steps 2 --warmup 1 --batch 16384 --code 1920.1280.A --rate none --variant $v --ebn0 1
+  LDPC_HIP_PATH=flood run --steps 2 --warmup 1 --batch 16384 --code 1920.1280.A --rate none --variant $v --ebn0 1
+done
 python - <<'PY'
 import json
 for l in open('gpurun_out/bench_matrix.jsonl'):

@@ -32,6 +32,9 @@ CASES = [
     # fused QC kernels on them, not only the CSR paths)
     ("jpl.4096.4.5", "min", 10, [(3.4, 71), (3.9, 72), (2.0, 73)], False),
     ("jpl.4096.4.5", "tanh", 8, [(3.4, 81), (2.0, 82)], False),
+    # the redundant-check matrix of the same code as 1920.1280.3.303 (added in round 3): 5760 x 1920, E = 32 000, column weight 18
+    ("1920.1280.A", "tanh", 5, [(1.5, 91), (3.0, 92)], False),
+    ("1920.1280.A", "min", 6, [(1.5, 93), (4.5, 94)], False),
 ]
 
 

@@ -99,10 +99,13 @@ def parse_functions(text):
 def blocks_of(lines):
     """basic blocks: list of dict(label, instrs=[(mnemonic, operands)], succ=[block indices])"""
     blocks, index = [], {}
+    turn_marks = []
     cur, pending, pending_cold = None, ["entry"], False
     for line in lines:
+        if "ldpc.turnloop" in line:
+            turn_marks.append(len(blocks) - 1 if cur is not None else len(blocks))   # LDPC_TURN_LOOP(): the block this comment sits in
         if "ldpc.cold" in line and cur is not None:
-            cur["cold"] = True            # LDPC_COLD_PATH() marker (fused_common.h)
+            cur["cold"] = True            # LDPC_COLD_PATH() marker (ldpc_math.h)
         elif "ldpc.cold" in line:
             pending_cold = True
         line = line.split(";")[0].rstrip()
@@ -136,6 +139,9 @@ def blocks_of(lines):
         else:
             succ = [i + 1] if i + 1 < len(blocks) else []
         b["succ"] = succ
+    for i in turn_marks:
+        if i < len(blocks):
+            blocks[i]["turn_mark"] = True
     return blocks
 
 
@@ -259,6 +265,17 @@ def analyse(name, lines):
     loops, latches, dom = natural_loops(blocks)
     size = lambda ids: sum(len(blocks[i]["instrs"]) for i in ids)
     outer = [h for h in loops if not any(h2 != h and h in loops[h2] for h2 in loops)]
+    marked = [i for i, b in enumerate(blocks) if b.get("turn_mark")]
+    if marked:
+        # the source names its iteration loop (LDPC_TURN_LOOP(): it is nested in a persistent workgroup's loop over frames):
+        # the smallest natural loop around each marked block
+        picked = []
+        for i in marked:
+            around = [h for h in loops if i in loops[h]]
+            if around:
+                picked.append(min(around, key=lambda h: size(loops[h])))
+        if picked:
+            outer = sorted(set(picked))
     if not outer:
         return None
     big = max(size(loops[h]) for h in outer)
@@ -273,7 +290,9 @@ def analyse(name, lines):
         every &= body
         res.append({"header": blocks[h]["label"], "blocks": len(body), "instructions": size(body),
                     "hot_turn": histogram(blocks, hot_path(blocks, body, h, latches[h], every)),
-                    "inner_loops": any(h2 != h and h2 in body for h2 in loops),
+                    # (loops that hang off a side path the source marks cold -- trace stores -- do not make a turn data-dependent)
+                    "inner_loops": any(h2 != h and h2 in body and loops[h2] < body and not any(blocks[d].get("cold") for d in dom[h2] if d in body)
+                                       for h2 in loops),
                     "every_turn": histogram(blocks, sorted(every)), "whole_loop": histogram(blocks, sorted(body))})
     return {"kernel": name, "loops": res}
 

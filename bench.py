@@ -37,7 +37,8 @@ def main():
     ap.add_argument("--code", default="jpl.4096.4.5")
     ap.add_argument("--rate", default="4/5")
     ap.add_argument("--variant", default="minsum", choices=["minsum", "tanh"])
-    ap.add_argument("--dtype", default="f32", choices=["f32", "f64", "f16"])
+    ap.add_argument("--dtype", default="f32", choices=["f32", "f64", "f16", "f16pk"],
+                    help="f16: fp16 LLRs, f32 arithmetic; f16pk: fp16 LLRs AND fp16 arithmetic, two frames per lane (BASELINE configs[3])")
     ap.add_argument("--iters", type=int, default=50)
     ap.add_argument("--ebn0", type=float, default=2.0)
     ap.add_argument("--batch", type=int, default=65536, help="frames per GPU per step")
@@ -96,7 +97,7 @@ def main():
     dec, sim, code = ecc.decoder, ecc.sim, ecc.code
     k, n_tx, N, Eg = ecc.message_length, ecc.codeword_length, code.N, code.E
     B = args.batch
-    s_bytes = {"f32": 4, "f64": 8, "f16": 2}[args.dtype]
+    s_bytes = {"f32": 4, "f64": 8, "f16": 2, "f16pk": 2}[args.dtype]
     B_cw = args.iters * (3 * Eg + 3 * N) * s_bytes + n_tx * s_bytes + (k + 7) // 8   # SURVEY.md section 8d, at max_iters
 
     # one explicit non-default stream for everything the library enqueues (a NULL handle would mean
@@ -105,7 +106,7 @@ def main():
     torch.cuda.set_stream(stream)
     sp = stream.cuda_stream
     nbuf = max(1, min(args.steps + args.warmup, 4))
-    f16 = args.dtype == "f16"   # configs[3] "fp16 LLRs": the frame source writes fp16, the decoder reads fp16
+    f16 = args.dtype in ("f16", "f16pk")   # configs[3] "fp16 LLRs": the frame source writes fp16, the decoder reads fp16
     llr = [torch.empty((B, N), dtype=torch.float16 if f16 else torch.float32, device=dev) for _ in range(nbuf)]
     msg = [torch.empty((B, k), dtype=torch.uint8, device=dev) for _ in range(nbuf)]
     bits = torch.empty((B, N), dtype=torch.uint8, device=dev)
@@ -172,7 +173,7 @@ def main():
             "metric": f"decoded info Mbit/s @ {args.iters} BP iters, {args.code}, Eb/N0={args.ebn0:g} dB",
             "value": round(value, 2), "unit": "Mbit/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "vs_baseline": None, "dtype": "f16" if args.dtype == "f16pk" else args.dtype, "data": "synthetic",
             "config": {"workload": f"{args.code} rate {args.rate} ({k},{n_tx}) {args.variant} {args.schedule} BP, {args.iters} iters, "
                                    f"Eb/N0={args.ebn0} dB, {B} frames/GPU/step", "code_name": ecc.name, "path": dec.path,
                        "batch_per_gpu": B, "parallelism": f"frames sharded over {world} GPU(s), tallies all-reduced"},
@@ -402,7 +403,7 @@ def proof_of_work(args, E, ecc, dec, sim, llr_t, msg_t, bits, iters_t, conv_t, s
     import torch
     n = min(1024, llr_t.shape[0])
     k = ecc.message_length
-    if dec.schedule == "layered":
+    if dec.schedule == "layered" or args.dtype == "f16pk":   # one implementation each: checked by invariant, judged by another kernel
         return proof_of_work_layered(args, E, ecc, dec, sim, llr_t, msg_t, bits, iters_t, conv_t, sp, f16, n)
     flood_dtype = "f32" if args.dtype == "f16" else args.dtype     # fused-F16(llr) == F32 decoder on the fp16-rounded LLRs
     variant = "min" if args.variant == "minsum" else "tanh"

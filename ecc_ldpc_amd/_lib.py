@@ -15,7 +15,7 @@ SO_PATH = os.environ.get("LDPC_SO") or os.path.join(HERE, "libldpc_hip.so")  # L
 
 OK, EINVAL, ENOMEM, EHIP, ENODEVICE, EUNSUPPORTED, EDEGREE, EFORMAT, ENOTFOUND = 0, -1, -2, -3, -4, -5, -6, -7, -8
 TANH, MINSUM, TANH_CM = 0, 1, 2
-F32, F64, F16 = 0, 1, 2
+F32, F64, F16, F16PK = 0, 1, 2, 3
 PATH_AUTO, PATH_FLOOD, PATH_FUSED = 0, 1, 2
 SCHED_FLOODING, SCHED_LAYERED = 0, 1
 
@@ -300,7 +300,7 @@ def init(device: int = 0):
 
 _VARIANTS = {"tanh": TANH, "min": MINSUM, "minsum": MINSUM, "min-sum": MINSUM, "cm": TANH_CM, "tanh-cm": TANH_CM, TANH: TANH, MINSUM: MINSUM,
              TANH_CM: TANH_CM}
-_DTYPES = {"f32": F32, "f64": F64, "f16": F16, F32: F32, F64: F64, F16: F16}
+_DTYPES = {"f32": F32, "f64": F64, "f16": F16, "f16pk": F16PK, F32: F32, F64: F64, F16: F16, F16PK: F16PK}
 _PATHS = {"auto": PATH_AUTO, "flood": PATH_FLOOD, "fused": PATH_FUSED, 0: 0, 1: 1, 2: 2}
 _SCHEDULES = {"flooding": SCHED_FLOODING, "flood": SCHED_FLOODING, "layered": SCHED_LAYERED, 0: 0, 1: 1}
 

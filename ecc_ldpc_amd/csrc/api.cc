@@ -376,7 +376,7 @@ ldpc_ctx *ldpc_ctx_create_cfg(const ldpc_code *code_c, const ldpc_ctx_config *cf
         return nullptr;
     }
     if (!code || max_batch <= 0 || (variant != LDPC_TANH && variant != LDPC_MINSUM && variant != LDPC_TANH_CM) ||
-        (dtype != LDPC_F32 && dtype != LDPC_F64 && dtype != LDPC_F16) ||
+        (dtype != LDPC_F32 && dtype != LDPC_F64 && dtype != LDPC_F16 && dtype != LDPC_F16PK) ||
         (path != LDPC_PATH_AUTO && path != LDPC_PATH_FLOOD && path != LDPC_PATH_FUSED)) {
         set_error(LDPC_EINVAL, "ldpc_ctx_create: bad arguments (variant=%d dtype=%d max_batch=%d path=%d)", variant, dtype, max_batch, path);
         return nullptr;
@@ -393,12 +393,16 @@ ldpc_ctx *ldpc_ctx_create_cfg(const ldpc_code *code_c, const ldpc_ctx_config *cf
     ldpc_code_dev tabs;
     if (code_upload(code, device, &tabs) != LDPC_OK) return nullptr;
 
+    if (dtype == LDPC_F16PK && (variant != LDPC_MINSUM || schedule != LDPC_SCHED_FLOODING || path == LDPC_PATH_FLOOD)) {
+        set_error(LDPC_EUNSUPPORTED, "LDPC_F16PK (packed fp16 arithmetic, two frames per lane) exists for min-sum, flooding schedule, on-chip path");
+        return nullptr;
+    }
     if (schedule == LDPC_SCHED_LAYERED) {
         if (dtype == LDPC_F16) { set_error(LDPC_EUNSUPPORTED, "the layered schedule exists for f32 and f64"); return nullptr; }
         if (code->max_row_deg > 32) { set_error(LDPC_EUNSUPPORTED, "layered schedule: check rows above weight 32 (this code has %d)", code->max_row_deg); return nullptr; }
     }
     const bool fused_ok = schedule == LDPC_SCHED_FLOODING && variant != LDPC_TANH_CM && ldpc::fused_supported(*code, variant, dtype);
-    if (path == LDPC_PATH_FUSED && !fused_ok) {
+    if ((path == LDPC_PATH_FUSED || dtype == LDPC_F16PK) && !fused_ok) {
         if (schedule == LDPC_SCHED_LAYERED) { set_error(LDPC_EUNSUPPORTED, "no on-chip kernel for the layered schedule (state lives in HBM: LDPC_PATH_FLOOD)"); return nullptr; }
         set_error(LDPC_EUNSUPPORTED, "no fused kernel for this code/variant/dtype (%s)", ldpc::fused_why_not(*code, variant, dtype));
         return nullptr;

@@ -33,6 +33,7 @@ struct FusedState {
     int static_id = 0;    // compiled-in rotation table matching this code (0 = none: table-driven kernel)
     bool use_split = false;  // four waves per frame, block rows split between wave pairs (fused_split.hip)
     bool use_msg = true;  // per-edge-message two-wave kernel (fused_msg.hip)
+    bool use_pk16 = false;   // LDPC_F16PK: packed fp16 arithmetic, two frames per lane (fused_pk16.hip)
     KernelTimer *timer = nullptr;
     LaunchInfo info;
     uint32_t *d_tab = nullptr;
@@ -49,6 +50,23 @@ static bool plan_matches_ar4ja45(const ldpc_code &c) {
     return true;
 }
 
+static int builtin_static_id(const ldpc_code &c) {
+    std::vector<uint16_t> rot; std::vector<uint8_t> bcv;
+    for (int br = 0; br < c.block_rows; br++)
+        for (int bc = 0; bc < c.block_cols; bc++) {
+            int off = c.offsets[(size_t)br * c.block_cols + bc];
+            if (off >= 0) { rot.push_back((uint16_t)off); bcv.push_back((uint8_t)bc); }
+        }
+    return fused_msg_static_id(c.sz, rot.data(), bcv.data(), (int)rot.size());
+}
+// LDPC_F16PK: only the built-in instances (compile-time tables of the shipped AR4JA matrices)
+static const char *pk16_why_not(const ldpc_code &c, int variant) {
+    if (variant != LDPC_MINSUM) return "the packed-fp16 kernel implements min-sum";
+    if (c.sz == 0 || !plan_matches_ar4ja45(c)) return "the packed-fp16 kernel has built-in instances only (AR4JA rate-4/5 plan: codes/jpl.1024.4.5, codes/jpl.4096.4.5)";
+    if (!fused_pk16_has(variant, c.sz, builtin_static_id(c))) return "no built-in packed-fp16 instance for this rotation table";
+    return nullptr;
+}
+
 static const char *plan_why_not(const ldpc_code &c, int variant, int dtype) {
     if (variant == LDPC_TANH && dtype != LDPC_F32) return "the fused tanh kernel exists for f32 only (f64 tanh: flood path)";
     if (dtype != LDPC_F32 && dtype != LDPC_F64) return "fused kernels exist for f32 and f64";
@@ -63,6 +81,7 @@ static inline int compute_dtype(int dtype) { return dtype == LDPC_F16 ? LDPC_F32
 
 // a fused (on-chip) kernel exists if the code matches a compiled QC plan, or failing that if a frame fits in LDS
 const char *fused_why_not(const ldpc_code &c, int variant, int dtype) {
+    if (dtype == LDPC_F16PK) return pk16_why_not(c, variant);
     dtype = compute_dtype(dtype);
     const char *p = plan_why_not(c, variant, dtype);
     if (!p) return nullptr;
@@ -84,6 +103,11 @@ FusedState *fused_create(const ldpc_code &c, int variant, int dtype, int max_bat
     if (why) { set_error(LDPC_EUNSUPPORTED, "%s", why); return nullptr; }
     FusedState *s = new (std::nothrow) FusedState();
     if (!s) { set_error(LDPC_ENOMEM, "out of host memory"); return nullptr; }
+    if (dtype == LDPC_F16PK) {
+        s->use_pk16 = true; s->use_msg = false;
+        s->variant = variant; s->dtype = dtype; s->max_batch = max_batch; s->sz = c.sz; s->M = c.M; s->N = c.N; s->E = c.E;
+        return s;
+    }
     s->round16 = dtype == LDPC_F16;
     dtype = compute_dtype(dtype);
     s->variant = variant; s->dtype = dtype; s->max_batch = max_batch; s->sz = c.sz; s->M = c.M; s->N = c.N; s->E = c.E;
@@ -172,7 +196,7 @@ void fused_destroy(FusedState *s) {
 void fused_set_timer(FusedState *s, KernelTimer *t) { if (s) { s->timer = t; fused_csr_set_timer(s->csr, t); } }
 
 bool fused_reads_llr_once(const FusedState &s, int max_iters) {
-    return s.jit != nullptr || s.csr != nullptr || (s.use_split && max_iters <= kSplitMaxIters);
+    return s.jit != nullptr || s.csr != nullptr || s.use_pk16 || (s.use_split && max_iters <= kSplitMaxIters);
 }
 
 const LaunchInfo &fused_launch_info(const FusedState &s) { return s.csr ? fused_csr_launch_info(*s.csr) : s.info; }
@@ -191,6 +215,7 @@ const char *fused_kernel_name(const FusedState &s) {
     const LaunchInfo &li = fused_launch_info(s);
     if (li.name[0]) return li.name;
     if (s.csr) return fused_csr_kernel_name(*s.csr);
+    if (s.use_pk16) return "fused_pk16_kernel";
     if (s.use_split) return "fused_split_kernel";
     return "fused_msg_kernel";
 }
@@ -201,6 +226,10 @@ int fused_decode(FusedState &s, hipStream_t st, int max_iters, int batch, const 
     FusedArgs a{};
     a.tab = s.d_tab; a.llr = d_llr; a.llr_fmt = llr_fmt; a.llr_round16 = s.round16; a.bits = d_bits; a.iters = d_iters; a.conv = d_conv;
     a.final_lam = d_final; a.trace = d_trace; a.batch = batch; a.max_iters = max_iters; a.step_mode = 0;
+    if (s.use_pk16) {
+        if (max_iters > kSplitMaxIters) return set_error(LDPC_EUNSUPPORTED, "LDPC_F16PK: at most %d iterations (a frame's result is packed into one register)", kSplitMaxIters);
+        return fused_pk16_launch(s.sz, st, a, s.timer, &s.info);
+    }
     if (s.jit) return launch_jit(s, st, a);
     // (the split kernel packs a frame's result into one register: 9 bits for the turn it converged at)
     if (s.use_split && max_iters <= kSplitMaxIters) return fused_split_launch(s.variant, s.sz, st, a, s.timer, &s.info);
@@ -210,6 +239,7 @@ int fused_decode(FusedState &s, hipStream_t st, int max_iters, int batch, const 
 int fused_step(FusedState &s, hipStream_t st, int batch, const double *d_orig, const double *d_lam, const double *d_ne,
                double *d_ne_out, double *d_lam_out, uint8_t *d_syn) {
     if (s.csr) return fused_csr_step(*s.csr, st, batch, d_orig, d_lam, d_ne, d_ne_out, d_lam_out, d_syn);
+    if (s.use_pk16) return set_error(LDPC_EUNSUPPORTED, "LDPC_F16PK has no teacher-forced step (its state is not the reference's: use ldpc_decode_trace)");
     if (s.use_msg || s.jit) {  // per-edge messages: the state goes in and out as it is
         FusedArgs a{};
         a.tab = s.d_tab; a.llr = d_orig; a.llr_fmt = LLR_F64; a.llr_round16 = 0; a.batch = batch; a.max_iters = 1; a.step_mode = 1;

@@ -1,0 +1,50 @@
+// fused_pk16.hip -- built-in instances of the packed-fp16 min-sum kernel (fused_pk16_body.h: two frames per lane), LDPC_F16PK.
+// Same workgroup shape as fused_split.hip (four waves, block rows dealt to two wave groups, lam in LDS, messages in
+// registers); a workgroup decodes 2 (sz = 128) or 4 (sz = 32) frames.
+#include <stdio.h>
+
+#include "fused_pk16_body.h"
+
+// 78 packed messages + 24 packed channel LLRs per thread as in the f32 split kernel, but the leave-one-out minimum of a
+// weight-18 row wants ~36 transient registers (magnitudes, suffix minima) where the f32 (min1, min2) form wants 18: at 4 waves
+// per SIMD (128 VGPRs) the compiler spills 150-210 registers, at 3 (168 VGPRs; 160-162 used) none.
+#ifndef PK16_WAVES_PER_EU
+#define PK16_WAVES_PER_EU 3
+#endif
+
+namespace ldpc {
+
+template <class Plan, int SZ, class T>
+__global__ __launch_bounds__((SplitGeom<Plan, SZ>::THREADS), PK16_WAVES_PER_EU)
+void fused_pk16_kernel(FusedArgs A) {
+    pk::kernel_body<Plan, SZ, T>(A);
+}
+
+bool fused_pk16_has(int variant, int sz, int static_id) {
+    return variant == LDPC_MINSUM && ((sz == 128 && static_id == 2) || (sz == 32 && static_id == 1));
+}
+
+template <int SZ, class T>
+static void launch_pk16(hipStream_t st, FusedArgs &a) {
+    using G = SplitGeom<PlanAR4JA45, SZ>;
+    const int per_wg = 2 * G::CPW;
+    const int grid = (a.batch + per_wg - 1) / per_wg;
+    hipLaunchKernelGGL((fused_pk16_kernel<PlanAR4JA45, SZ, T>), dim3(grid), dim3(G::THREADS), 0, st, a);
+}
+
+int fused_pk16_launch(int sz, hipStream_t st, FusedArgs &a, KernelTimer *timer, LaunchInfo *info) {
+    if (info) {
+        snprintf(info->name, sizeof(info->name), "ldpc::fused_pk16_kernel<ldpc::PlanAR4JA45, %d, ", sz);
+        info->threads = sz == 128 ? SplitGeom<PlanAR4JA45, 128>::THREADS : SplitGeom<PlanAR4JA45, 32>::THREADS;
+        info->frames_per_wg = 2 * (sz == 128 ? SplitGeom<PlanAR4JA45, 128>::CPW : SplitGeom<PlanAR4JA45, 32>::CPW);
+    }
+    if (timer) timer->begin(st);
+    if (sz == 128) launch_pk16<128, TabJpl4096>(st, a);
+    else launch_pk16<32, TabJpl1024>(st, a);
+    if (timer) timer->end(st);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return set_error(LDPC_EHIP, "fused_pk16 launch: %s", hipGetErrorString(e));
+    return LDPC_OK;
+}
+
+}  // namespace ldpc

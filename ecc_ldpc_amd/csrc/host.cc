@@ -466,7 +466,8 @@ ldpc_ecc *ldpc_ecc_create_replicas(const char *codes_dir, const char *code_name,
         std::string dec = xs[1];
         int dtype = LDPC_F32;
         auto ends = [&](const char *suf) { size_t n = strlen(suf); return dec.size() > n && dec.compare(dec.size() - n, n, suf) == 0; };
-        if (ends("-f64")) { dtype = LDPC_F64; dec.resize(dec.size() - 4); }
+        if (ends("-f16pk")) { dtype = LDPC_F16PK; dec.resize(dec.size() - 6); }   // packed fp16 arithmetic, two frames per lane (min-sum)
+        else if (ends("-f64")) { dtype = LDPC_F64; dec.resize(dec.size() - 4); }
         else if (ends("-f16")) { dtype = LDPC_F16; dec.resize(dec.size() - 4); }
         else if (ends("-f32")) { dec.resize(dec.size() - 4); }
         int variant, schedule = LDPC_SCHED_FLOODING;

@@ -13,6 +13,10 @@ the reference by construction.  What it pins is that the HIP kernels do exactly 
                library is built with -ffp-contract=off), so the min-sum trajectory is reproduced BIT FOR BIT.
   fused paths: the f32 decoder fed r16(llr); only the channel LLRs ever live in HBM.  (Tested as
                fused-F16(llr) == fused-F32(r16(llr)); no separate emulation needed.)
+  LDPC_F16PK : ARITHMETIC in binary16 (csrc/fused_pk16_body.h, two frames per lane in packed instructions): the same loop
+               with state L = -lam and u = ne' / (3/4) in fp16 and the 3/4 applied inside fused multiply-adds --
+               decode_minsum_pk16 below, bit for bit (numpy's float16 is IEEE binary16; an fp16 fma is computed exactly in
+               float64 -- 0.75 * u + L needs at most 43 significant bits -- and rounded once).
 """
 import numpy as np
 
@@ -91,3 +95,77 @@ def decode_minsum_f16_flood(g, llr, max_iters):
         lam = np.where(live[:, None], lam2, lam)
         ne = np.where(live[:, None], ne2, ne)
     return (out > 0).astype(np.uint8), iters, conv, trace
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# LDPC_F16PK: packed-fp16 min-sum (csrc/fused_pk16_body.h holds the specification this restates)
+def neg_llr16(llr):
+    """channel LLRs (float32) -> L0 = -(LLR saturated at +-65504 and rounded to fp16), a zero as +0"""
+    v = np.clip(np.asarray(llr, np.float32), -F16_MAX, F16_MAX)
+    h = (np.float32(0) - v).astype(np.float16)
+    h[h == 0] = np.float16(0)
+    return h
+
+
+def fma16(a, k, c):
+    """round16(a * k + c) with ONE rounding (v_pk_fma_f16); a, c float16 arrays, k a Python float exactly representable"""
+    return (a.astype(np.float64) * k + c.astype(np.float64)).astype(np.float16)
+
+
+def step_minsum_pk16(g, L0, L, u):
+    """one update.  L0, L [F, N] float16 (negated LLRs), u [F, E] float16 in CSR edge order -> u', L', syndrome_zero [F]"""
+    F = L.shape[0]
+    hard = np.signbit(L)                               # hard(lam) = lam > 0 = sign of -lam (L is never -0)
+    u2 = np.empty_like(u)
+    syn_ok = np.ones(F, bool)
+    rows = _rows(g)
+    for m, cols, e0 in rows:
+        d = len(cols)
+        syn_ok &= ~np.logical_xor.reduce(hard[:, cols], axis=1)
+        tn = fma16(u[:, e0:e0 + d], 0.75, L[:, cols])  # -(lam - ne)
+        a = np.abs(tn)
+        sg = np.signbit(tn)
+        X = np.logical_xor.reduce(sg, axis=1, keepdims=True)
+        i1 = np.argmin(a, axis=1)
+        m1 = np.take_along_axis(a, i1[:, None], axis=1)
+        a2 = a.copy()
+        np.put_along_axis(a2, i1[:, None], np.float16(np.inf), axis=1)
+        m2 = a2.min(axis=1, keepdims=True)
+        k = np.arange(d)[None, :]
+        mag = np.where(k == i1[:, None], m2, m1)       # leave-one-out minimum (ties: m2 == m1)
+        neg = ~np.logical_xor(X, sg)                   # sign(u'_k) = 1 ^ X ^ sign(tN_k) = -prod_{j /= k} sgn(tN_j)
+        u2[:, e0:e0 + d] = np.where(neg, -mag, mag).astype(np.float16)
+    acc = L0.copy()
+    for m, cols, e0 in reversed(rows):                 # Min.hs:101 foldr: rows in descending order
+        acc[:, cols] = fma16(u2[:, e0:e0 + len(cols)], -0.75, acc[:, cols])
+    return u2, acc, syn_ok
+
+
+def decode_minsum_pk16(g, llr, max_iters):
+    """llr [F, N] float32 -> bits [F, N] u8, iters [F], converged [F], trace (list over turns of lam = -L [F, N] float32,
+    zero for a frame that has finished -- ldpc_decode_trace leaves those rows untouched)"""
+    llr = np.asarray(llr, np.float32)
+    F = llr.shape[0]
+    L0 = neg_llr16(llr)
+    L = L0.copy()
+    u = np.zeros((F, g.E), np.float16)
+    iters = np.zeros(F, np.int32)
+    conv = np.zeros(F, bool)
+    live = np.ones(F, bool)
+    out = np.signbit(L0)
+    trace = []
+    with np.errstate(over="ignore", invalid="ignore"):
+        for n in range(max_iters + 1):
+            trace.append(np.where(live[:, None], -L.astype(np.float32), np.float32(0)))
+            u2, L2, ok = step_minsum_pk16(g, L0, L, u)
+            fin = live & ok                            # Min.hs:75: syndrome zero -> hard(lam)
+            out[fin] = np.signbit(L[fin]); conv[fin] = True; iters[fin] = n
+            live &= ~ok
+            if n >= max_iters:                         # Min.hs:76: out of turns -> the channel's hard decisions
+                iters[live] = n
+                break
+            if not live.any():
+                break
+            L = np.where(live[:, None], L2, L)
+            u = np.where(live[:, None], u2, u)
+    return out.astype(np.uint8), iters, conv, trace

@@ -46,6 +46,8 @@ def main():
     ap.add_argument("--schedule", default="flooding", choices=["flooding", "layered"], help="layered: extension (BASELINE configs[4])")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the cpu_baseline sample (0 = skip)")
     ap.add_argument("--seed", type=lambda s: int(s, 0), default=0x5EEDC0DE)
+    ap.add_argument("--fp16-leg", type=int, default=1, help="0: skip the second measurement of the same workload with the packed-fp16 decoder "
+                    "(BASELINE configs[3]; reported next to the f32 headline as `fp16_packed`, never as `value`)")
     ap.add_argument("--proof", type=int, default=1, help="0: skip the untimed proof-of-work sample (tools/profile.sh does, so that the "
                     "kernel-trace average covers full-size launches only)")
     args = ap.parse_args()
@@ -190,6 +192,8 @@ def main():
         }
         if world == 1 and args.cpu_seconds > 0:
             out["cpu_baseline"] = cpu_baseline(args, ecc, llr[0], value)
+        if world == 1 and args.dtype == "f32" and args.variant == "minsum" and args.schedule == "flooding" and args.path == "auto" and args.fp16_leg:
+            out["fp16_packed"] = fp16_packed_leg(args, E, torch, dev, sp, B)
         print(json.dumps(out), flush=True)
     # release the device objects in a known order before interpreter teardown
     torch.cuda.synchronize()
@@ -198,6 +202,57 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def fp16_packed_leg(args, E, torch, dev, sp, B):
+    """BASELINE configs[3] on the same workload: fp16 LLRs, ARITHMETIC in packed fp16, two frames per lane (LDPC_F16PK,
+    csrc/fused_pk16_body.h) -- the same frame ids, the same number of timed steps, HIP-event kernel time and wall time.  A second,
+    separately labelled measurement: `value` above stays the f32 decoder's."""
+    name = f"ldpc/hip-minsum-f16pk/{args.code}/{args.iters}"
+    if args.rate not in ("", "none"):
+        x, y = args.rate.split("/")
+        name += f"/{x}/{y}"
+    try:
+        ecc = E.ECC(os.path.join(ROOT, "codes"), name, max_batch=B)
+    except E.LdpcError as e:
+        return {"error": str(e)}
+    dec, sim, k, N = ecc.decoder, ecc.sim, ecc.message_length, ecc.code.N
+    llr = torch.empty((B, N), dtype=torch.float16, device=dev)
+    msg = torch.empty((B, k), dtype=torch.uint8, device=dev)
+    bits = torch.empty((B, N), dtype=torch.uint8, device=dev)
+    its = torch.empty((B,), dtype=torch.int32, device=dev)
+    sim.generate(args.seed, 0, B, args.ebn0, llr.data_ptr(), msg.data_ptr(), sp, llr_f16=True)
+    step = lambda: dec.decode_batch_dev(llr.data_ptr(), bits.data_ptr(), B, args.iters, its.data_ptr(), None, sp, llr_f16=True)
+    step()
+    torch.cuda.synchronize()
+    dec.set_timing(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    launches, kernel_ms = dec.kernel_time()
+    dec.set_timing(False)
+    wrong = (bits[:, :k] != msg).sum(dim=1)
+    threads, fpw = dec.kernel_geometry
+    res = {"metric": f"decoded info Mbit/s, {name}", "value": round(args.steps * B * k / dt / 1e6, 2), "unit": "Mbit/s", "dtype": "f16 (arithmetic and LLRs), two frames per lane",
+           "steps": args.steps, "ms_per_step": round(dt / args.steps * 1e3, 3), "avg_launch_ms": round(kernel_ms / max(launches, 1), 4), "kernel": dec.kernel_name,
+           "threads_per_workgroup": threads, "frames_per_workgroup": fpw, "ber": float(wrong.sum().item()) / (B * k), "fer": float((wrong > 0).sum().item()) / B,
+           "mean_iters": float(its.float().mean().item()),
+           "checked_by": "tests/test_pk16_gpu.py: bit-exact with oracle/emulate_f16.py decode_minsum_pk16 (the reference has no fp16 decoder)"}
+    ent = isa_entry(dec.kernel_name)
+    if ent is not None and kernel_ms:
+        loops = ent["loops"]
+        valu = sum(lp["hot_turn"]["units"].get("valu", 0) for lp in loops) / len(loops)
+        clk = sum(lp["hot_turn"]["valu_cost_weighted_clk"] for lp in loops) / len(loops)
+        turns = float(its.sum().item()) * args.steps
+        waves_per_frame = threads / 64.0 / fpw
+        res.update({"valu_instr_per_wave_turn": round(valu, 1), "waves_per_frame": waves_per_frame,
+                    "valu_frac": round(valu * waves_per_frame * turns / (kernel_ms * 1e-3) / VALU_PEAK, 4),
+                    "valu_pipe_busy_frac": round(clk * waves_per_frame * turns / (N_SIMD * CLOCK_HZ * kernel_ms * 1e-3), 4)})
+    ecc.close()
+    del llr, msg, bits, its
+    return res
 
 
 def self_launch(n):

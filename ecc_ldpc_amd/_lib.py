@@ -18,11 +18,12 @@ TANH, MINSUM, TANH_CM = 0, 1, 2
 F32, F64, F16, F16PK = 0, 1, 2, 3
 PATH_AUTO, PATH_FLOOD, PATH_FUSED = 0, 1, 2
 SCHED_FLOODING, SCHED_LAYERED = 0, 1
+SUM_REFERENCE, SUM_ARRAYLET, SUM_SPARSE = 0, 1, 2
 
 
 class CtxConfig(C.Structure):   # ldpc_ctx_config
     _fields_ = [("struct_size", C.c_size_t), ("device", C.c_int), ("variant", C.c_int), ("dtype", C.c_int), ("max_batch", C.c_int),
-                ("path", C.c_int), ("schedule", C.c_int)]
+                ("path", C.c_int), ("schedule", C.c_int), ("sum_order", C.c_int)]
 
 # every symbol include/ldpc_hip.h declares (tests/test_abi.py checks the library exports them all)
 ABI_SYMBOLS = [
@@ -302,6 +303,7 @@ _VARIANTS = {"tanh": TANH, "min": MINSUM, "minsum": MINSUM, "min-sum": MINSUM, "
              TANH_CM: TANH_CM}
 _DTYPES = {"f32": F32, "f64": F64, "f16": F16, "f16pk": F16PK, F32: F32, F64: F64, F16: F16, F16PK: F16PK}
 _PATHS = {"auto": PATH_AUTO, "flood": PATH_FLOOD, "fused": PATH_FUSED, 0: 0, 1: 1, 2: 2}
+_SUM_ORDERS = {"reference": SUM_REFERENCE, "arraylet": SUM_ARRAYLET, "sparse": SUM_SPARSE, 0: 0, 1: 1, 2: 2}
 _SCHEDULES = {"flooding": SCHED_FLOODING, "flood": SCHED_FLOODING, "layered": SCHED_LAYERED, 0: 0, 1: 1}
 
 
@@ -393,17 +395,20 @@ class Code:
 class Decoder:
     """One decoder replica (ldpc_ctx): the object behind the reference's per-frame closure."""
 
-    def __init__(self, code: Code, variant="min", dtype="f32", max_batch=64, path="auto", _handle=None, device=None, schedule="flooding"):
+    def __init__(self, code: Code, variant="min", dtype="f32", max_batch=64, path="auto", _handle=None, device=None, schedule="flooding",
+                 sum_order="reference"):
+        """sum_order: "reference" | "arraylet" | "sparse" -- the column-sum order of that family of the reference's decoders
+        (ldpc_sum_order: parity modes, flood path)"""
         self.code = code
         self.max_batch = int(max_batch)
         self._owned = _handle is None
         if _handle is not None:
             self._h = _handle
-        elif device is None and _SCHEDULES[schedule] == SCHED_FLOODING:
+        elif device is None and _SCHEDULES[schedule] == SCHED_FLOODING and _SUM_ORDERS[sum_order] == SUM_REFERENCE:
             self._h = lib().ldpc_ctx_create_ex(code._h, _VARIANTS[variant], _DTYPES[dtype], int(max_batch), _PATHS[path])
         else:   # explicit device (replicas of one code on several GPUs of this process) and/or the layered schedule
             cfg = CtxConfig(C.sizeof(CtxConfig), -1 if device is None else int(device), _VARIANTS[variant], _DTYPES[dtype], int(max_batch),
-                            _PATHS[path], _SCHEDULES[schedule])
+                            _PATHS[path], _SCHEDULES[schedule], _SUM_ORDERS[sum_order])
             self._h = lib().ldpc_ctx_create_cfg(code._h, C.byref(cfg))
         if not self._h:
             raise LdpcError(lib().ldpc_last_error_code(), last_error())

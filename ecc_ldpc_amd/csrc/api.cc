@@ -371,6 +371,12 @@ ldpc_ctx *ldpc_ctx_create_cfg(const ldpc_code *code_c, const ldpc_ctx_config *cf
     const int variant = cfg->variant, dtype = cfg->dtype, max_batch = cfg->max_batch, path = cfg->path;
     const int schedule = cfg->struct_size >= sizeof(ldpc_ctx_config) ? cfg->schedule : LDPC_SCHED_FLOODING;
     if (schedule != LDPC_SCHED_FLOODING && schedule != LDPC_SCHED_LAYERED) { set_error(LDPC_EINVAL, "unknown schedule %d", schedule); return nullptr; }
+    const int sum_order = cfg->struct_size >= offsetof(ldpc_ctx_config, sum_order) + sizeof(int) ? cfg->sum_order : LDPC_SUM_REFERENCE;
+    if (sum_order != LDPC_SUM_REFERENCE && sum_order != LDPC_SUM_ARRAYLET && sum_order != LDPC_SUM_SPARSE) { set_error(LDPC_EINVAL, "unknown sum order %d", sum_order); return nullptr; }
+    if (sum_order != LDPC_SUM_REFERENCE && (schedule != LDPC_SCHED_FLOODING || path == LDPC_PATH_FUSED || cfg->dtype == LDPC_F16 || cfg->dtype == LDPC_F16PK)) {
+        set_error(LDPC_EUNSUPPORTED, "LDPC_SUM_ARRAYLET / LDPC_SUM_SPARSE are parity modes: flooding schedule, flood path, f32 or f64");
+        return nullptr;
+    }
     if (variant == LDPC_TANH_CM && (dtype != LDPC_F64 || schedule != LDPC_SCHED_FLOODING || path == LDPC_PATH_FUSED)) {
         set_error(LDPC_EUNSUPPORTED, "LDPC_TANH_CM (arraylet-cm numerics) is a parity mode: f64, flooding schedule, flood path (an f32 kernel is 1e-5 away from either tanh flavour)");
         return nullptr;
@@ -401,7 +407,7 @@ ldpc_ctx *ldpc_ctx_create_cfg(const ldpc_code *code_c, const ldpc_ctx_config *cf
         if (dtype == LDPC_F16) { set_error(LDPC_EUNSUPPORTED, "the layered schedule exists for f32 and f64"); return nullptr; }
         if (code->max_row_deg > 32) { set_error(LDPC_EUNSUPPORTED, "layered schedule: check rows above weight 32 (this code has %d)", code->max_row_deg); return nullptr; }
     }
-    const bool fused_ok = schedule == LDPC_SCHED_FLOODING && variant != LDPC_TANH_CM && ldpc::fused_supported(*code, variant, dtype);
+    const bool fused_ok = schedule == LDPC_SCHED_FLOODING && variant != LDPC_TANH_CM && sum_order == LDPC_SUM_REFERENCE && ldpc::fused_supported(*code, variant, dtype);
     if ((path == LDPC_PATH_FUSED || dtype == LDPC_F16PK) && !fused_ok) {
         if (schedule == LDPC_SCHED_LAYERED) { set_error(LDPC_EUNSUPPORTED, "no on-chip kernel for the layered schedule (state lives in HBM: LDPC_PATH_FLOOD)"); return nullptr; }
         set_error(LDPC_EUNSUPPORTED, "no fused kernel for this code/variant/dtype (%s)", ldpc::fused_why_not(*code, variant, dtype));
@@ -431,13 +437,13 @@ ldpc_ctx *ldpc_ctx_create_cfg(const ldpc_code *code_c, const ldpc_ctx_config *cf
     d.row_ptr = tabs.row_ptr; d.col_idx = tabs.col_idx; d.col_ptr = tabs.col_ptr; d.csc_edge = tabs.csc_edge;
     d.unsat = nullptr; d.iters = nullptr; d.conv = nullptr; d.done = nullptr;
     d.wide_rows = 0;
-    d.cm_order = variant == LDPC_TANH_CM ? 1 : 0;
+    d.cm_order = variant == LDPC_TANH_CM ? LDPC_SUM_ARRAYLET : sum_order;
     d.saturate = (variant == LDPC_MINSUM && dtype != LDPC_F64) ? 1 : 0;
     ctx->flood.variant = variant; ctx->flood.dtype = dtype; ctx->flood.timer = &ctx->timer;
     // (the staging buffers of the host-pointer entry points are allocated on first use: a context driven
     //  through ldpc_decode_batch_dev with 65 536 frames would otherwise park 3 GB of HBM)
     const int qc_flooding = schedule == LDPC_SCHED_FLOODING ? 1 : 0;
-    if (ctx->path == LDPC_PATH_FLOOD && ldpc::layered_qc_why_not(*code, variant, dtype, qc_flooding) == nullptr) {
+    if (ctx->path == LDPC_PATH_FLOOD && sum_order == LDPC_SUM_REFERENCE && ldpc::layered_qc_why_not(*code, variant, dtype, qc_flooding) == nullptr) {
         // QC code, either schedule: one workgroup per frame, state in HBM (a frame stops when ITS rule fires);
         // any other H, fp16 storage and the arraylet-cm parity mode: the batch-major kernels below
         ctx->lqc = ldpc::layered_qc_create(*code, variant, dtype, max_batch, qc_flooding);

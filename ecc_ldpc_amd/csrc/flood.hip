@@ -299,10 +299,14 @@ __global__ __launch_bounds__(256) void flood_vn_kernel(FloodDev d, const ST *__r
     CT acc = Store<ST>::ld(orig + (size_t)col * d.Bp + b);
     const int qb = d.col_ptr[col], qe = d.col_ptr[col + 1];
     const int deg = qe - qb;   // wave-uniform
-    if (d.cm_order) {   // arraylet-cm: lam' = orig + foldr1 (+) [ne' of the column, ascending row] (CachedMult.hs:190-194,261-262)
-        if (deg > 0) {
-            CT sum = Store<ST>::ld(msg + (size_t)d.csc_edge[qe - 1] * d.Bp + b);
+    if (d.cm_order) {   // parity modes of the other registered decoders (uniform branch)
+        if (deg > 0 && d.cm_order == 1) {   // arraylet, arraylet-min, arraylet-cm: lam' = orig + foldr1 (+) [ne' of the column, ascending row]
+            CT sum = Store<ST>::ld(msg + (size_t)d.csc_edge[qe - 1] * d.Bp + b);   // (Fast/Arraylet.hs:105-109,185-186; CachedMult.hs:190-194,261-262)
             for (int q = qe - 2; q >= qb; q--) sum = Store<ST>::ld(msg + (size_t)d.csc_edge[q] * d.Bp + b) + sum;
+            acc = acc + sum;
+        } else if (deg > 0) {               // sparse, sparsemin: lam' = orig + sum (map snd column), a left fold from 0 over ascending rows
+            CT sum = CT(0);                 // (Reference/Sparse.hs:112-114, Data/Sparse/Matrix.hs:35-36)
+            for (int q = qb; q < qe; q++) sum = sum + Store<ST>::ld(msg + (size_t)d.csc_edge[q] * d.Bp + b);
             acc = acc + sum;
         }
         Store<ST>::st(lam + (size_t)col * d.Bp + b, acc);

@@ -480,16 +480,20 @@ ldpc_ecc *ldpc_ecc_create_replicas(const char *codes_dir, const char *code_name,
         //   as a Boolean matrix; arraylet, arraylet-min, arraylet-cm (Fast/Arraylet.hs:138, ArrayletMin.hs:136,
         //   CachedMult.hs:207) and the CUDA plug-ins (GPU/CUDA/Arraylet1.hs:60, Arraylet2.hs:61, TwoArrays.hs:61,
         //   CachedMult.hs:66) take it quasi-cyclic.  arraylet-cm's last-ulp numerics exist in f64 only (LDPC_TANH_CM).
-        static const struct { const char *ref, *hip; bool as_bool; int dtype; } kAliases[] = {
-            {"reference", "hip-tanh", true, -1},      {"sparse", "hip-tanh", true, -1},
-            {"min", "hip-minsum", true, -1},          {"sparsemin", "hip-minsum", true, -1},
-            {"arraylet", "hip-tanh", false, -1},      {"arraylet-min", "hip-minsum", false, -1},
-            {"arraylet-cm", "hip-tanh-cm", false, LDPC_F64},
-            {"cuda-arraylet1", "hip-tanh", false, -1}, {"cuda-arraylet2", "hip-tanh", false, -1},
-            {"two-arrays", "hip-tanh", false, -1},     {"cuda-arraylet-cm", "hip-tanh", false, -1},
+        // In f64 (the reference's own type: `ldpc/arraylet-f64/...`) an alias also selects ITS decoder's column-sum order
+        // (ldpc_sum_order), so that the trajectory is that decoder's bit for bit; in f32 the on-chip kernels run (reference order,
+        // within 1e-5 of any of them).
+        static const struct { const char *ref, *hip; bool as_bool; int dtype; int sum_order; } kAliases[] = {
+            {"reference", "hip-tanh", true, -1, LDPC_SUM_REFERENCE},      {"sparse", "hip-tanh", true, -1, LDPC_SUM_SPARSE},
+            {"min", "hip-minsum", true, -1, LDPC_SUM_REFERENCE},          {"sparsemin", "hip-minsum", true, -1, LDPC_SUM_SPARSE},
+            {"arraylet", "hip-tanh", false, -1, LDPC_SUM_ARRAYLET},      {"arraylet-min", "hip-minsum", false, -1, LDPC_SUM_ARRAYLET},
+            {"arraylet-cm", "hip-tanh-cm", false, LDPC_F64, LDPC_SUM_REFERENCE},
+            {"cuda-arraylet1", "hip-tanh", false, -1, LDPC_SUM_REFERENCE}, {"cuda-arraylet2", "hip-tanh", false, -1, LDPC_SUM_REFERENCE},
+            {"two-arrays", "hip-tanh", false, -1, LDPC_SUM_REFERENCE},     {"cuda-arraylet-cm", "hip-tanh", false, -1, LDPC_SUM_REFERENCE},
         };
+        int sum_order = LDPC_SUM_REFERENCE;
         for (const auto &a : kAliases)
-            if (dec == a.ref) { dec = a.hip; as_bool = as_bool || a.as_bool; if (a.dtype >= 0) dtype = a.dtype; break; }
+            if (dec == a.ref) { dec = a.hip; as_bool = as_bool || a.as_bool; if (a.dtype >= 0) dtype = a.dtype; if (dtype == LDPC_F64) sum_order = a.sum_order; break; }
         if (dec == "hip-tanh") variant = LDPC_TANH;
         else if (dec == "hip-tanh-cm") variant = LDPC_TANH_CM;   // the reference's `arraylet-cm` numerics (f64 parity mode)
         else if (dec == "hip-minsum") variant = LDPC_MINSUM;
@@ -582,7 +586,7 @@ ldpc_ecc *ldpc_ecc_create_replicas(const char *codes_dir, const char *code_name,
                 r->device = devices ? devices[i] : ldpc_current_device();
                 ldpc_ctx_config cfg{};
                 cfg.struct_size = sizeof(cfg); cfg.device = devices ? devices[i] : -1; cfg.variant = variant; cfg.dtype = dtype; cfg.max_batch = max_batch;
-                cfg.path = path; cfg.schedule = schedule;
+                cfg.path = (sum_order != LDPC_SUM_REFERENCE) ? LDPC_PATH_FLOOD : path; cfg.schedule = schedule; cfg.sum_order = sum_order;
                 r->ctx = ldpc_ctx_create_cfg(e->code, &cfg);
                 ldpc_ecc_replica *rp = r.get();
                 e->reps.push_back(std::move(r));      // owned by the record from here on (ldpc_ecc_destroy frees it)

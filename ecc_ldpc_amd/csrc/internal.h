@@ -20,7 +20,8 @@ int set_error(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3
 struct FloodDev {
     int M, N, E, Bp;
     int wide_rows;           // rows of weight 9..32 go to the padded-register CN instance (0: O(d^2) fallback, A/B)
-    int cm_order;            // arraylet-cm column sum: orig + foldr1 (+) (CachedMult.hs:261-262) instead of foldr (+) orig
+    int cm_order;            // column-sum order (ldpc_sum_order): 0 foldr (+) orig (Orig.hs:96); 1 orig + foldr1 (+) (Fast/Arraylet.hs:185-186,
+                             // CachedMult.hs:261-262); 2 orig + sum from 0 (Reference/Sparse.hs:112-114)
     int saturate;            // min-sum below f64: a column's new LLR is kept within +-2^100 (ldpc_math.h sat_lam)
     const int32_t *row_ptr;  // [M+1]
     const int32_t *col_idx;  // [E]   CSR, ascending column inside a row

@@ -73,6 +73,16 @@ typedef enum { LDPC_F32 = 0, LDPC_F64 = 1, LDPC_F16 = 2, LDPC_F16PK = 3 } ldpc_d
  * (specification: oracle/ldpc_oracle.c oracle_decode_layered); a frame out of sweeps returns the channel decisions,
  * as Orig.hs:70 does.  `iters` counts sweeps. */
 typedef enum { LDPC_SCHED_FLOODING = 0, LDPC_SCHED_LAYERED = 1 } ldpc_schedule;
+/* order in which a column's messages are added to the channel LLR.  The registered decoders of the reference compute the same
+ * check rule but add a column up differently -- the last ulps of a Double, nothing else:
+ *   REFERENCE  foldr (+) orig: ne_1 + (ne_2 + (... + (ne_k + orig)))          Reference/Orig.hs:96, Min.hs:101 (`reference`, `min`)
+ *   ARRAYLET   orig + (ne_1 + (ne_2 + (... + ne_k)))                          Fast/Arraylet.hs:105-109,185-186, ArrayletMin.hs:191-192
+ *                                                                             (`arraylet`, `arraylet-min`; LDPC_TANH_CM implies it)
+ *   SPARSE     orig + (((0 + ne_1) + ne_2) + ... + ne_k)                      Reference/Sparse.hs:112-114, SparseMin.hs:117-119,
+ *                                                                             Data/Sparse/Matrix.hs:35-36 (`sparse`, `sparsemin`)
+ * rows ascending.  ARRAYLET and SPARSE are PARITY MODES (bit-exact f64 against oracle "arraylet" / "sparse"...): flooding
+ * schedule, LDPC_PATH_FLOOD batch-major kernels; the on-chip kernels add in REFERENCE order. */
+typedef enum { LDPC_SUM_REFERENCE = 0, LDPC_SUM_ARRAYLET = 1, LDPC_SUM_SPARSE = 2 } ldpc_sum_order;
 /* which kernel family a context uses */
 typedef enum {
     LDPC_PATH_AUTO = 0,  /* on-chip kernel when the code/variant/dtype has one, else the HBM path */
@@ -136,6 +146,7 @@ ldpc_ctx *ldpc_ctx_create_on(const ldpc_code *code, int device, int variant, int
 typedef struct {
     size_t struct_size;
     int device, variant, dtype, max_batch, path, schedule;
+    int sum_order;   /* ldpc_sum_order; read when struct_size covers it, else LDPC_SUM_REFERENCE */
 } ldpc_ctx_config;
 ldpc_ctx *ldpc_ctx_create_cfg(const ldpc_code *code, const ldpc_ctx_config *cfg);
 int ldpc_ctx_schedule(const ldpc_ctx *ctx);

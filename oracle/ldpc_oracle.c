@@ -45,6 +45,16 @@
 #define ORACLE_TANH 0
 #define ORACLE_MINSUM 1
 #define ORACLE_TANH_CM 2 /* the reference's `arraylet-cm` numerics (Fast/CachedMult.hs), sparse form only */
+/* The other registered decoders compute the SAME check rule as Orig.hs / Min.hs (product / foldr1 min' over the row in ascending
+ * column) but add a column up in their own order -- only the last ulps of a Double differ:
+ *   arraylet, arraylet-min (Fast/Arraylet.hs:185-186, Fast/ArrayletMin.hs:191-192):
+ *       lam' = zipWith (+) orig_lam (foldRowsMatrixlet (+) ne')  =  orig + (ne_1 + (ne_2 + (... + ne_k))), rows ascending
+ *       (Arraylet.hs:105-109: foldr1 over the column's blocks, ascending block row)
+ *   sparse, sparsemin (Reference/Sparse.hs:112-114, SparseMin.hs:117-119; Data/Sparse/Matrix.hs:35-36 colSum = sum . map snd):
+ *       lam' = orig + (((0 + ne_1) + ne_2) + ... + ne_k), rows ascending (the column's assoc list, built row by row)
+ * encoded on top of the rule: variant + ORACLE_SUM_ARRAYLET / ORACLE_SUM_SPARSE (sparse form only). */
+#define ORACLE_SUM_ARRAYLET 16
+#define ORACLE_SUM_SPARSE 32
 
 #define ORACLE_OK 0
 #define ORACLE_EARG (-1)
@@ -185,9 +195,10 @@ static int syndrome_zero(const graph_t *g, const double *lam) {
 }
 
 /* one update: (lam, ne) -> (ne2, lam2).  Orig.hs:81-98 / Min.hs:75-104 */
-static int step_sparse(const graph_t *g, int variant, const double *orig, const double *lam,
+static int step_sparse(const graph_t *g, int variant_and_order, const double *orig, const double *lam,
                        const double *ne, double *ne2, double *lam2) {
     double tbuf[4096];
+    const int variant = variant_and_order & 15, sum_order = variant_and_order & ~15;
     for (int m = 0; m < g->M; m++) {
         int b = g->row_ptr[m], d = g->row_ptr[m + 1] - b;
         if (d > 4096) return ORACLE_EARG;
@@ -239,6 +250,19 @@ static int step_sparse(const graph_t *g, int variant, const double *orig, const 
             if (q1 == q0) { lam2[j] = orig[j]; continue; }
             double acc = ne2[g->csc_edge[q1 - 1]];
             for (int q = q1 - 2; q >= q0; q--) acc = ne2[g->csc_edge[q]] + acc;
+            lam2[j] = orig[j] + acc;
+            continue;
+        }
+        if (sum_order == ORACLE_SUM_ARRAYLET) {   /* orig + foldr1 (+): as the arraylet-cm decoder above */
+            if (q1 == q0) { lam2[j] = orig[j]; continue; }
+            double acc = ne2[g->csc_edge[q1 - 1]];
+            for (int q = q1 - 2; q >= q0; q--) acc = ne2[g->csc_edge[q]] + acc;
+            lam2[j] = orig[j] + acc;
+            continue;
+        }
+        if (sum_order == ORACLE_SUM_SPARSE) {     /* orig + sum: a left fold from 0 over the rows in ascending order */
+            double acc = 0.0;
+            for (int q = q0; q < q1; q++) acc = acc + ne2[g->csc_edge[q]];
             lam2[j] = orig[j] + acc;
             continue;
         }

@@ -209,3 +209,111 @@ def ldpc_layered(H: np.ndarray, layer_ptr, variant: str, max_iterations: int, or
             trace.append(list(lam))
         if not odd and not flip:
             return np.array([hard(v) for v in lam], np.uint8), n, True
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The other registered decoders of the reference: the same check rule as Orig.hs / Min.hs, their OWN column-sum order.
+def ldpc_arraylet(sz: int, offsets: np.ndarray, variant: str, max_iterations: int, orig_lam, trace=None):
+    """Fast/Arraylet.hs:164-186 (`arraylet`, variant "tanh") and Fast/ArrayletMin.hs:167-192 (`arraylet-min`, variant "min")
+    over the Matrixlet of a quasi-cyclic H (offsets[br][bc] = rotation or -1), written the way the Haskell folds run:
+    ne_tanh per row = foldr1 (zipWith (++)) over the row's blocks in ascending block column (Arraylet.hs:99-103), i.e. the
+    row's (column, value) pairs in ascending column; the rule over `[v | (j, v) <- ne_tanh ! m, j /= n]`; and
+    lam' = zipWith (+) orig_lam (foldRowsMatrixlet (+) ne') -- per column a foldr1 (+) over ascending block rows
+    (Arraylet.hs:105-109), THEN orig + that."""
+    R, Cb = offsets.shape
+    orig = [float(v) for v in orig_lam]
+    lam = list(orig)
+    ne = {(br, bc): [0.0] * sz for br in range(R) for bc in range(Cb) if offsets[br, bc] >= 0}   # indexed by row r'
+    col = lambda bc, br, r: bc * sz + (r + int(offsets[br, bc])) % sz                             # Arraylet.hs:45 arrayArraylet
+    n = 0
+    while True:
+        if trace is not None:
+            trace.append(list(lam))
+        ok = True
+        for br in range(R):                       # ans: foldr1 (zipWith (/=)) over the row's blocks
+            blocks = [bc for bc in range(Cb) if offsets[br, bc] >= 0]
+            for r in range(sz):
+                p = False
+                for bc in blocks:
+                    p ^= hard(lam[col(bc, br, r)])
+                ok = ok and not p
+        if ok:
+            return np.array([hard(v) for v in lam], np.uint8), n, True
+        if n >= max_iterations:
+            return np.array([hard(v) for v in orig], np.uint8), n, False
+        ne2 = {}
+        for br in range(R):
+            blocks = [bc for bc in range(Cb) if offsets[br, bc] >= 0]
+            for r in range(sz):
+                if variant == "tanh":   # Arraylet.hs:179-183
+                    row = [(col(bc, br, r), math.tanh(-((lam[col(bc, br, r)] - ne[(br, bc)][r]) / 2))) for bc in blocks]
+                    for bc in blocks:
+                        prod = 1.0
+                        for j, v in row:                         # product: a left fold from 1
+                            if j != col(bc, br, r):
+                                prod = prod * v
+                        ne2.setdefault((br, bc), [0.0] * sz)[r] = -2 * atanh_prime(prod)
+                else:                   # ArrayletMin.hs:182-189
+                    row = [(col(bc, br, r), -(lam[col(bc, br, r)] - ne[(br, bc)][r])) for bc in blocks]
+                    for bc in blocks:
+                        vals = [v for j, v in row if j != col(bc, br, r)]
+                        acc = vals[-1]
+                        for v in reversed(vals[:-1]):            # foldr1 min'
+                            acc = min_prime(v, acc)
+                        ne2.setdefault((br, bc), [0.0] * sz)[r] = (-3 / 4) * acc
+        lam2 = list(orig)
+        for bc in range(Cb):
+            rows = [br for br in range(R) if offsets[br, bc] >= 0]
+            for c in range(sz):                                  # foldRowsArraylet: column c <- row (c - off) mod sz
+                vals = [ne2[(br, bc)][(c - int(offsets[br, bc])) % sz] for br in rows]
+                acc = vals[-1]
+                for v in reversed(vals[:-1]):                    # foldr1 (+)
+                    acc = v + acc
+                lam2[bc * sz + c] = orig[bc * sz + c] + acc      # zipWith (+) orig_lam
+        ne, lam, n = ne2, lam2, n + 1
+
+
+def ldpc_sparse(H: np.ndarray, variant: str, max_iterations: int, orig_lam, trace=None):
+    """Reference/Sparse.hs:46-115 (`sparse`, variant "tanh") and Reference/SparseMin.hs:49-119 (`sparsemin`, variant "min"):
+    messages in a column-major assoc structure; the rule over `j <- ones, j /= n` (the row's columns, ascending:
+    Sparse.hs:71-75 rowOnes); lam' = orig_lam ! j + colSum j ne', colSum = sum . map snd over the column's (row, value) list
+    (Data/Sparse/Matrix.hs:35-36) -- a left fold from 0 over ascending rows (the list is built row by row, :48-52 with the
+    index list of Sparse.hs colMajorIndexList)."""
+    M, N = H.shape
+    orig = [float(v) for v in orig_lam]
+    lam = list(orig)
+    ones = [[j for j in range(N) if H[m, j]] for m in range(M)]
+    col_rows = [[m for m in range(M) if H[m, j]] for j in range(N)]
+    ne = {}
+    at = lambda m, j: ne.get((m, j), 0.0)                                   # (!!!): absent -> 0
+    n = 0
+    while True:
+        if trace is not None:
+            trace.append(list(lam))
+        c_hat = [hard(v) for v in lam]
+        if all(sum(c_hat[j] for j in ones[m]) % 2 == 0 for m in range(M)):  # allMultFalse
+            return np.array(c_hat, np.uint8), n, True
+        if n >= max_iterations:
+            return np.array([hard(v) for v in orig], np.uint8), n, False
+        ne2 = {}
+        for m in range(M):
+            for nn in ones[m]:
+                if variant == "tanh":
+                    prod = 1.0
+                    for j in ones[m]:
+                        if j != nn:
+                            prod = prod * math.tanh(-((lam[j] - at(m, j)) / 2))
+                    ne2[(m, nn)] = -2 * atanh_prime(prod)
+                else:
+                    vals = [-(lam[j] - at(m, j)) for j in ones[m] if j != nn]
+                    acc = vals[-1]
+                    for v in reversed(vals[:-1]):
+                        acc = min_prime(v, acc)
+                    ne2[(m, nn)] = (-3 / 4) * acc
+        lam2 = []
+        for j in range(N):
+            s = 0.0
+            for m in col_rows[j]:                                           # sum = foldl (+) 0
+                s = s + ne2[(m, j)]
+            lam2.append(orig[j] + s)
+        ne, lam, n = ne2, lam2, n + 1

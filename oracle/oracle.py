@@ -11,6 +11,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "_build", "libldpc_oracle.so")
 TANH, MINSUM, TANH_CM = 0, 1, 2
+SUM_ARRAYLET, SUM_SPARSE = 16, 32   # column-sum orders of the other registered decoders (ldpc_oracle.c)
 _lib = None
 
 
@@ -53,6 +54,17 @@ def _variant(v):
         return MINSUM
     if v in (TANH_CM, "cm", "tanh-cm", "arraylet-cm"):
         return TANH_CM
+    # the other registered decoders: the same check rule, their own column-sum order (ldpc_oracle.c ORACLE_SUM_*)
+    if v == "arraylet":
+        return TANH | SUM_ARRAYLET
+    if v == "arraylet-min":
+        return MINSUM | SUM_ARRAYLET
+    if v == "sparse":
+        return TANH | SUM_SPARSE
+    if v == "sparsemin":
+        return MINSUM | SUM_SPARSE
+    if isinstance(v, int) and (v & 15) in (TANH, MINSUM) and (v & ~15) in (SUM_ARRAYLET, SUM_SPARSE):
+        return v
     raise ValueError(v)
 
 

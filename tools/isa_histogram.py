@@ -17,7 +17,7 @@ the loop two counts are given:
 A dynamic cross-check is the PMC pass of tools/profile.sh: SQ_INSTS_VALU / SQ_WAVES / (mean turns per frame).
 
 Issue cost classes (clk per wave-instruction per SIMD, measured on MI355X with tools/microbench_valu.hip,
-profiles/*_microbench*.txt): "2" full rate, "4" half rate, "8" transcendental (quarter rate, 8.2), "pk" packed f32 (4.7),
+profiles/*_microbench*.txt): "2" full rate, "4" half rate, "8" transcendental (quarter rate, 8.2), "pk" packed f32 (4.7), "pk16" packed 16-bit (4.2),
 "f64", "?" = not measured (priced at 4).  cost_weighted_clk = sum(count * clk): the VALU-pipe time one wave-turn needs at best.
 """
 from __future__ import annotations
@@ -39,6 +39,9 @@ CLK4 = {"v_min_f32", "v_max_f32", "v_med3_f32", "v_min3_f32", "v_max3_f32", "v_l
         "v_readfirstlane_b32", "v_readlane_b32", "v_writelane_b32", "v_mbcnt_lo_u32_b32", "v_mbcnt_hi_u32_b32"}
 TRANS = {"v_exp_f32", "v_log_f32", "v_rcp_f32", "v_rsq_f32", "v_sqrt_f32", "v_sin_f32", "v_cos_f32", "v_rcp_iflag_f32", "v_exp_legacy_f32", "v_log_legacy_f32"}
 PK2 = {"v_pk_fma_f32", "v_pk_mul_f32", "v_pk_add_f32", "v_pk_mov_b32"}   # one instruction, two f32 results per lane
+# packed 16-bit (two fp16 / u16 results per lane): 4.1-4.3 clk measured (tools/microbench_pk16.hip, profiles/r03_microbench_pk16.txt)
+PK16 = {"v_pk_fma_f16", "v_pk_add_f16", "v_pk_mul_f16", "v_pk_min_f16", "v_pk_max_f16", "v_pk_min_u16", "v_pk_max_u16", "v_pk_add_u16", "v_pk_sub_u16",
+        "v_pk_sub_i16", "v_pk_min_i16", "v_pk_max_i16", "v_pk_minimum3_f16", "v_pk_maximum3_f16"}
 
 
 def valu_class(m):
@@ -49,6 +52,8 @@ def valu_class(m):
         return "4", 4
     if base in TRANS:
         return "8", 8.2     # measured 8.1-8.4 (tools/microbench_valu2.hip, profiles/r02_microbench_valu2.txt)
+    if base in PK16:
+        return "pk16", 4.2
     if base in PK2:
         return "pk", 4.7    # measured 4.5-4.8 per instruction: two f32 results per lane at the rate of two plain ops
     if base.endswith("_f64") or "_f64_" in base:

@@ -75,6 +75,15 @@ def load(name) -> LoadedCode:
     return LoadedCode(name)
 
 
+def iters_agree(its, oi):
+    """f32 kernel vs Double oracle: hard bits and flags are compared exactly elsewhere; the TURN a frame stops at may move by one
+    when a float LLR and the Double LLR straddle zero.  Measured (tools/iters_f32_vs_f64.py, profiles/r03_iters_f32_vs_f64.txt):
+    14 398 of 14 400 frames identical over three codes, both rules, the waterfall; the two others off by +1 / -1.  Bar: at most
+    max(1, 0.5 %) of the frames differ, none by more than one turn."""
+    d = np.asarray(its).astype(int) - np.asarray(oi).astype(int)
+    return int((d != 0).sum()) <= max(1, int(0.005 * len(d))) and (np.abs(d).max() if len(d) else 0) <= 1
+
+
 def lam_tolerance(g, ne_ref, lam_ref, rel=1e-5):
     """Per-entry tolerance for an fp32 LLR compared with the double oracle:
         rel * max(1, |lam_ref|)                      (north_star: 1e-5)

@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 
 from oracle import oracle
-from tests.helpers import lam_tolerance, load
+from tests.helpers import lam_tolerance, load, iters_agree
 
 pytestmark = pytest.mark.gpu
 
@@ -95,10 +95,10 @@ def test_f32_free_running_hard_bits_match(hip, name, iters, dbs, variant):
     obits, oits, oconv = oracle.decode_batch(c.graph, variant, iters, llr, nthreads=8)
     assert np.array_equal(bits, obits)
     assert np.array_equal(conv, oconv)
-    # iteration counts may differ by fp32 rounding only on knife-edge frames; report, require >= 95 %
+    # iteration counts may move by one turn on knife-edge frames (helpers.iters_agree has the measured rate)
     same = (its == oits).mean()
     print(f"{name} {variant}: {same * 100:.1f}% identical iteration counts, {conv.mean() * 100:.0f}% converged")
-    assert same >= 0.95
+    assert iters_agree(its, oits)
 
 
 def test_edge_cases(hip):

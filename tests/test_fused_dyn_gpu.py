@@ -11,7 +11,7 @@ import numpy as np
 import pytest
 
 from oracle import channel, oracle
-from tests.helpers import load, lam_tolerance
+from tests.helpers import load, lam_tolerance, iters_agree
 
 pytestmark = pytest.mark.gpu
 
@@ -51,7 +51,7 @@ def test_synthetic_rotations_f32(hip, sz, monkeypatch):
         bits, its, conv = dec.decode_batch(llr.astype(np.float32), 50)
         ob, oi, oc = oracle.decode_batch(g, variant, 50, llr, nthreads=8)
         assert np.array_equal(bits, ob) and np.array_equal(conv, oc), (sz, variant)
-        assert (its == oi).mean() >= 0.9
+        assert iters_agree(its, oi)
         flood = hip.Decoder(code, variant, "f32", F, path="flood")
         fb, fi, fc = flood.decode_batch(llr.astype(np.float32), 50)
         assert np.array_equal(bits, fb) and np.array_equal(its, fi) and np.array_equal(conv, fc)   # same arithmetic, same order

@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 
 from oracle import oracle
-from tests.helpers import load
+from tests.helpers import load, iters_agree
 
 pytestmark = pytest.mark.gpu
 
@@ -90,7 +90,7 @@ def test_f32_free_running_matches_oracle_and_flood(hip, name, dbs):
     assert np.array_equal(b1, b2) and np.array_equal(i1, i2) and np.array_equal(c1, c2)
     ob, oi, oc = oracle.decode_batch(c.graph, "min", 50, llr, nthreads=8)
     assert np.array_equal(b1, ob) and np.array_equal(c1, oc)
-    assert (i1 == oi).mean() >= 0.95
+    assert iters_agree(i1, oi)
     print(f"{name}: fused == flood exactly; vs oracle {100 * (i1 == oi).mean():.1f}% identical iteration counts, {c1.mean() * 100:.0f}% converged")
 
 
@@ -177,7 +177,7 @@ def test_tanh_f32_fused(hip, name, dbs):
     b2, i2, c2 = flood.decode_batch(llr.astype(np.float32), 50)
     assert np.array_equal(b1, b2) and np.array_equal(i1, i2) and np.array_equal(c1, c2)
     ob, oi, oc = oracle.decode_batch(c.graph, "tanh", 50, llr, nthreads=8)
-    assert np.array_equal(b1, ob) and np.array_equal(c1, oc) and (i1 == oi).mean() >= 0.95
+    assert np.array_equal(b1, ob) and np.array_equal(c1, oc) and iters_agree(i1, oi)
     states = []
     for f in range(0, len(llr), max(1, len(llr) // 6)):
         o = oracle.decode(c.graph, "tanh", 50, llr[f], trace=True)

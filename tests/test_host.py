@@ -7,7 +7,7 @@ import pytest
 
 import ecc_ldpc_amd as E
 from oracle import formats, oracle
-from tests.helpers import CODES, load
+from tests.helpers import CODES, load, iters_agree
 
 
 def test_loaders_match_the_restated_parsers():
@@ -241,3 +241,47 @@ def test_contexts_release_their_memory(hip):
     torch.cuda.synchronize()
     free1, _ = torch.cuda.mem_get_info()
     assert free0 - free1 < 8 << 20, (free0, free1)
+
+
+@pytest.mark.gpu
+def test_multi_circulant_q_file_decodes_through_the_csr_route(hip, tmp_path):
+    """SURVEY.md section 8 row f3's named case: a `.q` whose blocks hold MORE than one circulant.  The reference's quasi-cyclic
+    decoders reject it (Fast/Arraylet.hs:72-73 "non-powers of two initial value"); here the loader keeps the file, the
+    rotation-table route says so, and the record decodes it as a plain graph (what `Matrix Bool` decoders of the reference get)
+    -- against the oracle on the expansion of QuasiCyclic.hs:19-25."""
+    sz, R, Cb = 40, 3, 7                                   # not a power of two either
+    rng = np.random.default_rng(8)
+    rows = [[0] * Cb for _ in range(R)]
+    for br in range(R):
+        for bc in range(Cb):
+            if rng.random() < 0.75:
+                ks = rng.choice(sz, size=int(rng.integers(1, 4)), replace=False)     # 1..3 circulants in one block
+                rows[br][bc] = int(sum(1 << int(k) for k in ks))
+    rows[0][0] = (1 << 3) | (1 << 17) | (1 << 39)
+    d = tmp_path / "codes" / "multi"
+    d.mkdir(parents=True)
+    (d / "H.q").write_text(f"{sz}\n" + "\n".join(" ".join(str(v) for v in r) for r in rows) + "\n")
+    m = hip.Matrix.load(str(tmp_path / "codes"), "multi/H")
+    H = formats.qc_expand(sz, rows)
+    assert (m.rows, m.cols, m.sz) == (R * sz, Cb * sz, sz) and np.array_equal(m.dense(), H)
+    with pytest.raises(hip.LdpcError) as e:
+        m.qc_offsets()
+    assert e.value.code == -5 and "non-powers of two" in str(e.value)
+    g = oracle.Graph.from_dense(H)
+    from oracle import channel
+    k, N = (Cb - R) * sz, Cb * sz
+    llr = channel.frames(np.zeros((24, N), np.uint8), 3.0, k, N, N, 77)
+    for nm, variant in (("hip-minsum", "min"), ("hip-tanh", "tanh")):
+        ecc = hip.ECC(str(tmp_path / "codes"), f"ldpc/{nm}/multi/40", max_batch=24)   # H only: k = cols - rows, all-zero codewords
+        assert (ecc.message_length, ecc.unpunctured_length) == (k, N) and ecc.code.E == g.E
+        bits, its, conv = ecc.decoder.decode_batch(llr.astype(np.float32), 40)
+        ob, oi, oc = oracle.decode_batch(g, variant, 40, llr, nthreads=4)
+        assert np.array_equal(bits, ob) and np.array_equal(conv, oc) and iters_agree(its, oi)
+        d64 = hip.Decoder(ecc.code, variant, "f64", 24)
+        b64, i64, c64, tr = d64.decode_trace(llr, 40)
+        for f in range(0, 24, 5):
+            o = oracle.decode(g, variant, 40, llr[f], trace=True)
+            assert i64[f] == o["iters"] and np.array_equal(b64[f], o["bits"])
+            if variant == "min":
+                assert np.array_equal(tr[f, : o["iters"] + 1], o["trace_lam"])
+        d64.close(); ecc.close()

@@ -439,6 +439,7 @@ ldpc_ctx *ldpc_ctx_create_cfg(const ldpc_code *code_c, const ldpc_ctx_config *cf
     d.wide_rows = 0;
     d.cm_order = variant == LDPC_TANH_CM ? LDPC_SUM_ARRAYLET : sum_order;
     d.saturate = (variant == LDPC_MINSUM && dtype != LDPC_F64) ? 1 : 0;
+    d.pairs4 = (variant == LDPC_TANH && dtype != LDPC_F64 && code->sz == 0 && code->max_row_deg <= 4) ? 1 : 0;
     ctx->flood.variant = variant; ctx->flood.dtype = dtype; ctx->flood.timer = &ctx->timer;
     // (the staging buffers of the host-pointer entry points are allocated on first use: a context driven
     //  through ldpc_decode_batch_dev with 65 536 frames would otherwise park 3 GB of HBM)

@@ -58,6 +58,17 @@ __device__ __forceinline__ void cn_row_regs(const FloodDev &d, ST *__restrict__ 
     }
     if (par) d.unsat[b] = stamp; // benign race: every writer stores the same value
     if (syndrome_only) return;
+    if constexpr (VARIANT == LDPC_V_TANH && sizeof(CT) == 4 && DEG <= 4) {
+        if (d.pairs4) {   // (uniform) a code of row weight <= 4: the pair-product form, bit-identical with the on-chip DMAX = 4 kernels
+            float p[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) p[k] = k < DEG ? t[k] : INFINITY;
+            cn_tanh_f32_pairs4(p, DEG);
+#pragma unroll
+            for (int k = 0; k < DEG; k++) Store<ST>::st(msg + (size_t)(ebeg + k) * d.Bp + b, p[k]);
+            return;
+        }
+    }
     cn_update<CT, VARIANT, DEG>(t);
 #pragma unroll
     for (int k = 0; k < DEG; k++) Store<ST>::st(msg + (size_t)(ebeg + k) * d.Bp + b, t[k]);

@@ -22,6 +22,8 @@ struct FloodDev {
     int wide_rows;           // rows of weight 9..32 go to the padded-register CN instance (0: O(d^2) fallback, A/B)
     int cm_order;            // column-sum order (ldpc_sum_order): 0 foldr (+) orig (Orig.hs:96); 1 orig + foldr1 (+) (Fast/Arraylet.hs:185-186,
                              // CachedMult.hs:261-262); 2 orig + sum from 0 (Reference/Sparse.hs:112-114)
+    int pairs4;              // tanh rule, f32 arithmetic, a plain-graph code whose heaviest row has weight <= 4: rows use ldpc_math.h
+                             // cn_tanh_f32_pairs4, as the on-chip kernels' DMAX = 4 instances do (the paths stay bit-identical)
     int saturate;            // min-sum below f64: a column's new LLR is kept within +-2^100 (ldpc_math.h sat_lam)
     const int32_t *row_ptr;  // [M+1]
     const int32_t *col_idx;  // [E]   CSR, ascending column inside a row

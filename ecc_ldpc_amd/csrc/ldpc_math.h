@@ -263,6 +263,34 @@ __device__ __forceinline__ void cn_tanh_f32(float (&t)[DEG]) {
     }
 }
 
+// Rows of weight <= 4 (a code whose heaviest row has weight 4: codes/1920.1280.3.303, BASELINE configs[2]): the four
+// leave-one-out (A, S) pairs straight from two PAIR products instead of prefix / suffix chains --
+//     P01 = e0 (+) e1 = (1 + e0 e1, e0 + e1),  P23 likewise (the common factor 2 of TanhAS::one() dropped: only A/S matters)
+//     edge 0: P23 (+) e1,  edge 1: P23 (+) e0,  edge 2: P01 (+) e3,  edge 3: P01 (+) e2          ((A, S) (+) e = (A + e S, S + e A))
+// 4 + 8 fused multiply-adds per row against 40 operations in the chained form (r03: -15 % VALU per turn of the configs[2]
+// kernel).  Same real function; the properties the chained form is built around hold here too: a zero t_j (e = 1) gives A = S
+// EXACTLY for every other edge (fma(1, e, 1) and 1 + e round alike; fma(1, S, A) and fma(1, A, S) too), hence ne' = 0
+// exactly, and a padded slot (t = +inf, e = 0) is the neutral factor, so a row of weight 2 or 3 padded to 4 gets exactly what
+// the formula written for its own weight would give.  Every path that can see such a code uses THIS form (the on-chip
+// kernels' DMAX = 4 instances, and flood.hip when FloodDev::pairs4 is set), so that they keep agreeing bit for bit.
+__device__ __forceinline__ void cn_tanh_f32_pairs4(float (&t)[4], int deg) {
+    uint32_t sg[4], X = 0;
+    float e[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        sg[k] = __float_as_uint(t[k]) & 0x80000000u;
+        X ^= sg[k];
+        e[k] = TanhAS::e_of(fabsf(t[k]));   // padding: |t| = +inf -> e = 0
+    }
+    const TanhAS p01{fmaf(e[0], e[1], 1.0f), e[0] + e[1]}, p23{fmaf(e[2], e[3], 1.0f), e[2] + e[3]};
+    const float mag[4] = {p23.times(e[1]).mag(), p23.times(e[0]).mag(), p01.times(e[3]).mag(), p01.times(e[2]).mag()};
+    // sign as in cn_tanh_f32: ne'_k > 0 iff the number of negative factors among j /= k is odd, factor_j < 0 iff t_j > 0;
+    // padded slots carry sign bit 0 like a positive t and are taken back out through the real degree
+    const uint32_t base = X ^ ((deg & 1) ? 0u : 0x80000000u);
+#pragma unroll
+    for (int k = 0; k < 4; k++) t[k] = __uint_as_float(__float_as_uint(mag[k]) | (~(base ^ sg[k]) & 0x80000000u));
+}
+
 // ---------------------------------------------------------------- padded rows (generic on-chip kernel)
 // Rows of any degree <= DMAX: slots k >= deg hold t = +inf, which is neutral for both rules
 // (|t| = inf never wins a min; e^-inf = 0 is the neutral factor; sign bit 0) -- only the "(D odd)" term of the
@@ -319,6 +347,8 @@ __device__ __forceinline__ void cn_update_padded(CT (&t)[DMAX], int deg) {
             if (isinf(y)) y = (prod > 0.0 ? 1.0 : -1.0) * kAtanhClamp;
             t[k] = -2.0 * y;
         }
+    } else if constexpr (DMAX == 4) {
+        cn_tanh_f32_pairs4(t, deg);
     } else {
         static_assert(DMAX <= 32, "sign word holds 32 edges");
         uint32_t sg = 0, X = 0;

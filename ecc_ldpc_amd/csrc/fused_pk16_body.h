@@ -21,6 +21,10 @@
 // min-sum than a literal fp16 transcription would be.  BER against the f32 decoder: DESIGN.md.
 // The two frames of a lane stop independently (a finished frame keeps its answer in a snapshot register and its half keeps
 // computing until the partner is done, like the frames of a workgroup in the split kernel for sz < 64).
+// Tried in r03 and dropped: every block column of L kept TWICE in LDS, V positions apart, so that a check row's gather at
+// p + rotation never wraps (address = the lane's base register + an immediate: 945 -> 855 VALU instructions per wave-turn, LDS
+// 45 KB per workgroup, column updates storing both copies).  jpl.4096, 65 536 frames, 2 dB: 13.2 ms per launch against 11.85 --
+// the doubled LDS write traffic (both copies on the same bank) costs more than the 10 % of VALU issue it saves.
 #pragma once
 #include "fused_split_body.h"
 

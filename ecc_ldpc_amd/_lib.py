@@ -11,7 +11,7 @@ import weakref
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.environ.get("LDPC_SO") or os.path.join(HERE, "libldpc_hip.so")  # LDPC_SO: ablation builds (tools/)
+SO_PATH = (os.environ.get("LDPC_SO") or None) or os.path.join(HERE, "libldpc_hip.so")  # LDPC_SO: ablation builds (tools/)
 
 OK, EINVAL, ENOMEM, EHIP, ENODEVICE, EUNSUPPORTED, EDEGREE, EFORMAT, ENOTFOUND = 0, -1, -2, -3, -4, -5, -6, -7, -8
 TANH, MINSUM, TANH_CM = 0, 1, 2

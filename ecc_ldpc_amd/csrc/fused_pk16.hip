@@ -12,7 +12,22 @@
 #define PK16_WAVES_PER_EU 3
 #endif
 
+// wave groups a frame pair's block rows are dealt to (2 = as the f32 split kernel).  Measured on jpl.4096, 65 536 frames, 2 dB
+// (profiles/r03_pk16_np_ab.txt), ms per launch: 2 groups at 3 waves per SIMD 11.88 (the default); 4 groups (512 threads, 39
+// messages per thread, 115 VGPRs, 4 waves) 13.93; 4 groups at 5 waves (spills) 16.85; 3 groups 19.22; 2 groups at 4 waves (spills) 21.99.
+#ifndef PK16_NP
+#define PK16_NP 2
+#endif
+
 namespace ldpc {
+
+struct PlanPk16 {   // the AR4JA rate-4/5 plan of fused_common.h with its own number of wave groups
+    static constexpr int NBR = PlanAR4JA45::NBR, NBC = PlanAR4JA45::NBC, NEDGE = PlanAR4JA45::NEDGE, DMAX = PlanAR4JA45::DMAX;
+    static constexpr int NP = PK16_NP;
+    static constexpr int owner_br(int br) { return br % NP; }
+    static constexpr int deg(int br) { return PlanAR4JA45::deg(br); }
+    static constexpr int ebeg(int br) { return PlanAR4JA45::ebeg(br); }
+};
 
 template <class Plan, int SZ, class T>
 __global__ __launch_bounds__((SplitGeom<Plan, SZ>::THREADS), PK16_WAVES_PER_EU)
@@ -26,17 +41,17 @@ bool fused_pk16_has(int variant, int sz, int static_id) {
 
 template <int SZ, class T>
 static void launch_pk16(hipStream_t st, FusedArgs &a) {
-    using G = SplitGeom<PlanAR4JA45, SZ>;
+    using G = SplitGeom<PlanPk16, SZ>;
     const int per_wg = 2 * G::CPW;
     const int grid = (a.batch + per_wg - 1) / per_wg;
-    hipLaunchKernelGGL((fused_pk16_kernel<PlanAR4JA45, SZ, T>), dim3(grid), dim3(G::THREADS), 0, st, a);
+    hipLaunchKernelGGL((fused_pk16_kernel<PlanPk16, SZ, T>), dim3(grid), dim3(G::THREADS), 0, st, a);
 }
 
 int fused_pk16_launch(int sz, hipStream_t st, FusedArgs &a, KernelTimer *timer, LaunchInfo *info) {
     if (info) {
-        snprintf(info->name, sizeof(info->name), "ldpc::fused_pk16_kernel<ldpc::PlanAR4JA45, %d, ", sz);
-        info->threads = sz == 128 ? SplitGeom<PlanAR4JA45, 128>::THREADS : SplitGeom<PlanAR4JA45, 32>::THREADS;
-        info->frames_per_wg = 2 * (sz == 128 ? SplitGeom<PlanAR4JA45, 128>::CPW : SplitGeom<PlanAR4JA45, 32>::CPW);
+        snprintf(info->name, sizeof(info->name), "ldpc::fused_pk16_kernel<ldpc::PlanPk16, %d, ", sz);
+        info->threads = sz == 128 ? SplitGeom<PlanPk16, 128>::THREADS : SplitGeom<PlanPk16, 32>::THREADS;
+        info->frames_per_wg = 2 * (sz == 128 ? SplitGeom<PlanPk16, 128>::CPW : SplitGeom<PlanPk16, 32>::CPW);
     }
     if (timer) timer->begin(st);
     if (sz == 128) launch_pk16<128, TabJpl4096>(st, a);

@@ -306,6 +306,7 @@ def proof_of_work_layered(args, E, ecc, dec, sim, llr_t, msg_t, bits, iters_t, c
 PROFILE_TAGS = {   # committed rocprofv3 PMC passes (tools/profile.sh): (code, variant, dtype, kernel family) -> (tag, frames per launch profiled)
     ("jpl.4096.4.5", "minsum", "f32", "fused"): ("jpl4096_f32_minsum", 65536), ("jpl.1024.4.5", "minsum", "f32", "fused"): ("jpl1024_f32_minsum", 65536),
     ("jpl.4096.4.5", "tanh", "f32", "fused"): ("jpl4096_f32_tanh", 16384), ("1920.1280.3.303", "tanh", "f32", "fused"): ("mackay_f32_tanh", 65536),
+    ("jpl.4096.4.5", "minsum", "f16pk", "fused"): ("jpl4096_f16pk_minsum", 65536),
     ("jpl.4096.4.5", "minsum", "f32", "flood_qc"): ("floodqc_jpl4096_f32_minsum", 16384),
     ("dvbs2like.64800.1.2", "minsum", "f32", "layered_qc"): ("dvbs2like_layered_f32_minsum", 32768)}
 
@@ -322,7 +323,7 @@ def committed_traffic(args, dec, B):
     if ent is None:
         return None, None
     tag, frames = ent
-    for rnd in ("r02_final_", "r01_final_"):
+    for rnd in ("r03_final_", "r02_final_", "r01_final_"):
         path = os.path.join(ROOT, "profiles", rnd + tag + "_pmc.json")
         try:
             prof = json.load(open(path))

@@ -11,7 +11,8 @@
 -- one Haskell process drives every GPU of the node; and the replicas of one GPU share a coalescing batcher
 -- (ldpc_batcher_*): frames that several Haskell threads decode at the same moment go to the device in ONE launch.
 {-# LANGUAGE ForeignFunctionInterface #-}
-module ECC.Code.LDPC.GPU.HIP (codeTanh, codeMinSum, codeTanhBool, codeMinSumBool, codeMinSumLayered, hipThreads) where
+module ECC.Code.LDPC.GPU.HIP (codeTanh, codeMinSum, codeTanhBool, codeMinSumBool, codeMinSumLayered, codeMinSumF16PK,
+                              codeTanhArrayletF64, codeTanhSparseF64, hipThreads) where
 
 import ECC.Code.LDPC.Utils            (mkLDPC_CodeIO)
 import ECC.Types
@@ -48,8 +49,9 @@ foreign import ccall safe   "ldpc_batcher_create"     c_batcher    :: Ptr LdpcCt
 foreign import ccall safe   "ldpc_batcher_decode_one" c_decodeOne  :: Ptr LdpcBatcher -> CInt -> Ptr Double -> Ptr Word8
                                                                    -> Ptr CInt -> Ptr CInt -> IO CInt
 
-tanhRule, minSumRule, f32, flooding, layered, pathAuto :: CInt
-tanhRule = 0; minSumRule = 1; f32 = 0; flooding = 0; layered = 1; pathAuto = 0
+tanhRule, minSumRule, f32, f64, f16pk, flooding, layered, pathAuto, sumReference, sumArraylet, sumSparse :: CInt
+tanhRule = 0; minSumRule = 1; f32 = 0; f64 = 1; f16pk = 3; flooding = 0; layered = 1; pathAuto = 0
+sumReference = 0; sumArraylet = 1; sumSparse = 2      -- ldpc_sum_order: whose column-sum order the f64 parity modes follow
 
 -- | maxThreadCount of these codes (Utils.hs:53): how many Haskell threads may decode at once.  The harness picks the
 -- closure by ThreadId `rem` maxThreadCount (Utils.hs:63-69).
@@ -63,7 +65,7 @@ coalesceWaitUs = 200
 
 -- vars of the Code (the CUDA plug-ins keep their CudaAllocations there, Arraylet2.hs:287-293): the number of GPUs and,
 -- per (graph, rule, schedule, GPU), the batcher its replicas share
-data Vars = Vars { nDev :: Int, nextReplica :: IORef Int, batchers :: IORef [((String, CInt, CInt, Int), Ptr LdpcBatcher)] }
+data Vars = Vars { nDev :: Int, nextReplica :: IORef Int, batchers :: IORef [((String, (CInt, CInt, CInt, CInt), Int), Ptr LdpcBatcher)] }
 
 initialize :: IO Vars
 initialize = do
@@ -76,12 +78,20 @@ initialize = do
 finalize :: Vars -> IO ()
 finalize _ = c_shutdown >> return ()
 
-codeTanh, codeMinSum, codeMinSumLayered, codeTanhBool, codeMinSumBool :: Code
-codeTanh          = mkLDPC_CodeIO "hip-tanh"           hipThreads E.encoder (decoderQC   tanhRule   flooding) initialize finalize
-codeMinSum        = mkLDPC_CodeIO "hip-minsum"         hipThreads E.encoder (decoderQC   minSumRule flooding) initialize finalize
-codeMinSumLayered = mkLDPC_CodeIO "hip-minsum-layered" hipThreads E.encoder (decoderQC   minSumRule layered)  initialize finalize
-codeTanhBool      = mkLDPC_CodeIO "hip-tanh-bool"      hipThreads O.encoder (decoderBool tanhRule   flooding) initialize finalize
-codeMinSumBool    = mkLDPC_CodeIO "hip-minsum-bool"    hipThreads O.encoder (decoderBool minSumRule flooding) initialize finalize
+-- (rule, dtype, schedule, column-sum order)
+type Mode = (CInt, CInt, CInt, CInt)
+
+codeTanh, codeMinSum, codeMinSumLayered, codeTanhBool, codeMinSumBool, codeMinSumF16PK, codeTanhArrayletF64, codeTanhSparseF64 :: Code
+codeTanh          = mkLDPC_CodeIO "hip-tanh"           hipThreads E.encoder (decoderQC   (tanhRule,   f32, flooding, sumReference)) initialize finalize
+codeMinSum        = mkLDPC_CodeIO "hip-minsum"         hipThreads E.encoder (decoderQC   (minSumRule, f32, flooding, sumReference)) initialize finalize
+codeMinSumLayered = mkLDPC_CodeIO "hip-minsum-layered" hipThreads E.encoder (decoderQC   (minSumRule, f32, layered,  sumReference)) initialize finalize
+codeTanhBool      = mkLDPC_CodeIO "hip-tanh-bool"      hipThreads O.encoder (decoderBool (tanhRule,   f32, flooding, sumReference)) initialize finalize
+codeMinSumBool    = mkLDPC_CodeIO "hip-minsum-bool"    hipThreads O.encoder (decoderBool (minSumRule, f32, flooding, sumReference)) initialize finalize
+-- arithmetic in packed fp16, two frames per lane (LDPC_F16PK: the shipped AR4JA matrices)
+codeMinSumF16PK   = mkLDPC_CodeIO "hip-minsum-f16pk"   hipThreads E.encoder (decoderQC   (minSumRule, f16pk, flooding, sumReference)) initialize finalize
+-- Double twins of two of the reference's own decoders, last ulp included: run them next to `arraylet` / `sparse` in one harness
+codeTanhArrayletF64 = mkLDPC_CodeIO "hip-tanh-f64-arraylet"    hipThreads E.encoder (decoderQC   (tanhRule, f64, flooding, sumArraylet)) initialize finalize
+codeTanhSparseF64   = mkLDPC_CodeIO "hip-tanh-bool-f64-sparse" hipThreads O.encoder (decoderBool (tanhRule, f64, flooding, sumSparse))   initialize finalize
 
 -- rotation of the single set bit, -1 for an empty block (Fast/Arraylet.hs:68-79)
 offsetsOf :: Q.QuasiCyclic Integer -> [Int32]
@@ -95,45 +105,47 @@ offsetsOf (Q.QuasiCyclic _ qm) = map f (M.toList qm)
 type Closure = Rate -> Int -> U.Vector Double -> IO (Maybe (U.Vector Bool))
 
 -- `decoder vars h` is called maxThreadCount times by mkLDPC (Utils.hs:53); call number i serves GPU (i mod #GPUs)
-decoderQC :: CInt -> CInt -> Vars -> Q.QuasiCyclic Integer -> IO Closure
-decoderQC rule sched vars h@(Q.QuasiCyclic sz qm) = do
+decoderQC :: Mode -> Vars -> Q.QuasiCyclic Integer -> IO Closure
+decoderQC mode vars h@(Q.QuasiCyclic sz qm) = do
   let offs = S.fromList (offsetsOf h)
       key  = "qc" ++ show (sz, M.nrows qm, M.ncols qm, S.toList offs)
       mk   = S.unsafeWith offs $ \p -> c_codeQC (fromIntegral sz) (fromIntegral (M.nrows qm)) (fromIntegral (M.ncols qm)) p
-  closureFor vars key rule sched mk (sz * M.ncols qm)
+  closureFor vars key mode mk (sz * M.ncols qm)
 
 -- the `Matrix Bool` decoders' input (Reference/Orig.hs:30-31): H as CSR, columns ascending inside a row
-decoderBool :: CInt -> CInt -> Vars -> M.Matrix Bool -> IO Closure
-decoderBool rule sched vars h = do
+decoderBool :: Mode -> Vars -> M.Matrix Bool -> IO Closure
+decoderBool mode vars h = do
   let rows   = [ [ fromIntegral (c - 1) :: Int32 | c <- [1 .. M.ncols h], h M.! (r, c) ] | r <- [1 .. M.nrows h] ]
       rowPtr = S.fromList (scanl (+) 0 (map (fromIntegral . length) rows)) :: S.Vector Int32
       colIdx = S.fromList (concat rows) :: S.Vector Int32
       key    = "csr" ++ show (M.nrows h, M.ncols h, S.toList colIdx)
       mk     = S.unsafeWith rowPtr $ \pr -> S.unsafeWith colIdx $ \pc ->
                  c_codeCSR (fromIntegral (M.nrows h)) (fromIntegral (M.ncols h)) pr pc
-  closureFor vars key rule sched mk (M.ncols h)
+  closureFor vars key mode mk (M.ncols h)
 
--- one batcher (one ldpc_ctx behind it) per (graph, rule, schedule, GPU); every replica of that GPU shares it
-closureFor :: Vars -> String -> CInt -> CInt -> IO (Ptr LdpcCode) -> Int -> IO Closure
-closureFor vars key rule sched mkCode n = do
+-- one batcher (one ldpc_ctx behind it) per (graph, mode, GPU); every replica of that GPU shares it
+closureFor :: Vars -> String -> Mode -> IO (Ptr LdpcCode) -> Int -> IO Closure
+closureFor vars key mode@(rule, dtype, sched, sumOrder) mkCode n = do
   i <- atomicModifyIORef' (nextReplica vars) (\k -> (k + 1, k))
   let dev = i `mod` nDev vars
-      k4  = (key, rule, sched, dev)
+      k4  = (key, mode, dev)
   known <- lookup k4 <$> readIORef (batchers vars)
   b <- case known of
          Just b  -> return b
          Nothing -> do
            code <- mkCode
            if code == nullPtr then c_lastError >>= peekCString >>= error else return ()
-           -- ldpc_ctx_config { size_t struct_size; int device, variant, dtype, max_batch, path, schedule; }
-           ctx <- allocaBytes 32 $ \cfg -> do
-                    pokeByteOff cfg 0  (32 :: CSize)
+           -- ldpc_ctx_config { size_t struct_size; int device, variant, dtype, max_batch, path, schedule, sum_order; } (40 bytes)
+           ctx <- allocaBytes 40 $ \cfg -> do
+                    pokeByteOff cfg 0  (40 :: CSize)
                     pokeByteOff cfg 8  (fromIntegral dev :: CInt)
                     pokeByteOff cfg 12 rule
-                    pokeByteOff cfg 16 f32
+                    pokeByteOff cfg 16 dtype
                     pokeByteOff cfg 20 coalesceFrames
                     pokeByteOff cfg 24 pathAuto
                     pokeByteOff cfg 28 sched
+                    pokeByteOff cfg 32 sumOrder
+                    pokeByteOff cfg 36 (0 :: CInt)
                     c_ctxCfg code cfg
            if ctx == nullPtr then c_lastError >>= peekCString >>= error else return ()
            b <- c_batcher ctx coalesceFrames coalesceWaitUs

@@ -1,9 +1,12 @@
 #!/bin/bash
 # Runs bench.py over the BASELINE.json configurations that fit one GPU; one JSON line each -> gpurun_out/bench_matrix.jsonl
 mkdir -p gpurun_out; out=gpurun_out/bench_matrix.jsonl; : > $out
-run() { echo "# $*" >&2; python bench.py --cpu-seconds 0 "$@" 2>/dev/null | tail -1 >> $out; }
+run() { echo "# $*" >&2; python bench.py --cpu-seconds 0 --fp16-leg 0 "$@" 2>/dev/null | tail -1 >> $out; }
 run --steps 6 --warmup 2                                              # headline: jpl.4096 min-sum f32 (fused)
 LDPC_HIP_PATH=flood run --steps 3 --warmup 1 --batch 16384            # same on the generic flood path
+run --steps 6 --warmup 2 --dtype f16pk                                # configs[3]: fp16 LLRs AND arithmetic, two frames per lane (LDPC_F16PK)
+run --steps 6 --warmup 2 --dtype f16pk --ebn0 3                       # the same in the waterfall
+run --steps 6 --warmup 2 --dtype f16pk --code jpl.1024.4.5            # and on configs[1]'s code
 run --steps 6 --warmup 2 --dtype f16                                  # configs[3]: fp16 LLRs, fused (state on-chip in f32)
 LDPC_HIP_PATH=flood run --steps 3 --warmup 1 --batch 16384 --dtype f16 # configs[3] on the flood path: fp16 lam/messages in HBM
 run --steps 3 --warmup 1 --batch 16384 --variant tanh                 # tanh rule, fused
@@ -27,5 +30,5 @@ import json
 for l in open('gpurun_out/bench_matrix.jsonl'):
     d = json.loads(l)
     r = d['roofline']
-    print(f"{d['config']['code_name']:52s} {d['config']['path']:5s} {d['dtype']} B={d['config']['batch_per_gpu']:6d} {d['value']:9.1f} Mbit/s  {d['ms_per_step']:8.2f} ms  {r['bound']} roofline {r['frac'] if r['frac'] is not None else float('nan'):.3f}  ber {d['ber']:.3e} fer {d['fer']:.3f} it {d['mean_iters']:.1f}  {r['kernel'][:40]}")
+    print(f"{d['config']['code_name']:52s} {d['config']['path']:5s} {d['dtype']} {d['metric'].split('Eb/N0=')[1]:6s} B={d['config']['batch_per_gpu']:6d} {d['value']:9.1f} Mbit/s  {d['ms_per_step']:8.2f} ms  {r['bound']} roofline {r['frac'] if r['frac'] is not None else float('nan'):.3f}  ber {d['ber']:.3e} fer {d['fer']:.3f} it {d['mean_iters']:.1f}  {r['kernel'][:46]}")
 PY

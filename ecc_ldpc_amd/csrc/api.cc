@@ -403,13 +403,15 @@ ldpc_ctx *ldpc_ctx_create_cfg(const ldpc_code *code_c, const ldpc_ctx_config *cf
         set_error(LDPC_EUNSUPPORTED, "LDPC_F16PK (packed fp16 arithmetic, two frames per lane) exists for min-sum, flooding schedule, on-chip path");
         return nullptr;
     }
+    const bool layered_fused_ok = schedule == LDPC_SCHED_LAYERED && sum_order == LDPC_SUM_REFERENCE && ldpc::fused_layered_why_not(*code, variant, dtype) == nullptr;
     if (schedule == LDPC_SCHED_LAYERED) {
-        if (dtype == LDPC_F16) { set_error(LDPC_EUNSUPPORTED, "the layered schedule exists for f32 and f64"); return nullptr; }
+        if (dtype == LDPC_F16 && (!layered_fused_ok || path == LDPC_PATH_FLOOD)) { set_error(LDPC_EUNSUPPORTED, "the layered schedule from HBM exists for f32 and f64"); return nullptr; }
         if (code->max_row_deg > 32) { set_error(LDPC_EUNSUPPORTED, "layered schedule: check rows above weight 32 (this code has %d)", code->max_row_deg); return nullptr; }
     }
-    const bool fused_ok = schedule == LDPC_SCHED_FLOODING && variant != LDPC_TANH_CM && sum_order == LDPC_SUM_REFERENCE && ldpc::fused_supported(*code, variant, dtype);
+    const bool fused_ok = layered_fused_ok ||
+                          (schedule == LDPC_SCHED_FLOODING && variant != LDPC_TANH_CM && sum_order == LDPC_SUM_REFERENCE && ldpc::fused_supported(*code, variant, dtype));
     if ((path == LDPC_PATH_FUSED || dtype == LDPC_F16PK) && !fused_ok) {
-        if (schedule == LDPC_SCHED_LAYERED) { set_error(LDPC_EUNSUPPORTED, "no on-chip kernel for the layered schedule (state lives in HBM: LDPC_PATH_FLOOD)"); return nullptr; }
+        if (schedule == LDPC_SCHED_LAYERED) { set_error(LDPC_EUNSUPPORTED, "no on-chip kernel for the layered schedule on this code / rule / type (%s); LDPC_PATH_FLOOD keeps the state in HBM", ldpc::fused_layered_why_not(*code, variant, dtype)); return nullptr; }
         set_error(LDPC_EUNSUPPORTED, "no fused kernel for this code/variant/dtype (%s)", ldpc::fused_why_not(*code, variant, dtype));
         return nullptr;
     }
@@ -417,7 +419,7 @@ ldpc_ctx *ldpc_ctx_create_cfg(const ldpc_code *code_c, const ldpc_ctx_config *cf
     if (!ctx) { set_error(LDPC_ENOMEM, "out of host memory"); return nullptr; }
     ctx->code = code; ctx->variant = variant; ctx->dtype = dtype; ctx->max_batch = max_batch; ctx->device = device; ctx->schedule = schedule;
     ctx->Bp = (max_batch + 63) / 64 * 64;
-    ctx->path = (path == LDPC_PATH_AUTO) ? ((fused_ok && ldpc::fused_preferred(*code, variant, dtype)) ? LDPC_PATH_FUSED : LDPC_PATH_FLOOD) : path;
+    ctx->path = (path == LDPC_PATH_AUTO) ? ((fused_ok && (layered_fused_ok || ldpc::fused_preferred(*code, variant, dtype))) ? LDPC_PATH_FUSED : LDPC_PATH_FLOOD) : path;
 
 #define CTX_HIP(x)                                                       \
     do {                                                                 \
@@ -477,7 +479,7 @@ ldpc_ctx *ldpc_ctx_create_cfg(const ldpc_code *code_c, const ldpc_ctx_config *cf
             CTX_HIP(hipMemcpy(ctx->flood.d_layer_ptr, code->layer_ptr.data(), sizeof(int32_t) * code->layer_ptr.size(), hipMemcpyHostToDevice));
         }
     } else {
-        ctx->fused = ldpc::fused_create(*code, variant, dtype, max_batch);
+        ctx->fused = schedule == LDPC_SCHED_LAYERED ? ldpc::fused_layered_create(*code, variant, dtype, max_batch) : ldpc::fused_create(*code, variant, dtype, max_batch);
         if (!ctx->fused) { ldpc_ctx_destroy(ctx); return nullptr; }
         ldpc::fused_set_timer(ctx->fused, &ctx->timer);
     }

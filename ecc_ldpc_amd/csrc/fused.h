@@ -10,6 +10,9 @@ const char *fused_why_not(const ldpc_code &code, int variant, int dtype);
 // whether LDPC_PATH_AUTO should pick the fused kernel (it exists AND is the faster path today)
 bool fused_preferred(const ldpc_code &code, int variant, int dtype);
 FusedState *fused_create(const ldpc_code &code, int variant, int dtype, int max_batch);
+// the row-layered schedule on-chip (an extension; fused_layered.hip): null = no reason, else why not
+const char *fused_layered_why_not(const ldpc_code &code, int variant, int dtype);
+FusedState *fused_layered_create(const ldpc_code &code, int variant, int dtype, int max_batch);
 void fused_destroy(FusedState *s);
 void fused_set_timer(FusedState *s, KernelTimer *t);
 // d_llr [batch][N] float32/float64; outputs may be null except d_bits

@@ -34,6 +34,7 @@ struct FusedState {
     bool use_split = false;  // four waves per frame, block rows split between wave pairs (fused_split.hip)
     bool use_msg = true;  // per-edge-message two-wave kernel (fused_msg.hip)
     bool use_pk16 = false;   // LDPC_F16PK: packed fp16 arithmetic, two frames per lane (fused_pk16.hip)
+    bool use_layered = false;   // LDPC_SCHED_LAYERED on-chip (fused_layered.hip)
     KernelTimer *timer = nullptr;
     LaunchInfo info;
     uint32_t *d_tab = nullptr;
@@ -65,6 +66,27 @@ static const char *pk16_why_not(const ldpc_code &c, int variant) {
     if (c.sz == 0 || !plan_matches_ar4ja45(c)) return "the packed-fp16 kernel has built-in instances only (AR4JA rate-4/5 plan: codes/jpl.1024.4.5, codes/jpl.4096.4.5)";
     if (!fused_pk16_has(variant, c.sz, builtin_static_id(c))) return "no built-in packed-fp16 instance for this rotation table";
     return nullptr;
+}
+
+const char *fused_layered_why_not(const ldpc_code &c, int variant, int dtype) {
+    if (variant != LDPC_MINSUM) return "the on-chip layered kernel implements min-sum";
+    if (dtype != LDPC_F32 && dtype != LDPC_F16) return "the on-chip layered kernel computes in f32";
+    if (c.sz == 0 || !plan_matches_ar4ja45(c)) return "the on-chip layered kernel has built-in instances only (AR4JA rate-4/5 plan)";
+    if ((int)c.layer_ptr.size() != c.block_rows + 1) return "layers were replaced: not the block rows";
+    for (int br = 0; br <= c.block_rows; br++) if (c.layer_ptr[br] != br * c.sz) return "layers were replaced: not the block rows";
+    if (!fused_layered_has(variant, dtype, c.sz, builtin_static_id(c))) return "no built-in on-chip layered instance for this rotation table";
+    const char *e = getenv("LDPC_LAYERED_FUSED");
+    if (e && !strcmp(e, "0")) return "disabled (LDPC_LAYERED_FUSED=0)";
+    return nullptr;
+}
+FusedState *fused_layered_create(const ldpc_code &c, int variant, int dtype, int max_batch) {
+    const char *why = fused_layered_why_not(c, variant, dtype);
+    if (why) { set_error(LDPC_EUNSUPPORTED, "%s", why); return nullptr; }
+    FusedState *s = new (std::nothrow) FusedState();
+    if (!s) { set_error(LDPC_ENOMEM, "out of host memory"); return nullptr; }
+    s->use_layered = true; s->use_msg = false; s->round16 = dtype == LDPC_F16;
+    s->variant = variant; s->dtype = LDPC_F32; s->max_batch = max_batch; s->sz = c.sz; s->M = c.M; s->N = c.N; s->E = c.E;
+    return s;
 }
 
 static const char *plan_why_not(const ldpc_code &c, int variant, int dtype) {
@@ -196,7 +218,7 @@ void fused_destroy(FusedState *s) {
 void fused_set_timer(FusedState *s, KernelTimer *t) { if (s) { s->timer = t; fused_csr_set_timer(s->csr, t); } }
 
 bool fused_reads_llr_once(const FusedState &s, int max_iters) {
-    return s.jit != nullptr || s.csr != nullptr || s.use_pk16 || (s.use_split && max_iters <= kSplitMaxIters);
+    return s.jit != nullptr || s.csr != nullptr || s.use_pk16 || s.use_layered || (s.use_split && max_iters <= kSplitMaxIters);
 }
 
 const LaunchInfo &fused_launch_info(const FusedState &s) { return s.csr ? fused_csr_launch_info(*s.csr) : s.info; }
@@ -216,6 +238,7 @@ const char *fused_kernel_name(const FusedState &s) {
     if (li.name[0]) return li.name;
     if (s.csr) return fused_csr_kernel_name(*s.csr);
     if (s.use_pk16) return "fused_pk16_kernel";
+    if (s.use_layered) return "fused_layered_kernel";
     if (s.use_split) return "fused_split_kernel";
     return "fused_msg_kernel";
 }
@@ -226,6 +249,10 @@ int fused_decode(FusedState &s, hipStream_t st, int max_iters, int batch, const 
     FusedArgs a{};
     a.tab = s.d_tab; a.llr = d_llr; a.llr_fmt = llr_fmt; a.llr_round16 = s.round16; a.bits = d_bits; a.iters = d_iters; a.conv = d_conv;
     a.final_lam = d_final; a.trace = d_trace; a.batch = batch; a.max_iters = max_iters; a.step_mode = 0;
+    if (s.use_layered) {
+        if (max_iters > kSplitMaxIters) return set_error(LDPC_EUNSUPPORTED, "on-chip layered kernel: at most %d sweeps (a frame's result is packed into one register)", kSplitMaxIters);
+        return fused_layered_launch(s.sz, st, a, s.timer, &s.info);
+    }
     if (s.use_pk16) {
         if (max_iters > kSplitMaxIters) return set_error(LDPC_EUNSUPPORTED, "LDPC_F16PK: at most %d iterations (a frame's result is packed into one register)", kSplitMaxIters);
         return fused_pk16_launch(s.sz, st, a, s.timer, &s.info);
@@ -239,6 +266,7 @@ int fused_decode(FusedState &s, hipStream_t st, int max_iters, int batch, const 
 int fused_step(FusedState &s, hipStream_t st, int batch, const double *d_orig, const double *d_lam, const double *d_ne,
                double *d_ne_out, double *d_lam_out, uint8_t *d_syn) {
     if (s.csr) return fused_csr_step(*s.csr, st, batch, d_orig, d_lam, d_ne, d_ne_out, d_lam_out, d_syn);
+    if (s.use_layered) return set_error(LDPC_EUNSUPPORTED, "the on-chip layered kernel has no teacher-forced step (use path = LDPC_PATH_FLOOD: the same arithmetic, state in HBM)");
     if (s.use_pk16) return set_error(LDPC_EUNSUPPORTED, "LDPC_F16PK has no teacher-forced step (its state is not the reference's: use ldpc_decode_trace)");
     if (s.use_msg || s.jit) {  // per-edge messages: the state goes in and out as it is
         FusedArgs a{};

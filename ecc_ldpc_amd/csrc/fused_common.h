@@ -139,6 +139,9 @@ int fused_split_launch(int variant, int sz, hipStream_t st, FusedArgs &a, Kernel
 // packed-fp16 min-sum, two frames per lane (fused_pk16.hip): LDPC_F16PK contexts
 bool fused_pk16_has(int variant, int sz, int static_id);
 int fused_pk16_launch(int sz, hipStream_t st, FusedArgs &a, KernelTimer *timer, LaunchInfo *info);
+// row-layered schedule on-chip (fused_layered.hip): min-sum f32, the built-in AR4JA instances
+bool fused_layered_has(int variant, int dtype, int sz, int static_id);
+int fused_layered_launch(int sz, hipStream_t st, FusedArgs &a, KernelTimer *timer, LaunchInfo *info);
 #endif
 constexpr int kSplitMaxIters = 511;  // fused_split_body.h packed result word: bits 23..31 hold the turn a frame converged at
 

@@ -48,7 +48,7 @@ def test_f32_free_running_and_teacher_forced(hip, name, dbs):
     F = 24 if c.N > 4000 else 48
     llr = np.concatenate([c.frames(F // 2, db, 910 + i)[1] for i, db in enumerate(dbs)])
     for variant in ("min", "tanh"):
-        dec = hip.Decoder(c.hip_code(hip), variant, "f32", F, schedule="layered")
+        dec = hip.Decoder(c.hip_code(hip), variant, "f32", F, schedule="layered", path="flood")   # (the HBM kernels: they have the teacher-forced step)
         bits, its, conv = dec.decode_batch(llr.astype(np.float32), 40)
         ref = [oracle.decode_layered(c.graph, lp, variant, 40, l) for l in llr]
         ob = np.stack([o["bits"] for o in ref]); oi = np.array([o["iters"] for o in ref]); oc = np.array([o["converged"] for o in ref])
@@ -85,9 +85,9 @@ def test_both_layered_kernels_agree_on_qc_codes(hip, name, monkeypatch):
     _, llr = c.frames(70, 3.0, seed=123)
     code = c.hip_code(hip)
     for variant in ("min", "tanh"):
-        qc = hip.Decoder(code, variant, "f32", 70, schedule="layered")
+        qc = hip.Decoder(code, variant, "f32", 70, schedule="layered", path="flood")
         monkeypatch.setenv("LDPC_LAYERED_QC", "0")
-        bm = hip.Decoder(code, variant, "f32", 70, schedule="layered")
+        bm = hip.Decoder(code, variant, "f32", 70, schedule="layered", path="flood")
         bm64 = hip.Decoder(code, variant, "f64", 4, schedule="layered")
         monkeypatch.delenv("LDPC_LAYERED_QC")
         assert "layered_qc_kernel" in qc.kernel_name and bm.kernel_name == "layered_kernel"
@@ -135,9 +135,14 @@ def test_edge_cases_and_custom_layers(hip):
         code_csr.set_layers(np.arange(c.M + 1))
     b0, i0, c0 = dec.decode_batch(llr[:3].astype(np.float32), 0)     # no sweeps allowed: channel decisions
     assert np.array_equal(b0, (llr[:3] > 0).astype(np.uint8)) and not c0.any()
-    with pytest.raises(hip.LdpcError) as e:
-        hip.Decoder(c.hip_code(hip), "min", "f16", 8, schedule="layered")
+    with pytest.raises(hip.LdpcError) as e:                 # fp16 STORAGE of a layered decoder's HBM state does not exist ...
+        hip.Decoder(c.hip_code(hip), "min", "f16", 8, schedule="layered", path="flood")
     assert e.value.code == -5
+    from oracle import emulate_f16 as em                    # ... on-chip the only thing in HBM is the LLRs: the f32 decoder on fp16-rounded LLRs
+    d16 = hip.Decoder(c.hip_code(hip), "min", "f16", 70, schedule="layered")
+    d32 = hip.Decoder(c.hip_code(hip), "min", "f32", 70, schedule="layered")
+    assert d16.path == "fused"
+    assert all(np.array_equal(x, y) for x, y in zip(d16.decode_batch(llr.astype(np.float32), 30), d32.decode_batch(em.r16(llr), 30)))
     ecc = hip.ECC(CODES, "ldpc/hip-minsum-layered/jpl.1024.4.5/50/4/5", max_batch=4)
     assert ecc.decoder.schedule == "layered"
     out, ok = ecc.decode(llr[5][:1280])
@@ -188,10 +193,10 @@ def test_row_records_equal_per_edge_messages(hip, name, monkeypatch):
     F = 20 if c.N > 4000 else 48
     _, llr = c.frames(F, 3.0 if name != "ira-12x24-sz64" else 2.0, seed=555)
     code = c.hip_code(hip)
-    rec = hip.Decoder(code, "min", "f32", F, schedule="layered")
+    rec = hip.Decoder(code, "min", "f32", F, schedule="layered", path="flood")
     rec64 = hip.Decoder(code, "min", "f64", 4, schedule="layered")
     monkeypatch.setenv("LDPC_LAYERED_RECORDS", "0")
-    edge = hip.Decoder(code, "min", "f32", F, schedule="layered")
+    edge = hip.Decoder(code, "min", "f32", F, schedule="layered", path="flood")
     edge64 = hip.Decoder(code, "min", "f64", 4, schedule="layered")
     monkeypatch.delenv("LDPC_LAYERED_RECORDS")
     assert rec.kernel_name.endswith(", true>") and edge.kernel_name.endswith(", false>")

@@ -399,8 +399,8 @@ ldpc_ctx *ldpc_ctx_create_cfg(const ldpc_code *code_c, const ldpc_ctx_config *cf
     ldpc_code_dev tabs;
     if (code_upload(code, device, &tabs) != LDPC_OK) return nullptr;
 
-    if (dtype == LDPC_F16PK && (variant != LDPC_MINSUM || schedule != LDPC_SCHED_FLOODING || path == LDPC_PATH_FLOOD)) {
-        set_error(LDPC_EUNSUPPORTED, "LDPC_F16PK (packed fp16 arithmetic, two frames per lane) exists for min-sum, flooding schedule, on-chip path");
+    if (dtype == LDPC_F16PK && (variant != LDPC_MINSUM || path == LDPC_PATH_FLOOD)) {
+        set_error(LDPC_EUNSUPPORTED, "LDPC_F16PK (packed fp16 arithmetic, two frames per lane) exists for min-sum on the on-chip path");
         return nullptr;
     }
     const bool layered_fused_ok = schedule == LDPC_SCHED_LAYERED && sum_order == LDPC_SUM_REFERENCE && ldpc::fused_layered_why_not(*code, variant, dtype) == nullptr;

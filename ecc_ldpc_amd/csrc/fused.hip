@@ -70,7 +70,7 @@ static const char *pk16_why_not(const ldpc_code &c, int variant) {
 
 const char *fused_layered_why_not(const ldpc_code &c, int variant, int dtype) {
     if (variant != LDPC_MINSUM) return "the on-chip layered kernel implements min-sum";
-    if (dtype != LDPC_F32 && dtype != LDPC_F16) return "the on-chip layered kernel computes in f32";
+    if (dtype != LDPC_F32 && dtype != LDPC_F16 && dtype != LDPC_F16PK) return "the on-chip layered kernels compute in f32 or packed fp16";
     if (c.sz == 0 || !plan_matches_ar4ja45(c)) return "the on-chip layered kernel has built-in instances only (AR4JA rate-4/5 plan)";
     if ((int)c.layer_ptr.size() != c.block_rows + 1) return "layers were replaced: not the block rows";
     for (int br = 0; br <= c.block_rows; br++) if (c.layer_ptr[br] != br * c.sz) return "layers were replaced: not the block rows";
@@ -84,8 +84,8 @@ FusedState *fused_layered_create(const ldpc_code &c, int variant, int dtype, int
     if (why) { set_error(LDPC_EUNSUPPORTED, "%s", why); return nullptr; }
     FusedState *s = new (std::nothrow) FusedState();
     if (!s) { set_error(LDPC_ENOMEM, "out of host memory"); return nullptr; }
-    s->use_layered = true; s->use_msg = false; s->round16 = dtype == LDPC_F16;
-    s->variant = variant; s->dtype = LDPC_F32; s->max_batch = max_batch; s->sz = c.sz; s->M = c.M; s->N = c.N; s->E = c.E;
+    s->use_layered = true; s->use_msg = false; s->round16 = dtype == LDPC_F16; s->use_pk16 = dtype == LDPC_F16PK;
+    s->variant = variant; s->dtype = dtype == LDPC_F16PK ? LDPC_F16PK : LDPC_F32; s->max_batch = max_batch; s->sz = c.sz; s->M = c.M; s->N = c.N; s->E = c.E;
     return s;
 }
 
@@ -237,8 +237,8 @@ const char *fused_kernel_name(const FusedState &s) {
     const LaunchInfo &li = fused_launch_info(s);
     if (li.name[0]) return li.name;
     if (s.csr) return fused_csr_kernel_name(*s.csr);
+    if (s.use_layered) return s.use_pk16 ? "fused_layered_pk16_kernel" : "fused_layered_kernel";
     if (s.use_pk16) return "fused_pk16_kernel";
-    if (s.use_layered) return "fused_layered_kernel";
     if (s.use_split) return "fused_split_kernel";
     return "fused_msg_kernel";
 }
@@ -251,7 +251,7 @@ int fused_decode(FusedState &s, hipStream_t st, int max_iters, int batch, const 
     a.final_lam = d_final; a.trace = d_trace; a.batch = batch; a.max_iters = max_iters; a.step_mode = 0;
     if (s.use_layered) {
         if (max_iters > kSplitMaxIters) return set_error(LDPC_EUNSUPPORTED, "on-chip layered kernel: at most %d sweeps (a frame's result is packed into one register)", kSplitMaxIters);
-        return fused_layered_launch(s.sz, st, a, s.timer, &s.info);
+        return s.use_pk16 ? fused_layered_pk16_launch(s.sz, st, a, s.timer, &s.info) : fused_layered_launch(s.sz, st, a, s.timer, &s.info);
     }
     if (s.use_pk16) {
         if (max_iters > kSplitMaxIters) return set_error(LDPC_EUNSUPPORTED, "LDPC_F16PK: at most %d iterations (a frame's result is packed into one register)", kSplitMaxIters);

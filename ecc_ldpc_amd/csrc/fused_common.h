@@ -142,6 +142,7 @@ int fused_pk16_launch(int sz, hipStream_t st, FusedArgs &a, KernelTimer *timer, 
 // row-layered schedule on-chip (fused_layered.hip): min-sum f32, the built-in AR4JA instances
 bool fused_layered_has(int variant, int dtype, int sz, int static_id);
 int fused_layered_launch(int sz, hipStream_t st, FusedArgs &a, KernelTimer *timer, LaunchInfo *info);
+int fused_layered_pk16_launch(int sz, hipStream_t st, FusedArgs &a, KernelTimer *timer, LaunchInfo *info);   // LDPC_F16PK
 #endif
 constexpr int kSplitMaxIters = 511;  // fused_split_body.h packed result word: bits 23..31 hold the turn a frame converged at
 

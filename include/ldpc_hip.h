@@ -62,9 +62,10 @@ typedef enum { LDPC_TANH = 0, LDPC_MINSUM = 1, LDPC_TANH_CM = 2 } ldpc_variant;
  *      emulation in oracle/emulate_f16.py, whereas for F32/F64 they agree bit for bit. */
 /* F16PK (extension, BASELINE.json configs[3] "min-sum fp16 LLRs"): ARITHMETIC in IEEE binary16, two frames per lane in
  *      packed instructions (csrc/fused_pk16_body.h holds the specification: the loop of Min.hs:54-104 on fp16 values, the 3/4
- *      applied inside fused multiply-adds).  Min-sum, flooding schedule, on-chip path, quasi-cyclic codes with a built-in
- *      instance (the shipped AR4JA matrices); anything else: LDPC_EUNSUPPORTED.  Its checker is the bit-exact emulation
- *      oracle/emulate_f16.py decode_minsum_pk16; BER next to the F32 decoder: DESIGN.md. */
+ *      applied inside fused multiply-adds).  Min-sum, on-chip path, either schedule (layered: csrc/fused_layered_body.h),
+ *      quasi-cyclic codes with a built-in instance (the shipped AR4JA matrices); anything else: LDPC_EUNSUPPORTED.  Its
+ *      checker is the bit-exact emulation oracle/emulate_f16.py decode_minsum_pk16 / decode_minsum_pk16_layered; BER next
+ *      to the F32 decoder: DESIGN.md. */
 typedef enum { LDPC_F32 = 0, LDPC_F64 = 1, LDPC_F16 = 2, LDPC_F16PK = 3 } ldpc_dtype;
 /* message-passing schedule.  FLOODING: the reference's (Orig.hs:81-98: all checks, then all variables).
  * LAYERED (extension, no reference counterpart): checks layer by layer, each seeing the LLRs the layers before it

@@ -169,3 +169,69 @@ def decode_minsum_pk16(g, llr, max_iters):
             L = np.where(live[:, None], L2, L)
             u = np.where(live[:, None], u2, u)
     return out.astype(np.uint8), iters, conv, trace
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# LDPC_F16PK + LDPC_SCHED_LAYERED (csrc/fused_layered_body.h, namespace laypk): the row-layered schedule of
+# oracle_decode_layered (ldpc_oracle.c) in the packed-fp16 arithmetic of decode_minsum_pk16 above
+def sweep_minsum_pk16_layered(g, L, u):
+    """one sweep over all rows in ascending order (= layer by layer: the rows of a layer share no column), in place on copies.
+    L [F, N] float16 (negated LLRs), u [F, E] float16 -> L', u', moved [F] (some check was odd or some hard decision flipped)"""
+    L, u = L.copy(), u.copy()
+    F = L.shape[0]
+    moved = np.zeros(F, bool)
+    for m, cols, e0 in _rows(g):
+        d = len(cols)
+        l = L[:, cols]
+        moved |= np.logical_xor.reduce(np.signbit(l), axis=1)           # odd: parity of the hard decisions this row saw
+        tn = fma16(u[:, e0:e0 + d], 0.75, l)                            # -(lam - msg); first sweep: u = 0, tn = l
+        a = np.abs(tn)
+        sg = np.signbit(tn)
+        X = np.logical_xor.reduce(sg, axis=1, keepdims=True)
+        i1 = np.argmin(a, axis=1)
+        m1 = np.take_along_axis(a, i1[:, None], axis=1)
+        a2 = a.copy()
+        np.put_along_axis(a2, i1[:, None], np.float16(np.inf), axis=1)
+        m2 = a2.min(axis=1, keepdims=True)
+        k = np.arange(d)[None, :]
+        mag = np.where(k == i1[:, None], m2, m1)
+        un = np.where(~np.logical_xor(X, sg), -mag, mag).astype(np.float16)
+        ln = fma16(un, -0.75, tn)                                       # -(t + msg'), one rounding
+        moved |= (np.signbit(ln) != np.signbit(l)).any(axis=1)          # flip
+        L[:, cols] = ln
+        u[:, e0:e0 + d] = un
+    return L, u, moved
+
+
+def decode_minsum_pk16_layered(g, llr, max_iters):
+    """llr [F, N] float32 -> bits, sweeps, converged, trace (lam = -L after sweep n at row n, row 0 = the channel LLRs in fp16;
+    zero rows for a frame that has stopped)"""
+    llr = np.asarray(llr, np.float32)
+    F = llr.shape[0]
+    L0 = neg_llr16(llr)
+    L = L0.copy()
+    u = np.zeros((F, g.E), np.float16)
+    iters = np.zeros(F, np.int32)
+    conv = np.zeros(F, bool)
+    out = np.signbit(L0)
+    # before the first sweep: the syndrome of the channel's hard decisions
+    hard = np.signbit(L)
+    ok = np.ones(F, bool)
+    for m, cols, e0 in _rows(g):
+        ok &= ~np.logical_xor.reduce(hard[:, cols], axis=1)
+    conv |= ok
+    live = ~ok
+    trace = [-L.astype(np.float32)]
+    with np.errstate(over="ignore", invalid="ignore"):
+        for n in range(1, max_iters + 1):
+            if not live.any():
+                break
+            L2, u2, moved = sweep_minsum_pk16_layered(g, L, u)
+            L = np.where(live[:, None], L2, L)
+            u = np.where(live[:, None], u2, u)
+            trace.append(np.where(live[:, None], -L.astype(np.float32), np.float32(0)))
+            fin = live & ~moved
+            out[fin] = np.signbit(L[fin]); conv[fin] = True; iters[fin] = n
+            live &= moved
+    iters[live] = max_iters
+    return out.astype(np.uint8), iters, conv, trace

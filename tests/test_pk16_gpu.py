@@ -113,6 +113,7 @@ def test_record_by_name_and_full_size_invariants(hip):
     conv = torch.empty((B,), dtype=torch.uint8, device=dev)
     torch.cuda.synchronize()
     ecc.sim.generate(7, 0, B, 2.8, llr.data_ptr(), msg.data_ptr(), None, llr_f16=True)
+    torch.cuda.synchronize()       # (a NULL stream means the default stream for the frame source but the context's own for decode)
     ecc.decoder.decode_batch_dev(llr.data_ptr(), bits.data_ptr(), B, 50, its.data_ptr(), conv.data_ptr(), None, llr_f16=True)
     torch.cuda.synchronize()
     b, cv, it = bits.cpu().numpy(), conv.cpu().numpy().astype(bool), its.cpu().numpy()
@@ -125,3 +126,36 @@ def test_record_by_name_and_full_size_invariants(hip):
     err = (b[cv][:, :k] != msg.cpu().numpy()[cv]).sum()
     assert err == 0                                                                 # and the transmitted ones, at this Eb/N0
     ecc.close()
+
+
+@pytest.mark.parametrize("name,per_db,dbs", [("jpl.1024.4.5", 7, (2.2, 3.0, 4.0)), ("jpl.4096.4.5", 3, (2.6, 3.2, 4.0))])
+def test_layered_trajectory_is_bit_exact_with_the_emulation(hip, name, per_db, dbs):
+    """LDPC_F16PK + LDPC_SCHED_LAYERED: the on-chip layered kernel in packed fp16 (csrc/fused_layered_body.h, laypk) against
+    oracle/emulate_f16.py decode_minsum_pk16_layered -- every LLR after every sweep, bits, sweep counts, flags; odd batch, partners
+    that stop at different sweeps, saturation / zero LLRs"""
+    c = load(name)
+    llr = _frames(c, per_db, dbs, 4700)
+    llr = llr[np.random.default_rng(6).permutation(len(llr))]
+    llr[1, :8] = [7e4, -7e4, 1e-9, -1e-9, 0.0, 65504.0, 3.0e-8, -6.0e-8]
+    dec = hip.Decoder(c.hip_code(hip), "min", "f16pk", len(llr), schedule="layered")
+    assert dec.path == "fused" and dec.schedule == "layered"
+    bits, its, conv, trace = dec.decode_trace(llr, 40)
+    assert "fused_layered_pk16_kernel" in dec.kernel_name
+    eb, ei, ec, et = em.decode_minsum_pk16_layered(c.graph, llr, 40)
+    assert np.array_equal(its, ei) and np.array_equal(conv.astype(bool), ec) and np.array_equal(bits, eb)
+    assert len(set(its.tolist())) > 3 and 0 < conv.sum() < len(llr)
+    for n, lam in enumerate(et):
+        live = n <= np.where(ec, ei, 40)
+        assert np.array_equal(trace[live, n, :], lam[live].astype(np.float64)), n
+    for x in (llr, em.r16(llr).astype(np.float16)):
+        b2, i2, c2 = dec.decode_batch(x, 40)
+        assert np.array_equal(b2, bits) and np.array_equal(i2, its) and np.array_equal(c2, conv)
+    z = np.zeros((2, c.N), np.float32)
+    assert dec.decode_batch(z, 40)[1].tolist() == [0, 0]                                   # all-zero LLRs: syndrome zero before the first sweep
+    b0, i0, c0 = dec.decode_batch(llr[:5], 0)                                              # no sweeps allowed
+    assert np.array_equal(b0, (em.r16(llr[:5]) > 0).astype(np.uint8)) and not c0.any()
+    # needs about half the sweeps of the flooding fp16 kernel's turns, finds the same codewords
+    fl = hip.Decoder(c.hip_code(hip), "min", "f16pk", len(llr)).decode_batch(llr, 40)
+    both = conv.astype(bool) & fl[2].astype(bool)
+    assert both.sum() >= 3 and np.array_equal(bits[both], fl[0][both]) and its[both].mean() < 0.75 * fl[1][both].mean()
+    dec.close()

@@ -17,6 +17,8 @@ run --steps 3 --warmup 1 --batch 32768 --code dvbs2like.64800.1.2 --rate none --
 run --steps 3 --warmup 1 --batch 8192 --code dvbs2like.64800.1.2 --rate none --ebn0 2                            # the same code, flooding (frame-per-workgroup HBM kernel)
 run --steps 4 --warmup 2 --schedule layered --ebn0 3                                                             # jpl.4096 layered ON-CHIP in the waterfall
 run --steps 4 --warmup 2 --schedule layered --ebn0 2                                                             # ... and below it
+run --steps 4 --warmup 2 --schedule layered --dtype f16pk --ebn0 3                                               # layered on-chip in packed fp16
+run --steps 4 --warmup 2 --schedule layered --dtype f16pk --ebn0 2
 LDPC_HIP_PATH=flood run --steps 3 --warmup 1 --batch 16384 --schedule layered --ebn0 3                           # jpl.4096 layered from HBM
 run --steps 3 --warmup 1 --batch 65536 --ebn0 3                                                                  # jpl.4096 flooding (on-chip) at the same point
 for db in 1 2 3 4; do run --steps 3 --warmup 1 --code 1920.1280.3.303 --rate none --variant tanh --ebn0 $db; done   # configs[2], generic on-chip kernel

@@ -36,7 +36,7 @@ ABI_SYMBOLS = [
     "ldpc_decode_batch_f16", "ldpc_decode_batch_dev_f16", "ldpc_sim_generate_f16",
     "ldpc_debug_step", "ldpc_decode_trace",
     "ldpc_host_alloc", "ldpc_host_free",
-    "ldpc_ctx_set_timing", "ldpc_ctx_kernel_time", "ldpc_ctx_kernel_name", "ldpc_ctx_kernel_geometry", "ldpc_jit_cache_dir", "ldpc_jit_source", "ldpc_jit_prepare",
+    "ldpc_ctx_set_timing", "ldpc_ctx_kernel_time", "ldpc_ctx_kernel_name", "ldpc_ctx_kernel_geometry", "ldpc_jit_cache_dir", "ldpc_jit_source", "ldpc_jit_prepare", "ldpc_jit_source_for", "ldpc_jit_prepare_for",
     "ldpc_sim_create", "ldpc_sim_destroy", "ldpc_sim_generate", "ldpc_sim_tally", "ldpc_sim_encode_host",
     "ldpc_sim_create_qc_on", "ldpc_sim_encoder", "ldpc_sim_encode_batch", "ldpc_matrix_qc_words", "ldpc_matrix_rank",
     "ldpc_matrix_load", "ldpc_matrix_load_mackay", "ldpc_matrix_destroy", "ldpc_matrix_info", "ldpc_matrix_dense",
@@ -190,6 +190,9 @@ def lib():
     L.ldpc_jit_source.restype = C.c_long
     L.ldpc_jit_source.argtypes = [vp, C.c_int, C.c_int, C.c_char_p, C.c_size_t]
     L.ldpc_jit_prepare.argtypes = [vp, C.c_int, C.c_int, C.c_char_p, C.c_size_t, ip, f64p]
+    L.ldpc_jit_source_for.restype = C.c_long
+    L.ldpc_jit_source_for.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_size_t]
+    L.ldpc_jit_prepare_for.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_size_t, ip, f64p]
     L.ldpc_sim_create.restype = vp
     L.ldpc_sim_create.argtypes = [vp, C.c_int, C.c_int, C.c_int, u8p, C.c_int]
     L.ldpc_sim_destroy.restype = None
@@ -358,20 +361,21 @@ class Code:
         check(lib().ldpc_code_layers(self._h, C.byref(n), ptr(lp, C.c_int32)))
         return lp
 
-    def jit_source(self, variant="min", dtype="f32") -> str:
+    def jit_source(self, variant="min", dtype="f32", schedule="flooding") -> str:
         """the translation unit the run-time compiler would be given for this code (LdpcError -5 if there is none)"""
-        n = lib().ldpc_jit_source(self._h, _VARIANTS[variant], _DTYPES[dtype], None, 0)
+        sch = _SCHEDULES[schedule]
+        n = lib().ldpc_jit_source_for(self._h, _VARIANTS[variant], _DTYPES[dtype], sch, None, 0)
         if n < 0:
             raise LdpcError(int(n), last_error())
         buf = C.create_string_buffer(n + 1)
-        lib().ldpc_jit_source(self._h, _VARIANTS[variant], _DTYPES[dtype], buf, n + 1)
+        lib().ldpc_jit_source_for(self._h, _VARIANTS[variant], _DTYPES[dtype], sch, buf, n + 1)
         return buf.value.decode()
 
-    def jit_prepare(self, variant="min", dtype="f32"):
+    def jit_prepare(self, variant="min", dtype="f32", schedule="flooding"):
         """compile this code's specialised kernel into the disk cache (no GPU needed) -> (kernel name, from_cache, seconds)"""
         name = C.create_string_buffer(128)
         fc, sec = C.c_int(), C.c_double()
-        check(lib().ldpc_jit_prepare(self._h, _VARIANTS[variant], _DTYPES[dtype], name, 128, C.byref(fc), C.byref(sec)))
+        check(lib().ldpc_jit_prepare_for(self._h, _VARIANTS[variant], _DTYPES[dtype], _SCHEDULES[schedule], name, 128, C.byref(fc), C.byref(sec)))
         return name.value.decode(), bool(fc.value), sec.value
 
     @classmethod

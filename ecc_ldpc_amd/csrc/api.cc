@@ -809,24 +809,33 @@ int ldpc_ctx_kernel_geometry(const ldpc_ctx *ctx, int *threads_per_workgroup, in
 // ------------------------------------------------------------------------------- run-time specialised kernels
 const char *ldpc_jit_cache_dir(void) { return ldpc::jit_cache_dir(); }
 
-long ldpc_jit_source(const ldpc_code *code, int variant, int dtype, char *buf, size_t cap) {
+static int jit_kind_of(int dtype, int schedule) {
+    if (schedule == LDPC_SCHED_LAYERED) return dtype == LDPC_F16PK ? ldpc::JIT_LAYERED_PK16 : ldpc::JIT_LAYERED;
+    return dtype == LDPC_F16PK ? ldpc::JIT_PK16 : ldpc::JIT_SPLIT;
+}
+
+long ldpc_jit_source_for(const ldpc_code *code, int variant, int dtype, int schedule, char *buf, size_t cap) {
     if (!code) return set_error(LDPC_EINVAL, "null code");
+    if (schedule != LDPC_SCHED_FLOODING && schedule != LDPC_SCHED_LAYERED) return set_error(LDPC_EINVAL, "unknown schedule %d", schedule);
     try {
-        const char *why = ldpc::jit_split_why_not(*code, variant, dtype);
+        const int kind = jit_kind_of(dtype, schedule);
+        const char *why = ldpc::jit_split_why_not(*code, variant, dtype, kind);
         if (why) return set_error(LDPC_EUNSUPPORTED, "%s", why);
-        const std::string src = ldpc::jit_split_source(*code, variant, dtype, nullptr);
+        const std::string src = ldpc::jit_split_source(*code, variant, dtype, nullptr, kind);
         if (buf && cap) { size_t n = std::min(cap - 1, src.size()); memcpy(buf, src.data(), n); buf[n] = 0; }
         return (long)src.size();
     } catch (...) { return set_error(LDPC_ENOMEM, "out of host memory"); }
 }
 
-int ldpc_jit_prepare(const ldpc_code *code, int variant, int dtype, char *kernel_name, size_t cap, int *from_cache, double *seconds) {
+int ldpc_jit_prepare_for(const ldpc_code *code, int variant, int dtype, int schedule, char *kernel_name, size_t cap, int *from_cache, double *seconds) {
     if (!code) return set_error(LDPC_EINVAL, "null code");
+    if (schedule != LDPC_SCHED_FLOODING && schedule != LDPC_SCHED_LAYERED) return set_error(LDPC_EINVAL, "unknown schedule %d", schedule);
     try {
-        const char *why = ldpc::jit_split_why_not(*code, variant, dtype);
+        const int kind = jit_kind_of(dtype, schedule);
+        const char *why = ldpc::jit_split_why_not(*code, variant, dtype, kind);
         if (why) return set_error(LDPC_EUNSUPPORTED, "%s", why);
         ldpc::JitKernel g;
-        const std::string src = ldpc::jit_split_source(*code, variant, dtype, &g);
+        const std::string src = ldpc::jit_split_source(*code, variant, dtype, &g, kind);
         std::vector<char> co;
         bool fc = false;
         double sec = 0;
@@ -837,6 +846,13 @@ int ldpc_jit_prepare(const ldpc_code *code, int variant, int dtype, char *kernel
         if (seconds) *seconds = sec;
         return LDPC_OK;
     } catch (...) { return set_error(LDPC_ENOMEM, "out of host memory"); }
+}
+
+long ldpc_jit_source(const ldpc_code *code, int variant, int dtype, char *buf, size_t cap) {
+    return ldpc_jit_source_for(code, variant, dtype, LDPC_SCHED_FLOODING, buf, cap);
+}
+int ldpc_jit_prepare(const ldpc_code *code, int variant, int dtype, char *kernel_name, size_t cap, int *from_cache, double *seconds) {
+    return ldpc_jit_prepare_for(code, variant, dtype, LDPC_SCHED_FLOODING, kernel_name, cap, from_cache, seconds);
 }
 
 // ------------------------------------------------------------------------------- frame source

@@ -60,24 +60,29 @@ static int builtin_static_id(const ldpc_code &c) {
         }
     return fused_msg_static_id(c.sz, rot.data(), bcv.data(), (int)rot.size());
 }
-// LDPC_F16PK: only the built-in instances (compile-time tables of the shipped AR4JA matrices)
+static bool pk16_builtin(const ldpc_code &c, int variant) {
+    return c.sz > 0 && plan_matches_ar4ja45(c) && fused_pk16_has(variant, c.sz, builtin_static_id(c));
+}
+// LDPC_F16PK: the built-in instances (compile-time tables of the shipped AR4JA matrices), any other single-circulant QC code
+// through the run-time compiler (jit.cc JIT_PK16)
 static const char *pk16_why_not(const ldpc_code &c, int variant) {
     if (variant != LDPC_MINSUM) return "the packed-fp16 kernel implements min-sum";
-    if (c.sz == 0 || !plan_matches_ar4ja45(c)) return "the packed-fp16 kernel has built-in instances only (AR4JA rate-4/5 plan: codes/jpl.1024.4.5, codes/jpl.4096.4.5)";
-    if (!fused_pk16_has(variant, c.sz, builtin_static_id(c))) return "no built-in packed-fp16 instance for this rotation table";
-    return nullptr;
+    if (c.sz == 0) return "the packed-fp16 kernel takes quasi-cyclic codes (built-in instances for codes/jpl.1024.4.5 and codes/jpl.4096.4.5, run-time specialised ones for any other single-circulant .q)";
+    if (pk16_builtin(c, variant)) return nullptr;
+    return jit_split_why_not(c, variant, LDPC_F16PK, JIT_PK16);
 }
 
 const char *fused_layered_why_not(const ldpc_code &c, int variant, int dtype) {
     if (variant != LDPC_MINSUM) return "the on-chip layered kernel implements min-sum";
     if (dtype != LDPC_F32 && dtype != LDPC_F16 && dtype != LDPC_F16PK) return "the on-chip layered kernels compute in f32 or packed fp16";
-    if (c.sz == 0 || !plan_matches_ar4ja45(c)) return "the on-chip layered kernel has built-in instances only (AR4JA rate-4/5 plan)";
+    if (c.sz == 0) return "the on-chip layered kernels take quasi-cyclic codes";
     if ((int)c.layer_ptr.size() != c.block_rows + 1) return "layers were replaced: not the block rows";
     for (int br = 0; br <= c.block_rows; br++) if (c.layer_ptr[br] != br * c.sz) return "layers were replaced: not the block rows";
-    if (!fused_layered_has(variant, dtype, c.sz, builtin_static_id(c))) return "no built-in on-chip layered instance for this rotation table";
     const char *e = getenv("LDPC_LAYERED_FUSED");
     if (e && !strcmp(e, "0")) return "disabled (LDPC_LAYERED_FUSED=0)";
-    return nullptr;
+    if (plan_matches_ar4ja45(c) && fused_layered_has(variant, dtype, c.sz, builtin_static_id(c))) return nullptr;
+    // any other single-circulant QC code: the same bodies specialised at run time
+    return dtype == LDPC_F16PK ? jit_split_why_not(c, variant, LDPC_F16PK, JIT_LAYERED_PK16) : jit_split_why_not(c, variant, LDPC_F32, JIT_LAYERED);
 }
 FusedState *fused_layered_create(const ldpc_code &c, int variant, int dtype, int max_batch) {
     const char *why = fused_layered_why_not(c, variant, dtype);
@@ -86,6 +91,12 @@ FusedState *fused_layered_create(const ldpc_code &c, int variant, int dtype, int
     if (!s) { set_error(LDPC_ENOMEM, "out of host memory"); return nullptr; }
     s->use_layered = true; s->use_msg = false; s->round16 = dtype == LDPC_F16; s->use_pk16 = dtype == LDPC_F16PK;
     s->variant = variant; s->dtype = dtype == LDPC_F16PK ? LDPC_F16PK : LDPC_F32; s->max_batch = max_batch; s->sz = c.sz; s->M = c.M; s->N = c.N; s->E = c.E;
+    if (!(plan_matches_ar4ja45(c) && fused_layered_has(variant, dtype, c.sz, builtin_static_id(c)))) {
+        s->jit = dtype == LDPC_F16PK ? jit_split_create(c, variant, LDPC_F16PK, JIT_LAYERED_PK16) : jit_split_create(c, variant, LDPC_F32, JIT_LAYERED);
+        if (!s->jit) { delete s; return nullptr; }
+        snprintf(s->info.name, sizeof(s->info.name), "%s", s->jit->name.c_str());
+        s->info.threads = s->jit->threads; s->info.frames_per_wg = s->jit->frames_per_wg;
+    }
     return s;
 }
 
@@ -128,6 +139,12 @@ FusedState *fused_create(const ldpc_code &c, int variant, int dtype, int max_bat
     if (dtype == LDPC_F16PK) {
         s->use_pk16 = true; s->use_msg = false;
         s->variant = variant; s->dtype = dtype; s->max_batch = max_batch; s->sz = c.sz; s->M = c.M; s->N = c.N; s->E = c.E;
+        if (!pk16_builtin(c, variant)) {
+            s->jit = jit_split_create(c, variant, LDPC_F16PK, JIT_PK16);
+            if (!s->jit) { delete s; return nullptr; }
+            snprintf(s->info.name, sizeof(s->info.name), "%s", s->jit->name.c_str());
+            s->info.threads = s->jit->threads; s->info.frames_per_wg = s->jit->frames_per_wg;
+        }
         return s;
     }
     s->round16 = dtype == LDPC_F16;
@@ -249,6 +266,7 @@ int fused_decode(FusedState &s, hipStream_t st, int max_iters, int batch, const 
     FusedArgs a{};
     a.tab = s.d_tab; a.llr = d_llr; a.llr_fmt = llr_fmt; a.llr_round16 = s.round16; a.bits = d_bits; a.iters = d_iters; a.conv = d_conv;
     a.final_lam = d_final; a.trace = d_trace; a.batch = batch; a.max_iters = max_iters; a.step_mode = 0;
+    if (s.jit && (s.use_layered || s.use_pk16)) return launch_jit(s, st, a);   // (run-time instances: no limit on max_iters)
     if (s.use_layered) {
         if (max_iters > kSplitMaxIters) return set_error(LDPC_EUNSUPPORTED, "on-chip layered kernel: at most %d sweeps (a frame's result is packed into one register)", kSplitMaxIters);
         return s.use_pk16 ? fused_layered_pk16_launch(s.sz, st, a, s.timer, &s.info) : fused_layered_launch(s.sz, st, a, s.timer, &s.info);

@@ -11,7 +11,12 @@
 // fp16 decoder: this is the loop of Reference/Min.hs:54-104 with every quantity in IEEE binary16 and the 3/4 of Min.hs:78
 // applied where a message is USED, inside a fused multiply-add, instead of where it is made:
 //   state   L_j = -lam_j (column LLR, negated) and u_e = ne'_e / (3/4) (check->variable message without its 3/4); u = +0 at start,
-//           L = -(channel LLR rounded to fp16, saturated at +-65504), a zero LLR as +0
+//           L = -(channel LLR saturated at +-16384 = LLR16_MAX, rounded to fp16), a zero LLR as +0
+//   range   message magnitudes saturate at 2048 = U16_MAX (folded into the leave-one-out minimum: free for rows of degree 3 and 4,
+//           one instruction per row above that).  With column degree <= 30 (the host refuses more) every quantity stays finite:
+//           |L| <= 16384 + 30 * 1536 (+ roundings) and |tN| <= |L| + 1536 < 65504.  Without it a frame that diverges reaches +-inf,
+//           inf - inf = NaN, and a NaN has sign bit 0: the frame would "converge" on the all-zero word (seen on a (3,6)-regular
+//           code with a saturated input, tests/test_jit_kinds_gpu.py; the f32 kernels saturate lam for the same reason)
 //   hard    hard(lam_j) = lam_j > 0 = sign bit of L_j   (L is never -0: sums that cancel give +0 in round-to-nearest, and -0
 //           enters nowhere -- which is why the NEGATED LLR is what is stored: `hard 0 = False` needs no compare)
 //   check   tN_k = fma(u_k, 3/4, L_k) = -(lam_k - ne_k);  u'_k = -prod_{j/=k} sgn(tN_j) * min_{j/=k} |tN_j|   (no rounding at all)
@@ -31,6 +36,9 @@
 namespace ldpc {
 namespace pk {
 constexpr uint32_t K75 = 0x3a003a00u, KN75 = 0xba00ba00u, ABS = 0x7fff7fffu, SGN = 0x80008000u, INF2 = 0x7c007c00u;
+constexpr uint32_t UMAX2 = 0x68006800u;    // U16_MAX = 2048 in both halves
+constexpr float LLR16_MAX = 16384.0f;
+constexpr int PK16_MAX_COLUMN_DEGREE = 30;
 // (non-volatile asm: pure functions of their inputs, free to be scheduled; the compiler's own elementwise min/max on half2 adds
 //  a canonicalising v_pk_max_f16 x, x, x per operand)
 __device__ __forceinline__ uint32_t fma_k(uint32_t a, uint32_t k, uint32_t c) {   // a * k + c, k wave-uniform
@@ -48,6 +56,16 @@ __device__ __forceinline__ uint32_t min3(uint32_t a, uint32_t b, uint32_t c) {
     asm("v_pk_minimum3_f16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
     return r;
 }
+__device__ __forceinline__ uint32_t min2_umax(uint32_t a) {               // min(a, U16_MAX)
+    uint32_t r;
+    asm("v_pk_min_u16 %0, %1, %2" : "=v"(r) : "v"(a), "s"(UMAX2));
+    return r;
+}
+__device__ __forceinline__ uint32_t min3_umax(uint32_t a, uint32_t b) {   // min(a, b, U16_MAX)
+    uint32_t r;
+    asm("v_pk_minimum3_f16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(UMAX2));
+    return r;
+}
 __device__ __forceinline__ uint32_t xor3(uint32_t a, uint32_t b, uint32_t c) { return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96); }
 
 // Leave-one-out minimum of D magnitudes a[k] = |tN_k|, each result turned into the new message at once:
@@ -59,12 +77,15 @@ template <int D>
 __device__ __forceinline__ void loo_min_update(uint32_t *u, const uint32_t (&a)[D], uint32_t xf) {
     static_assert(D >= 2, "min-sum needs degree >= 2");
     auto put = [&](int k, uint32_t loo) { u[k] = xor3(loo, u[k] ^ a[k], xf); };
-    if constexpr (D == 2) { put(0, a[1]); put(1, a[0]); }
+    if constexpr (D == 2) { put(0, min2_umax(a[1])); put(1, min2_umax(a[0])); }
     else if constexpr (D == 3) {
-        const uint32_t m12 = min2(a[1], a[2]), m02 = min2(a[0], a[2]), m01 = min2(a[0], a[1]);
+        const uint32_t m12 = min3_umax(a[1], a[2]), m02 = min3_umax(a[0], a[2]), m01 = min3_umax(a[0], a[1]);
         put(0, m12); put(1, m02); put(2, m01);
     } else {
         constexpr int NB = (D + 1) / 2;
+        // U16_MAX rides in the free operand of the first pair's and (two pairs only) the last pair's minimum; with three or more
+        // pairs it is folded into the running prefix once, which every later element takes
+        constexpr bool FOLD = NB >= 3;
         auto pair_min = [&](auto jc) -> uint32_t {
             constexpr int j = decltype(jc)::value;
             if constexpr (2 * j + 1 < D) return min2(a[2 * j], a[2 * j + 1]); else return a[2 * j];
@@ -83,15 +104,15 @@ __device__ __forceinline__ void loo_min_update(uint32_t *u, const uint32_t (&a)[
             auto others = [&](uint32_t partner) -> uint32_t {
                 if constexpr (has_pre && has_suf && has_partner) return min3(pre, suf[j], partner);
                 else if constexpr (has_pre && has_suf) return min2(pre, suf[j]);
-                else if constexpr (has_pre && has_partner) return min2(pre, partner);
-                else if constexpr (has_suf && has_partner) return min2(suf[j], partner);
+                else if constexpr (has_pre && has_partner) { if constexpr (FOLD) return min2(pre, partner); else return min3_umax(pre, partner); }
+                else if constexpr (has_suf && has_partner) return min3_umax(suf[j], partner);
                 else if constexpr (has_pre) return pre;
                 else if constexpr (has_suf) return suf[j];
                 else return partner;
             };
             if constexpr (has_partner) {
                 const uint32_t o0 = others(a[2 * j + 1]), o1 = others(a[2 * j]);
-                if constexpr (has_suf) { const uint32_t b = pair_min(jc); if constexpr (j == 0) pre = b; else pre = min2(pre, b); }
+                if constexpr (has_suf) { const uint32_t b = pair_min(jc); if constexpr (j == 0) pre = FOLD ? min2_umax(b) : b; else pre = min2(pre, b); }
                 put(2 * j, o0); put(2 * j + 1, o1);
             } else {
                 put(2 * j, others(0u));
@@ -164,9 +185,9 @@ __device__ __forceinline__ void round(char *lds, uint32_t p4, uint32_t vmask, co
     }
 }
 
-// -(x) of a channel LLR as fp16 bits, saturated at +-65504, a zero as +0
+// -(x) of a channel LLR as fp16 bits, saturated at +-LLR16_MAX, a zero as +0
 __device__ __forceinline__ uint32_t neg_llr16(float x) {
-    const float v = fminf(fmaxf(x, -65504.f), 65504.f);
+    const float v = fminf(fmaxf(x, -LLR16_MAX), LLR16_MAX);
     const _Float16 h = (_Float16)(0.0f - v);          // 0 - (+-0) = +0; the f32 negation is exact, the conversion rounds to nearest even
     uint16_t b;
     __builtin_memcpy(&b, &h, 2);

@@ -349,7 +349,9 @@ void deal_cost(const PlanChoice &p, const std::vector<int> &own, int np, int *ma
     *path = pb + 4L * *max_msgs;   // phase A costs ~4x a phase-B edge
 }
 
-const char *choose_plan(const ldpc_code &c, int variant, PlanChoice &p) {
+constexpr int kPk16MaxColumnDegree = 30;   // = pk::PK16_MAX_COLUMN_DEGREE (fused_pk16_body.h, device header)
+
+const char *choose_plan(const ldpc_code &c, int variant, PlanChoice &p, int kind = JIT_SPLIT) {
     if (c.sz <= 0) return "code was not created from a quasi-cyclic description";
     if (c.sz < 16) return "circulant size below 16 (the generic on-chip kernel takes those)";
     if (c.sz > 1024) return "circulant size above 1024";
@@ -444,7 +446,13 @@ const char *choose_plan(const ldpc_code &c, int variant, PlanChoice &p) {
     const int norig = (p.nbc + p.np - 1) / p.np + 2;
     // (calibrated on the shipped AR4JA instances: 78 messages + 24 LLRs run best at 4 waves/SIMD for min-sum -- 128 VGPRs,
     //  ~30 spilled -- and at 3 for the tanh rule, which keeps ~3 transient registers per edge of a row)
-    const int est = msgs + norig + (variant == LDPC_TANH ? 3 * p.dmax + 10 : 24);
+    int est = msgs + norig + (variant == LDPC_TANH ? 3 * p.dmax + 10 : 24);
+    // the other bodies (calibrated on the AR4JA instances, 78 messages): packed-fp16 flooding keeps magnitudes and suffix minima
+    // of a row next to the LLR registers (160 VGPRs: 3 waves); the layered bodies have no LLR registers but keep a row's lam,
+    // t and addresses (f32: 127 VGPRs, 4 waves; packed: 160, 3 waves)
+    if (kind == JIT_PK16) est = msgs + norig + 2 * p.dmax + p.dmax / 2 + 12;
+    else if (kind == JIT_LAYERED) est = msgs + 2 * p.dmax + 12;
+    else if (kind == JIT_LAYERED_PK16) est = msgs + 4 * p.dmax + 8;
     int w = est <= 64 ? 8 : est <= 80 ? 6 : est <= 96 ? 5 : est <= 128 ? 4 : est <= 168 ? 3 : 2;
     const int threads = p.np * p.v;
     const int wg_per_cu = (int)std::max<size_t>(1, (160 * 1024) / lds);
@@ -460,23 +468,32 @@ std::string list_of(const std::vector<int> &v) {
 }
 }  // namespace
 
-const char *jit_split_why_not(const ldpc_code &c, int variant, int dtype) {
-    if (dtype != LDPC_F32) return "run-time specialised kernels exist for f32 only";
+const char *jit_split_why_not(const ldpc_code &c, int variant, int dtype, int kind) {
+    const bool packed = kind == JIT_PK16 || kind == JIT_LAYERED_PK16;
+    if (dtype != (packed ? LDPC_F16PK : LDPC_F32)) return packed ? "the packed-fp16 kernels serve LDPC_F16PK contexts" : "run-time specialised kernels exist for f32 only";
     if (variant != LDPC_MINSUM && variant != LDPC_TANH) return "unknown variant";
+    if (kind != JIT_SPLIT && variant != LDPC_MINSUM) return "the packed-fp16 and layered on-chip kernels implement min-sum";
     if (variant == LDPC_MINSUM && c.min_row_deg < 2) return "min-sum needs check rows of weight >= 2";
     const char *e = getenv("LDPC_JIT");
     if (e && !strcmp(e, "0")) return "disabled (LDPC_JIT=0)";
     PlanChoice p;
-    return choose_plan(c, variant, p);
+    const char *why = choose_plan(c, variant, p, kind);
+    if (why) return why;
+    if (packed) {   // fused_pk16_body.h "range": the fp16 sums stay finite up to this column degree
+        std::vector<int> cd(p.nbc, 0);
+        for (int b : p.bc) if (++cd[b] > kPk16MaxColumnDegree) return "packed fp16: a column degree above 30 (its LLR sum could overflow fp16)";
+    }
+    return nullptr;
 }
 
-std::string jit_split_source(const ldpc_code &c, int variant, int dtype, JitKernel *g) {
+std::string jit_split_source(const ldpc_code &c, int variant, int dtype, JitKernel *g, int kind) {
     PlanChoice p;
-    if (dtype != LDPC_F32 || choose_plan(c, variant, p)) return std::string();
+    if (jit_split_why_not(c, variant, dtype, kind) || choose_plan(c, variant, p, kind)) return std::string();
+    static const char *const kHeader[] = {"fused_split_body.h", "fused_pk16_body.h", "fused_layered_body.h", "fused_layered_body.h"};
     std::ostringstream s;
     s << "// generated by libldpc_hip (jit.cc) for a " << p.nbr << " x " << p.nbc << " block quasi-cyclic H, circulant size " << p.sz << "\n"
       << "#define SPLIT_RESULT_PACKED 0\n"
-      << "#include \"fused_split_body.h\"\n"
+      << "#include \"" << kHeader[kind] << "\"\n"
       << "namespace ldpc {\n"
       << "struct JPlan {\n"
       << "    static constexpr int NBR = " << p.nbr << ", NBC = " << p.nbc << ", NEDGE = " << p.nedge << ", DMAX = " << p.dmax << ", NP = " << p.np << ";\n"
@@ -494,14 +511,17 @@ std::string jit_split_source(const ldpc_code &c, int variant, int dtype, JitKern
       << "};\n"
       << "}  // namespace ldpc\n";
     const std::string body = s.str();
+    static const char *const kStem[] = {"split", "pk16", "layered", "layered_pk16"};
     char name[96];
-    snprintf(name, sizeof(name), "ldpc_jit_split_%s_sz%d_%s", variant == LDPC_MINSUM ? "minsum" : "tanh", p.sz, hash_hex(body).substr(0, 10).c_str());
+    snprintf(name, sizeof(name), "ldpc_jit_%s_%s_sz%d_%s", kStem[kind], variant == LDPC_MINSUM ? "minsum" : "tanh", p.sz, hash_hex(body + kStem[kind]).substr(0, 10).c_str());
     std::ostringstream k;
     k << body << "extern \"C\" __global__ __launch_bounds__(" << p.np * p.v << ") __attribute__((amdgpu_waves_per_eu(" << p.waves_per_eu << ", " << p.waves_per_eu << ")))\n"
-      << "void " << name << "(ldpc::FusedArgs A) {\n"
-      << "    ldpc::split_kernel_body<float, " << (variant == LDPC_MINSUM ? "LDPC_V_MINSUM" : "LDPC_V_TANH") << ", ldpc::JPlan, " << p.sz << ", ldpc::JTab>(A);\n"
-      << "}\n";
-    if (g) { g->threads = p.np * p.v; g->frames_per_wg = p.cpw; g->np = p.np; g->waves_per_eu = p.waves_per_eu; g->name = name; }
+      << "void " << name << "(ldpc::FusedArgs A) {\n";
+    if (kind == JIT_SPLIT) k << "    ldpc::split_kernel_body<float, " << (variant == LDPC_MINSUM ? "LDPC_V_MINSUM" : "LDPC_V_TANH") << ", ldpc::JPlan, " << p.sz << ", ldpc::JTab>(A);\n";
+    else k << "    ldpc::" << (kind == JIT_PK16 ? "pk" : kind == JIT_LAYERED ? "lay" : "laypk") << "::kernel_body<ldpc::JPlan, " << p.sz << ", ldpc::JTab>(A);\n";
+    k << "}\n";
+    const bool packed = kind == JIT_PK16 || kind == JIT_LAYERED_PK16;
+    if (g) { g->threads = p.np * p.v; g->frames_per_wg = (packed ? 2 : 1) * p.cpw; g->np = p.np; g->waves_per_eu = p.waves_per_eu; g->name = name; }
     return k.str();
 }
 
@@ -511,13 +531,13 @@ void jit_destroy(JitKernel *k) {
     delete k;
 }
 
-JitKernel *jit_split_create(const ldpc_code &c, int variant, int dtype) {
-    const char *why = jit_split_why_not(c, variant, dtype);
+JitKernel *jit_split_create(const ldpc_code &c, int variant, int dtype, int kind) {
+    const char *why = jit_split_why_not(c, variant, dtype, kind);
     if (why) { set_error(LDPC_EUNSUPPORTED, "%s", why); return nullptr; }
     JitKernel *k = new (std::nothrow) JitKernel();
     if (!k) { set_error(LDPC_ENOMEM, "out of host memory"); return nullptr; }
     try {
-        const std::string src = jit_split_source(c, variant, dtype, k);
+        const std::string src = jit_split_source(c, variant, dtype, k, kind);
         std::vector<char> co;
         if (jit_compile_cached(src, k->name, co, &k->from_cache, &k->compile_seconds) != LDPC_OK) { delete k; return nullptr; }
         (void)hipGetDevice(&k->device);

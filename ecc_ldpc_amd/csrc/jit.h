@@ -24,13 +24,21 @@ struct JitKernel {
     double compile_seconds = 0;
 };
 
-// Why the run-time specialised split kernel cannot be built for this code/variant/dtype (nullptr = it can).
-const char *jit_split_why_not(const ldpc_code &c, int variant, int dtype);
+// which device body the generated kernel wraps (r03: the packed-fp16 and layered kernels are specialised the same way)
+enum JitKind {
+    JIT_SPLIT = 0,          // fused_split_body.h   flooding, f32 (min-sum or tanh)
+    JIT_PK16 = 1,           // fused_pk16_body.h    flooding, packed fp16, two frames per lane (min-sum)
+    JIT_LAYERED = 2,        // fused_layered_body.h layered, f32 (min-sum)
+    JIT_LAYERED_PK16 = 3,   // fused_layered_body.h layered, packed fp16 (min-sum)
+};
+// Why the run-time specialised kernel cannot be built for this code/variant/dtype (nullptr = it can).  dtype: LDPC_F32, or
+// LDPC_F16PK for the packed-fp16 kinds.
+const char *jit_split_why_not(const ldpc_code &c, int variant, int dtype, int kind = JIT_SPLIT);
 // Compile (or load from the disk cache) and load on the CURRENT device.  nullptr + set_error on failure.
-JitKernel *jit_split_create(const ldpc_code &c, int variant, int dtype);
+JitKernel *jit_split_create(const ldpc_code &c, int variant, int dtype, int kind = JIT_SPLIT);
 void jit_destroy(JitKernel *k);
 // the generated translation unit (tests and tools/ look at it; also what the cache key hashes)
-std::string jit_split_source(const ldpc_code &c, int variant, int dtype, JitKernel *geom_out);
+std::string jit_split_source(const ldpc_code &c, int variant, int dtype, JitKernel *geom_out, int kind = JIT_SPLIT);
 // compile only (no device needed): returns the code object; used to pre-warm the cache at build time
 int jit_compile_cached(const std::string &source, const std::string &kernel_name, std::vector<char> &code_object, bool *from_cache, double *seconds);
 const char *jit_cache_dir();

@@ -62,10 +62,12 @@ typedef enum { LDPC_TANH = 0, LDPC_MINSUM = 1, LDPC_TANH_CM = 2 } ldpc_variant;
  *      emulation in oracle/emulate_f16.py, whereas for F32/F64 they agree bit for bit. */
 /* F16PK (extension, BASELINE.json configs[3] "min-sum fp16 LLRs"): ARITHMETIC in IEEE binary16, two frames per lane in
  *      packed instructions (csrc/fused_pk16_body.h holds the specification: the loop of Min.hs:54-104 on fp16 values, the 3/4
- *      applied inside fused multiply-adds).  Min-sum, on-chip path, either schedule (layered: csrc/fused_layered_body.h),
- *      quasi-cyclic codes with a built-in instance (the shipped AR4JA matrices); anything else: LDPC_EUNSUPPORTED.  Its
- *      checker is the bit-exact emulation oracle/emulate_f16.py decode_minsum_pk16 / decode_minsum_pk16_layered; BER next
- *      to the F32 decoder: DESIGN.md. */
+ *      applied inside fused multiply-adds; channel LLRs saturate at +-16384 and message magnitudes at 2048, so that no sum
+ *      leaves the fp16 range).  Min-sum, on-chip path, either schedule (layered: csrc/fused_layered_body.h), single-circulant
+ *      quasi-cyclic codes whose frame fits in LDS, column degree <= 30: built-in instances for the shipped AR4JA matrices,
+ *      run-time specialised ones for any other (ldpc_jit_prepare_for); anything else: LDPC_EUNSUPPORTED.  Its checker is the
+ *      bit-exact emulation oracle/emulate_f16.py decode_minsum_pk16 / decode_minsum_pk16_layered; BER next to the F32
+ *      decoder: DESIGN.md, profiles/r03_ber_pk16_vs_f32.txt. */
 typedef enum { LDPC_F32 = 0, LDPC_F64 = 1, LDPC_F16 = 2, LDPC_F16PK = 3 } ldpc_dtype;
 /* message-passing schedule.  FLOODING: the reference's (Orig.hs:81-98: all checks, then all variables).
  * LAYERED (extension, no reference counterpart): checks layer by layer, each seeing the LLRs the layers before it
@@ -256,6 +258,12 @@ long ldpc_jit_source(const ldpc_code *code, int variant, int dtype, char *buf, s
 /* compile into the cache (or find it there); kernel_name receives the symbol rocprofv3 will list */
 int ldpc_jit_prepare(const ldpc_code *code, int variant, int dtype, char *kernel_name, size_t cap, int *from_cache,
                      double *seconds);
+/* the same for a given schedule (ldpc_schedule).  What is specialised at run time: flooding f32 (min-sum, tanh), flooding
+ * LDPC_F16PK (min-sum), and the on-chip layered kernels (min-sum; LDPC_F32 or LDPC_F16PK, layers = the block rows).  The two
+ * functions above are these with LDPC_SCHED_FLOODING. */
+long ldpc_jit_source_for(const ldpc_code *code, int variant, int dtype, int schedule, char *buf, size_t cap);
+int ldpc_jit_prepare_for(const ldpc_code *code, int variant, int dtype, int schedule, char *kernel_name, size_t cap,
+                         int *from_cache, double *seconds);
 
 /* ---- frame source and error tally for a BER / throughput harness -----------------------------------
  * The reference leaves message generation, BPSK + AWGN and BER statistics to the external tester

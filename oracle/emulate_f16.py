@@ -99,9 +99,13 @@ def decode_minsum_f16_flood(g, llr, max_iters):
 
 # ---------------------------------------------------------------------------------------------------------------------
 # LDPC_F16PK: packed-fp16 min-sum (csrc/fused_pk16_body.h holds the specification this restates)
+LLR16_MAX = np.float32(16384.0)    # channel LLRs saturate here ...
+U16_MAX = np.float16(2048.0)       # ... and message magnitudes (before their 3/4) here: with column degree <= 30 nothing overflows
+
+
 def neg_llr16(llr):
-    """channel LLRs (float32) -> L0 = -(LLR saturated at +-65504 and rounded to fp16), a zero as +0"""
-    v = np.clip(np.asarray(llr, np.float32), -F16_MAX, F16_MAX)
+    """channel LLRs (float32) -> L0 = -(LLR saturated at +-16384 and rounded to fp16), a zero as +0"""
+    v = np.clip(np.asarray(llr, np.float32), -LLR16_MAX, LLR16_MAX)
     h = (np.float32(0) - v).astype(np.float16)
     h[h == 0] = np.float16(0)
     return h
@@ -132,7 +136,7 @@ def step_minsum_pk16(g, L0, L, u):
         np.put_along_axis(a2, i1[:, None], np.float16(np.inf), axis=1)
         m2 = a2.min(axis=1, keepdims=True)
         k = np.arange(d)[None, :]
-        mag = np.where(k == i1[:, None], m2, m1)       # leave-one-out minimum (ties: m2 == m1)
+        mag = np.minimum(np.where(k == i1[:, None], m2, m1), U16_MAX)   # leave-one-out minimum (ties: m2 == m1), saturated
         neg = ~np.logical_xor(X, sg)                   # sign(u'_k) = 1 ^ X ^ sign(tN_k) = -prod_{j /= k} sgn(tN_j)
         u2[:, e0:e0 + d] = np.where(neg, -mag, mag).astype(np.float16)
     acc = L0.copy()
@@ -194,7 +198,7 @@ def sweep_minsum_pk16_layered(g, L, u):
         np.put_along_axis(a2, i1[:, None], np.float16(np.inf), axis=1)
         m2 = a2.min(axis=1, keepdims=True)
         k = np.arange(d)[None, :]
-        mag = np.where(k == i1[:, None], m2, m1)
+        mag = np.minimum(np.where(k == i1[:, None], m2, m1), U16_MAX)
         un = np.where(~np.logical_xor(X, sg), -mag, mag).astype(np.float16)
         ln = fma16(un, -0.75, tn)                                       # -(t + msg'), one rounding
         moved |= (np.signbit(ln) != np.signbit(l)).any(axis=1)          # flip

@@ -34,9 +34,17 @@ def test_random_protograph(hip, seed, monkeypatch):
         a, b = fused.decode_batch(llr, 30), flood.decode_batch(llr, 30)
         assert all(np.array_equal(x, y) for x, y in zip(a, b)), (c.name, rule)
         assert 0 < a[2].sum() < F or a[1].max() > 1           # the SNR mix makes some frames work for it
-        qc = hip.Decoder(code, rule, "f32", F, schedule="layered")
+        qc = hip.Decoder(code, rule, "f32", F, schedule="layered", path="flood")
         monkeypatch.setenv("LDPC_LAYERED_QC", "0")
-        bm = hip.Decoder(code, rule, "f32", F, schedule="layered")
+        bm = hip.Decoder(code, rule, "f32", F, schedule="layered", path="flood")
         monkeypatch.delenv("LDPC_LAYERED_QC")
         a, b = qc.decode_batch(llr, 20), bm.decode_batch(llr, 20)
         assert all(np.array_equal(x, y) for x, y in zip(a, b)), (c.name, rule, "layered")
+        if rule == "min":                                     # ... and the on-chip layered kernel, specialised at run time
+            on = hip.Decoder(code, rule, "f32", F, schedule="layered")
+            assert on.path == "fused" and on.kernel_name.startswith("ldpc_jit_layered_"), on.kernel_name
+            assert all(np.array_equal(x, y) for x, y in zip(on.decode_batch(llr, 20), a)), (c.name, "on-chip layered")
+            pk = hip.Decoder(code, rule, "f16pk", F).decode_batch(llr, 30)
+            from oracle import emulate_f16 as em
+            e = em.decode_minsum_pk16(c.graph, llr[:9], 30)
+            assert np.array_equal(pk[0][:9], e[0]) and np.array_equal(pk[1][:9], e[1])

@@ -2,7 +2,8 @@
 """Differential fuzz of the on-chip QC kernels (built-in / run-time specialised / table-driven / generic) against the HBM
 flood path on random single-circulant protographs: circulant sizes that are and are not powers of two, 2..16 block rows,
 row weights 2..24, punctured-looking weight-1 columns included.  Both paths implement the same decoder; for f32 they must
-agree bit for bit (hard bits, iteration counts, converged flags); so must the two kernels of the row-layered schedule.  Usage: python tools/fuzz_qc.py [n_codes] [first_seed]
+agree bit for bit (hard bits, iteration counts, converged flags); so must the kernels of the row-layered schedule (two from HBM,
+r03: one on-chip), and the packed-fp16 kernels (r03) reproduce their emulation bit for bit.  Usage: python tools/fuzz_qc.py [n_codes] [first_seed]
 Prints one line per (code, rule); exit status 1 on the first disagreement."""
 import os
 import sys
@@ -40,6 +41,39 @@ def random_code(seed):
     return SyntheticQC(f"fuzz{seed}-{R}x{C}-sz{sz}", sz, off)
 
 
+def fuzz_r03_kinds(c, code, llr, hbm_layered, hbm_result):
+    """r03: the on-chip layered kernel (f32: bit for bit the HBM layered kernel) and the two packed-fp16 kernels (bit for bit the
+    emulation oracle/emulate_f16.py, on the first frames -- the emulation is numpy) specialised for this code at run time"""
+    from oracle import emulate_f16 as em
+    bad = 0
+    F = len(llr)
+    try:
+        on = E.Decoder(code, "min", "f32", F, schedule="layered", path="fused")
+    except E.LdpcError as e:
+        print(f"{'':26s} min  no on-chip layered kernel ({str(e)[:60]}...)", flush=True)
+        return 0
+    a = on.decode_batch(llr, 20)
+    same = all(np.array_equal(x, y) for x, y in zip(a, hbm_result))
+    print(f"{'':26s} min  layered {on.kernel_name[:50]:50s} vs {hbm_layered.kernel_name[:20]:20s} {'ok' if same else 'MISMATCH'}", flush=True)
+    bad += 0 if same else 1
+    nf = 10
+    sub = np.concatenate([llr[: nf // 2], llr[-nf // 2:]])        # both Eb/N0 halves
+    for sched, fn in (("flooding", em.decode_minsum_pk16), ("layered", em.decode_minsum_pk16_layered)):
+        try:
+            pk = E.Decoder(code, "min", "f16pk", F, schedule=sched)
+        except E.LdpcError as e:
+            print(f"{'':26s} min  f16pk {sched}: no kernel ({str(e)[:60]}...)", flush=True)
+            continue
+        got = pk.decode_batch(sub, 30)
+        eb, ei, ec, et = fn(c.graph, sub, 30)
+        same = np.array_equal(got[0], eb) and np.array_equal(got[1], ei) and np.array_equal(got[2].astype(bool), ec)
+        finite = all(np.isfinite(t).all() for t in et)
+        print(f"{'':26s} min  f16pk {sched:8s} {pk.kernel_name[:44]:44s} vs emulation: converged {ec.mean():.2f} mean iters {ei.mean():5.1f} "
+              f"{'ok' if same and finite else 'MISMATCH'}", flush=True)
+        bad += 0 if same and finite else 1
+    return bad
+
+
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 16
     first = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
@@ -72,9 +106,9 @@ def main():
                 print("   differing (bits, iters, conv):", d, flush=True)
             del fused, flood
             # row-layered schedule: the frame-per-workgroup QC kernel (min-sum: row records) against the batch-major any-H kernel
-            qc = E.Decoder(code, rule, "f32", F, schedule="layered")
+            qc = E.Decoder(code, rule, "f32", F, schedule="layered", path="flood")
             os.environ["LDPC_LAYERED_QC"] = "0"
-            bm = E.Decoder(code, rule, "f32", F, schedule="layered")
+            bm = E.Decoder(code, rule, "f32", F, schedule="layered", path="flood")
             del os.environ["LDPC_LAYERED_QC"]
             a = qc.decode_batch(llr, 20)
             b = bm.decode_batch(llr, 20)
@@ -84,7 +118,10 @@ def main():
             if not same:
                 bad += 1
                 print("   differing (bits, sweeps, conv):", [int((x != y).sum()) for x, y in zip(a, b)], flush=True)
-            del qc, bm
+            del bm
+            if rule == "min":
+                bad += fuzz_r03_kinds(c, code, llr, qc, a)
+            del qc
     print("fuzz:", "FAILED" if bad else "all equal")
     return 1 if bad else 0
 

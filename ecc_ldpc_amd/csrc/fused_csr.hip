@@ -43,13 +43,16 @@ struct CsrArgs {
     double *st_ne_out;
     uint8_t *st_syn;
     int *work_counter;    // batched kernel, persistent workgroups: next frame to take = gridDim.x + atomicAdd(work_counter, 1)
+    const uint32_t *cpack_tab;   // batched kernel, OSH instance: the threads' packed column-slot offsets, [kCpackStride / 4][THREADS][4]
+    const uint32_t *rpack_tab;   // ... and packed row-slot offsets, same layout
 };
 
 // RPT / CPT > 0: the thread's column indices (RPT rows x DMAX) and message slots (CPT columns x CDMAX)
 // are loaded into registers ONCE before the turn loop; 0: re-read from global memory every turn.
 constexpr int kCdMax = 8;  // column degree bound of the register-cached variant
-// THREADS: 256, or 1024 for frames whose state leaves room for ONE workgroup per CU anyway (codes/1920.1280.A: 150 KB): 16 waves
-// per CU instead of 4 to cover the LDS round trips.
+constexpr int kCpackStride = 20;   // dwords per thread in CsrArgs::cpack_tab (2 columns x 9 words, padded to whole 16-byte loads)
+// THREADS: 256, or 1024 for frames whose state leaves room for ONE workgroup per CU anyway: 16 waves per CU instead of 4 to cover
+// the LDS round trips (codes/1920.1280.A ran here first; it now has a batched instance, below; LDPC_CSR_BATCHED=0 comes back here).
 template <typename CT, int VARIANT, int DMAX, int RPT, int CPT, int THREADS = kCsrThreads>
 __global__ __launch_bounds__(THREADS) void fused_csr_kernel(CsrArgs A) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -232,45 +235,82 @@ __global__ __launch_bounds__(THREADS) void fused_csr_kernel(CsrArgs A) {
 // by the known count of padded slots), an absent column slot at a cell holding 0.
 // (row weights <= 8: 4 waves/SIMD = 128 VGPRs with a few spilled registers measured 2-4 % faster than 3 waves
 //  without; the weight-20 instance needs its 211-256 registers)
-template <typename CT, int VARIANT, int DMAX, int RPT, int CPT, int CD, int THREADS>
-__global__ __launch_bounds__(THREADS, (DMAX <= 8 ? (THREADS > 256 ? 6 : 4) : 1)) void fused_csr_batched_kernel(CsrArgs A) {
+// OSH = 2 (r03, codes/1920.1280.A: 146 KB of state, one 1024-thread workgroup per CU): the 16-bit offsets count DWORDS, so that
+// they reach the whole 160 KB; its 6 rows x 6 slots and 2 columns x 18 slots per thread are gathered in groups of RG rows / CG
+// columns (18 values in flight instead of 36: the instance has to fit 128 VGPRs -- 16 waves on a CU are 4 per SIMD).
+template <typename CT, int VARIANT, int DMAX, int RPT, int CPT, int CD, int THREADS, int OSH = 0>
+__global__ __launch_bounds__(THREADS, (DMAX <= 8 ? (THREADS > 512 ? 4 : THREADS > 256 ? 6 : 4) : 1)) void fused_csr_batched_kernel(CsrArgs A) {
     static_assert(sizeof(CT) == 4 && DMAX % 2 == 0 && CD % 2 == 0, "pairs of 16-bit offsets");
+    constexpr int RG = (RPT * DMAX > 24 && DMAX <= 8) ? (VARIANT == LDPC_V_TANH ? (RPT + 2) / 3 : (RPT + 1) / 2) : RPT;    // rows gathered together
+    constexpr int CG = (CPT * CD > 24 && OSH > 0) ? 1 : CPT;                     // columns gathered together
+    // the OSH instance does not keep its 18 registers of column-slot offsets across the row phase (with them it spilled 39
+    // registers per turn at 128 VGPRs and ran SLOWER than the row-by-row kernel: 44.7 vs 29.9 ms): it re-reads them every turn
+    // from a table in memory (72 KB per workgroup, L2-resident), issued before the barrier that ends the row phase
+    constexpr bool CP_MEM = OSH > 0;
+    // ... and the row offsets likewise (18 registers; tanh still spilled 32 per turn and ran slower than the row-by-row kernel):
+    // read for the NEXT turn before the barrier that ends a turn
+    constexpr bool RP_MEM = OSH > 0 && VARIANT == LDPC_V_TANH;   // (min-sum: 18.7 ms with the table, 16.6 with 5 spilled registers)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int M = A.M, N = A.N;
     CT *lam = reinterpret_cast<CT *>(smem);
     CT *msg = lam + N;  // [DMAX][M]
     const uint32_t off_inf = (uint32_t)(N + DMAX * M) * 4u, off_zero = off_inf + 4u, off_msg = (uint32_t)N * 4u;
-    auto lds_at = [&](uint32_t byte_off) -> CT { return *reinterpret_cast<const CT *>(smem + byte_off); };
+    auto lds_at = [&](uint32_t stored_off) -> CT { return *reinterpret_cast<const CT *>(smem + (stored_off << OSH)); };
+    auto load_pack = [&](const uint32_t *tab, auto &dst, auto nwords_c, auto inner_c) {
+        constexpr int NW = decltype(nwords_c)::value, INNER = decltype(inner_c)::value;
+        // [kCpackStride / 4][THREADS] x 16 bytes: a wave reads 1 KB in one piece; scalar base + one 32-bit lane offset
+        // (buffer loads: with flat addresses the compiler spends a 64-bit address register pair per load and spills for it)
+        const uint32_t lane_off = (uint32_t)tid * 16u;
+        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t *>(tab), 0, kCpackStride * THREADS * 4, 0x00020000);
+#pragma unroll
+        for (int w = 0; w < (NW + 3) / 4; w++) {
+            typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+            const u32x4 xv = __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane_off, w * THREADS * 16, 0);
+            const uint4 x = {xv.x, xv.y, xv.z, xv.w};
+            const uint32_t xs[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+            for (int z = 0; z < 4; z++)
+                if (4 * w + z < NW) dst[(4 * w + z) / INNER][(4 * w + z) % INNER] = xs[z];
+        }
+    };
 
     // ---- this thread's share of the graph: registers, loaded ONCE per workgroup.  The workgroup is persistent: it decodes
     // frames blockIdx.x, blockIdx.x + gridDim.x, ... one after the other (r03: the per-frame prologue -- three dependent
     // global loads deep: position -> row -> row_ptr -> indices -- was ~10 us per frame, 40 % of the launch at 4 dB where a
     // frame takes 4.7 turns; profiles/r03_mackay_f32_tanh_4dB_*).
     uint32_t rpack[RPT][DMAX / 2], cpack[CPT][CD / 2];
-    int rdeg[RPT];
+    int rdeg_arr[OSH > 0 ? 1 : RPT];
+    uint32_t rdeg_pack = 0;                              // OSH instance: the row degrees in one register, 5 bits each
+    static_assert(OSH == 0 || (RPT <= 6 && DMAX < 32), "row degrees packed 5 bits each");
+    auto rdeg_of = [&](int i) -> int { if constexpr (OSH > 0) return (int)((rdeg_pack >> (5 * i)) & 31u); else return rdeg_arr[i]; };
 #pragma unroll
     for (int i = 0; i < RPT; i++) {
         const int m = tid + i * THREADS;                 // a row POSITION; the row behind it:
         const int row = (m < M) ? A.row_of_pos[m] : 0;
         const int e0 = (m < M) ? A.row_ptr[row] : 0;
-        rdeg[i] = (m < M) ? A.row_ptr[row + 1] - e0 : 0;
+        const int deg_i = (m < M) ? A.row_ptr[row + 1] - e0 : 0;
+        if constexpr (OSH > 0) rdeg_pack |= (uint32_t)deg_i << (5 * i); else rdeg_arr[i] = deg_i;
+        if constexpr (!RP_MEM) {
 #pragma unroll
         for (int k = 0; k < DMAX; k++) {
             const int col = (m < M) ? A.ell_col[k * M + m] : -1;   // a column POSITION
-            const uint32_t off = col < 0 ? off_inf : (uint32_t)col * 4u;
+            const uint32_t off = (col < 0 ? off_inf : (uint32_t)col * 4u) >> OSH;
             if (k & 1) rpack[i][k / 2] |= off << 16; else rpack[i][k / 2] = off;
         }
+        }
     }
+    if constexpr (!CP_MEM) {
 #pragma unroll
     for (int i = 0; i < CPT; i++) {
         const int c = tid + i * THREADS;
 #pragma unroll
         for (int j = 0; j < CD; j++) {
             const int slot = (c < N && j < A.cdmax) ? A.csc_slot[j * N + c] : -1;
-            const uint32_t off = slot < 0 ? off_zero : off_msg + (uint32_t)slot * 4u;
+            const uint32_t off = (slot < 0 ? off_zero : off_msg + (uint32_t)slot * 4u) >> OSH;
             if (j & 1) cpack[i][j / 2] |= off << 16; else cpack[i][j / 2] = off;
         }
+    }
     }
     if (tid == 0) {
         *reinterpret_cast<CT *>(smem + off_inf) = CT(INFINITY);
@@ -298,7 +338,7 @@ __global__ __launch_bounds__(THREADS, (DMAX <= 8 ? (THREADS > 256 ? 6 : 4) : 1))
             const int e0 = (m < M) ? A.row_ptr[A.row_of_pos[m]] : 0;
 #pragma unroll
             for (int k = 0; k < DMAX; k++)
-                if (k < rdeg[i]) mreg[i][k] = (CT)A.st_ne_in[fE + e0 + k];
+                if (k < rdeg_of(i)) mreg[i][k] = (CT)A.st_ne_in[fE + e0 + k];
         }
     }
 #pragma unroll
@@ -315,6 +355,7 @@ __global__ __launch_bounds__(THREADS, (DMAX <= 8 ? (THREADS > 256 ? 6 : 4) : 1))
     bool converged = false;
     int n_done = 0;
     const int turns = A.step_mode ? 1 : A.max_iters;
+    if constexpr (RP_MEM) load_pack(A.rpack_tab, rpack, std::integral_constant<int, RPT * (DMAX / 2)>{}, std::integral_constant<int, DMAX / 2>{});
     for (int n = 0;; n++) {
         LDPC_TURN_LOOP();
         if (A.trace) {
@@ -323,32 +364,48 @@ __global__ __launch_bounds__(THREADS, (DMAX <= 8 ? (THREADS > 256 ? 6 : 4) : 1))
         }
         const bool last = n >= turns;
         // ---- rows: every lam gather of the thread first, then syndrome + check-node updates out of registers
-        CT l[RPT][DMAX];
-#pragma unroll
-        for (int i = 0; i < RPT; i++)
-#pragma unroll
-            for (int k = 0; k < DMAX; k += 2) {
-                l[i][k] = lds_at(rpack[i][k / 2] & 0xffffu);
-                l[i][k + 1] = lds_at(rpack[i][k / 2] >> 16);
-            }
         int unsat = 0;
 #pragma unroll
-        for (int i = 0; i < RPT; i++) {
+        for (int g = 0; g < RPT; g += RG) {
+        CT l[RG][DMAX];
+#pragma unroll
+        for (int i = g; i < g + RG && i < RPT; i++)
+#pragma unroll
+            for (int k = 0; k < DMAX; k += 2) {
+                l[i - g][k] = lds_at(rpack[i][k / 2] & 0xffffu);
+                l[i - g][k + 1] = lds_at(rpack[i][k / 2] >> 16);
+            }
+#pragma unroll
+        for (int i = g; i < g + RG && i < RPT; i++) {
             CT t[DMAX];
-            uint32_t par = (uint32_t)(DMAX - rdeg[i]);   // each padded slot reads +inf: its "hard bit" 1 is taken back out
+            uint32_t par = (uint32_t)(DMAX - rdeg_of(i));   // each padded slot reads +inf: its "hard bit" 1 is taken back out
 #pragma unroll
             for (int k = 0; k < DMAX; k++) {
-                par ^= (l[i][k] > CT(0)) ? 1u : 0u;
-                t[k] = l[i][k] - mreg[i][k];             // padded slot: inf - finite = inf
+                par ^= (l[i - g][k] > CT(0)) ? 1u : 0u;
+                t[k] = l[i - g][k] - mreg[i][k];         // padded slot: inf - finite = inf
             }
             unsat |= (tid + i * THREADS < M) ? (int)(par & 1u) : 0;
             if (!last) {
-                cn_update_padded<CT, VARIANT, DMAX>(t, rdeg[i]);
+                cn_update_padded<CT, VARIANT, DMAX>(t, rdeg_of(i));
 #pragma unroll
                 for (int k = 0; k < DMAX; k++) mreg[i][k] = t[k];   // padded slots: finite, never read by a column
             }
         }
+        }
         if (!last) {
+            if constexpr (OSH > 0) {
+                // slot k of row position tid + i * THREADS: one address register per turn, k * M * 4 from a scalar, i * THREADS * 4 as the
+                // instruction's immediate (left to itself the compiler keeps all RPT * DMAX loop-invariant addresses in registers)
+                uint32_t mb = off_msg + (uint32_t)tid * 4u;
+                asm volatile("" : "+v"(mb));
+#pragma unroll
+                for (int k = 0; k < DMAX; k++) {
+                    const uint32_t kb = mb + (uint32_t)(k * M) * 4u;
+#pragma unroll
+                    for (int i = 0; i < RPT; i++)
+                        if (tid + i * THREADS < M) *reinterpret_cast<CT *>(smem + kb + (uint32_t)(i * THREADS) * 4u) = mreg[i][k];
+                }
+            } else {
 #pragma unroll
             for (int i = 0; i < RPT; i++) {
                 const int m = tid + i * THREADS;
@@ -357,6 +414,16 @@ __global__ __launch_bounds__(THREADS, (DMAX <= 8 ? (THREADS > 256 ? 6 : 4) : 1))
                     for (int k = 0; k < DMAX; k++) msg[k * M + m] = mreg[i][k];
                 }
             }
+            }
+        }
+        if constexpr (CP_MEM) {   // this turn's column-slot offsets: on their way while the workgroup meets at the barrier
+#pragma unroll
+            for (int i = 0; i < CPT; i++)
+#pragma unroll
+                for (int jj = 0; jj < CD / 2; jj++) cpack[i][jj] = 0u;
+            // 16-byte loads, coalesced across the wave
+            static_assert(!CP_MEM || (CPT * (CD / 2) <= kCpackStride && RPT * (DMAX / 2) <= kCpackStride), "table stride");
+            load_pack(A.cpack_tab, cpack, std::integral_constant<int, CPT * (CD / 2)>{}, std::integral_constant<int, CD / 2>{});
         }
         const int any_unsat = __syncthreads_or(unsat);  // also: every message written, every lam read
         if (A.step_mode) {
@@ -367,21 +434,26 @@ __global__ __launch_bounds__(THREADS, (DMAX <= 8 ? (THREADS > 256 ? 6 : 4) : 1))
         }
         if (last) { n_done = n; break; }  // Orig.hs:70
         // ---- columns: every message gather first, then lam = foldr (+) orig (column of ne'), descending rows
-        CT v[CPT][CD];
+        // (the NEXT turn's row offsets first: they arrive while the columns are summed)
+        if constexpr (RP_MEM) load_pack(A.rpack_tab, rpack, std::integral_constant<int, RPT * (DMAX / 2)>{}, std::integral_constant<int, DMAX / 2>{});
 #pragma unroll
-        for (int i = 0; i < CPT; i++)
+        for (int g = 0; g < CPT; g += CG) {
+        CT v[CG][CD];
+#pragma unroll
+        for (int i = g; i < g + CG && i < CPT; i++)
 #pragma unroll
             for (int j = 0; j < CD; j += 2) {
-                v[i][j] = lds_at(cpack[i][j / 2] & 0xffffu);
-                v[i][j + 1] = lds_at(cpack[i][j / 2] >> 16);
+                v[i - g][j] = lds_at(cpack[i][j / 2] & 0xffffu);
+                v[i - g][j + 1] = lds_at(cpack[i][j / 2] >> 16);
             }
 #pragma unroll
-        for (int i = 0; i < CPT; i++) {
+        for (int i = g; i < g + CG && i < CPT; i++) {
             const int c = tid + i * THREADS;
             CT acc = oreg[i];
 #pragma unroll
-            for (int j = 0; j < CD; j++) acc = v[i][j] + acc;   // absent slots add 0 (they follow the present ones)
+            for (int j = 0; j < CD; j++) acc = v[i - g][j] + acc;   // absent slots add 0 (they follow the present ones)
             if (c < N) lam[c] = sat_lam<CT, VARIANT>(acc);
+        }
         }
         __syncthreads();
         if (A.step_mode) break;
@@ -396,7 +468,7 @@ __global__ __launch_bounds__(THREADS, (DMAX <= 8 ? (THREADS > 256 ? 6 : 4) : 1))
                 const int e0 = A.row_ptr[A.row_of_pos[m]];
 #pragma unroll
                 for (int k = 0; k < DMAX; k++)
-                    if (k < rdeg[i]) A.st_ne_out[fE + e0 + k] = (double)mreg[i][k];
+                    if (k < rdeg_of(i)) A.st_ne_out[fE + e0 + k] = (double)mreg[i][k];
             }
         }
     } else {
@@ -429,6 +501,7 @@ struct CsrState {
     // batched kernel: the same tables in POSITION space (conflict-aware placement of rows and columns in LDS)
     int32_t *d_ell_b = nullptr, *d_csc_b = nullptr, *d_row_of_pos = nullptr, *d_col_of_pos = nullptr;
     int *d_counter = nullptr;     // work counter of the persistent batched kernel
+    uint32_t *d_cpack = nullptr, *d_rpack = nullptr;  // OSH instance: packed column-slot / row-slot offsets per thread
     KernelTimer *timer = nullptr;
     LaunchInfo info;
 };
@@ -571,14 +644,20 @@ const char *fused_csr_why_not(const ldpc_code &c, int variant, int dtype) {
 void fused_csr_destroy(CsrState *s) {
     if (!s) return;
     (void)hipFree(s->d_ell); (void)hipFree(s->d_csc); (void)hipFree(s->d_row_ptr);
-    (void)hipFree(s->d_ell_b); (void)hipFree(s->d_csc_b); (void)hipFree(s->d_row_of_pos); (void)hipFree(s->d_col_of_pos); (void)hipFree(s->d_counter);
+    (void)hipFree(s->d_ell_b); (void)hipFree(s->d_csc_b); (void)hipFree(s->d_row_of_pos); (void)hipFree(s->d_col_of_pos); (void)hipFree(s->d_counter); (void)hipFree(s->d_cpack); (void)hipFree(s->d_rpack);
     delete s;
 }
 
 // which batched instance (if any) serves this shape: 0 = none (row-by-row kernel)
 static int batched_shape(const CsrState &s) {
     const int rpt = (s.M + kCsrThreads - 1) / kCsrThreads, cpt = (s.N + kCsrThreads - 1) / kCsrThreads;
-    if (((size_t)s.N + (size_t)s.dmax * s.M + 3) * 4 > 65536) return 0;   // 16-bit LDS byte offsets
+    const size_t cells = (size_t)s.N + (size_t)s.dmax * s.M + 3;
+    // r03, codes/1920.1280.A (5760 x 1920, row weights 4 / 6, column weights 14 / 18; 146 KB): one 1024-thread workgroup per
+    // frame and CU, 16-bit DWORD offsets
+    if (cells * 4 > 65536 && cells * 4 <= 160 * 1024 && cells <= 65536 && s.dmax == 6 && (s.M + 1023) / 1024 <= 6 && (s.N + 1023) / 1024 <= 2 &&
+        s.cdmax <= 18 && s.want_wide)
+        return 4;
+    if (cells * 4 > 65536) return 0;   // 16-bit LDS byte offsets
     if (s.dmax == 4 && rpt <= 6 && cpt <= 8 && s.cdmax <= 4) return 1;
     if (s.dmax == 8 && rpt <= 2 && cpt <= 4 && s.cdmax <= 8) return 2;
     if (s.dmax == 20 && rpt <= 2 && cpt <= 6 && s.cdmax <= 8) return 3;
@@ -639,6 +718,38 @@ CsrState *fused_csr_create(const ldpc_code &c, int variant, int dtype) {
         }
         e = up(&s->d_ell_b, ell_b);
         if (e == hipSuccess) e = up(&s->d_csc_b, csc_b);
+        if (e == hipSuccess && batched_shape(*s) == 4) {   // [kCpackStride / 4][1024 threads][4 words]: CPT = 2 columns x CD / 2 = 9 words per thread, offsets in dwords (OSH = 2)
+            constexpr int T = 1024, CPT = 2, CD = 18;
+            const uint32_t off_msg = (uint32_t)c.N, off_zero = (uint32_t)(c.N + s->dmax * c.M) + 1u;
+            std::vector<int32_t> cp((size_t)T * kCpackStride, 0);
+            for (int i = 0; i < CPT; i++)
+                for (int t = 0; t < T; t++) {
+                    const int q = t + i * T;
+                    for (int j = 0; j < CD; j++) {
+                        const int slot = (q < c.N && j < s->cdmax) ? csc_b[(size_t)j * c.N + q] : -1;
+                        const uint32_t off = slot < 0 ? off_zero : off_msg + (uint32_t)slot;
+                        const int word = i * (CD / 2) + j / 2;
+                        int32_t &w = cp[((size_t)(word / 4) * T + t) * 4 + word % 4];
+                        w = (int32_t)((j & 1) ? ((uint32_t)w | (off << 16)) : off);
+                    }
+                }
+            e = up((int32_t **)&s->d_cpack, cp);
+            constexpr int RPT = 6;
+            const uint32_t off_inf = (uint32_t)(c.N + s->dmax * c.M);
+            std::vector<int32_t> rp((size_t)T * kCpackStride, 0);
+            for (int i = 0; i < RPT; i++)
+                for (int t = 0; t < T; t++) {
+                    const int m = t + i * T;
+                    for (int k = 0; k < s->dmax; k++) {
+                        const int col = m < c.M ? ell_b[(size_t)k * c.M + m] : -1;
+                        const uint32_t off = col < 0 ? off_inf : (uint32_t)col;
+                        const int word = i * (s->dmax / 2) + k / 2;
+                        int32_t &w = rp[((size_t)(word / 4) * T + t) * 4 + word % 4];
+                        w = (int32_t)((k & 1) ? ((uint32_t)w | (off << 16)) : off);
+                    }
+                }
+            if (e == hipSuccess) e = up((int32_t **)&s->d_rpack, rp);
+        }
         if (e == hipSuccess) e = up(&s->d_row_of_pos, P.row_of_pos);
         if (e == hipSuccess) e = up(&s->d_col_of_pos, P.col_of_pos);
     }
@@ -675,12 +786,19 @@ static int launch_csr(CsrState &s, hipStream_t st, CsrArgs &a) {
     return LDPC_OK;
 }
 
-template <typename CT, int VARIANT, int DMAX, int RPT, int CPT, int CD, int THREADS = kCsrThreads>
+template <typename CT, int VARIANT, int DMAX, int RPT, int CPT, int CD, int THREADS = kCsrThreads, int OSH = 0>
 static int launch_csr_batched(CsrState &s, hipStream_t st, CsrArgs &a) {
-    auto kern = fused_csr_batched_kernel<CT, VARIANT, DMAX, RPT, CPT, CD, THREADS>;
-    const size_t lds = ((size_t)s.N + (size_t)DMAX * s.M + 3) * sizeof(CT);   // lam, messages, the +inf and 0 cells, the next-frame cell; <= 64 KB
+    auto kern = fused_csr_batched_kernel<CT, VARIANT, DMAX, RPT, CPT, CD, THREADS, OSH>;
+    const size_t lds = ((size_t)s.N + (size_t)DMAX * s.M + 3) * sizeof(CT);   // lam, messages, the +inf and 0 cells, the next-frame cell
+    static size_t attr_set = 0;
+    if (lds > 64 * 1024 && lds > attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return set_error(LDPC_EHIP, "hipFuncSetAttribute(%zu B LDS): %s", lds, hipGetErrorString(e));
+        attr_set = lds;
+    }
     if (!a.step_mode) {
-        snprintf(s.info.name, sizeof(s.info.name), "ldpc::fused_csr_batched_kernel<%s, %d, %d, %d, %d, %d, %d>", sizeof(CT) == 8 ? "double" : "float", VARIANT, DMAX, RPT, CPT, CD, THREADS);
+        if (OSH) snprintf(s.info.name, sizeof(s.info.name), "ldpc::fused_csr_batched_kernel<%s, %d, %d, %d, %d, %d, %d, %d>", sizeof(CT) == 8 ? "double" : "float", VARIANT, DMAX, RPT, CPT, CD, THREADS, OSH);
+        else snprintf(s.info.name, sizeof(s.info.name), "ldpc::fused_csr_batched_kernel<%s, %d, %d, %d, %d, %d, %d>", sizeof(CT) == 8 ? "double" : "float", VARIANT, DMAX, RPT, CPT, CD, THREADS);
         s.info.threads = THREADS; s.info.frames_per_wg = 1;
     }
     // persistent workgroups: as many as are resident at once (LDPC_CSR_PERSIST=0: one workgroup per frame)
@@ -715,7 +833,7 @@ static int dispatch_dmax(CsrState &s, hipStream_t st, CsrArgs &a) {
     if constexpr (sizeof(CT) == 4) {
         const int shape = (s.d_ell_b && s.want_batched) ? batched_shape(s) : 0;
         if (shape) {
-            a.ell_col = s.d_ell_b; a.csc_slot = s.d_csc_b; a.row_of_pos = s.d_row_of_pos; a.col_of_pos = s.d_col_of_pos;
+            a.ell_col = s.d_ell_b; a.csc_slot = s.d_csc_b; a.row_of_pos = s.d_row_of_pos; a.col_of_pos = s.d_col_of_pos; a.cpack_tab = s.d_cpack; a.rpack_tab = s.d_rpack;
             if (shape == 1) {
                 // 512 threads per frame when the share then is <= 3 rows / 4 columns per thread: 75-80 VGPRs, 6 waves per
                 // SIMD.  Measured on 1920.1280.3.303 against the 256-thread instance: tanh 4.14 -> 4.22 Gbit/s at 1 dB,
@@ -724,6 +842,7 @@ static int dispatch_dmax(CsrState &s, hipStream_t st, CsrArgs &a) {
                 return launch_csr_batched<CT, VARIANT, 4, 6, 8, 4>(s, st, a);
             }
             if (shape == 2) return launch_csr_batched<CT, VARIANT, 8, 2, 4, 8>(s, st, a);
+            if (shape == 4) return launch_csr_batched<CT, VARIANT, 6, 6, 2, 18, 1024, 2>(s, st, a);
             // (jpl.1024 given as CSR: min-sum 3.69 -> 4.73 Gbit/s with 512 threads per frame, tanh 2.19 -> 1.71: its
             //  weight-20 rows need the registers)
             if constexpr (VARIANT == LDPC_V_MINSUM)

@@ -109,3 +109,33 @@ def test_flood_padded_rows_equal_the_fallback(hip, monkeypatch, label, M, N, deg
     for variant, dtype in (("min", "f32"), ("min", "f64")):
         assert all(np.array_equal(a, b) for a, b in zip(out[("1", variant, dtype)], out[("0", variant, dtype)]))
     assert np.array_equal(out[("1", "tanh", "f32")][0], out[("0", "tanh", "f32")][0])
+
+
+@pytest.mark.parametrize("M,N,seed", [(4000, 1500, 1), (6100, 2040, 2), (3000, 1100, 3)])
+@pytest.mark.parametrize("variant", ["min", "tanh"])
+def test_large_frames_of_row_class_6_on_chip(hip, M, N, seed, variant):
+    """fused_csr.hip's 1024-thread batched instance (built for codes/1920.1280.A: 16-bit DWORD offsets, offset tables re-read
+    every turn) on random graphs of its class -- row weights <= 6, column weights <= 18, more than 64 KB of state per frame:
+    ragged last rows / columns per thread, rows of weight 2..6, empty and light columns; against the flood path bit for bit
+    and the oracle's hard bits"""
+    rng = np.random.default_rng(seed)
+    H = np.zeros((M, N), np.uint8)
+    col_deg = np.zeros(N, int)
+    for m in range(M):
+        d = int(rng.choice([2, 3, 4, 5, 6, 6, 6]))
+        free = np.flatnonzero(col_deg < 18)
+        cols = rng.choice(free, size=d, replace=False)
+        H[m, cols] = 1
+        col_deg[cols] += 1
+    assert H.sum(1).max() == 6 and H.sum(0).max() <= 18 and (N + 6 * M + 3) * 4 > 65536
+    g = oracle.Graph.from_dense(H)
+    x = rng.normal(2.2, 2.0, size=(9, N)).astype(np.float32)
+    code = hip.Code.from_dense(H)
+    on = hip.Decoder(code, variant, "f32", len(x), path="fused")
+    a = on.decode_batch(x, 25)
+    assert on.kernel_name == f"ldpc::fused_csr_batched_kernel<float, {1 if variant == 'min' else 0}, 6, 6, 2, 18, 1024, 2>", on.kernel_name
+    b = hip.Decoder(code, variant, "f32", len(x), path="flood").decode_batch(x, 25)
+    assert all(np.array_equal(p, q) for p, q in zip(a, b))
+    ob, oi, oc = oracle.decode_batch(g, variant, 25, x.astype(np.float64), nthreads=8)
+    assert np.array_equal(a[0], ob) and np.array_equal(a[2], oc)
+    assert 0 < oc.sum() or oi.max() > 1

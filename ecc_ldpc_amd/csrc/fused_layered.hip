@@ -16,10 +16,10 @@ void fused_layered_kernel(FusedArgs A) {
     lay::kernel_body<Plan, SZ, T>(A);
 }
 
-// the same in packed fp16, two frames per lane (LDPC_F16PK): 78 packed messages, no channel-LLR registers, the transients of the
-// packed leave-one-out minimum -> 3 waves per SIMD
+// the same in packed fp16, two frames per lane (LDPC_F16PK): 80 packed messages, no channel-LLR registers, the transients of the
+// packed leave-one-out minimum for half a row (profiles/r03_layered_rs_ab.txt: 4 waves per SIMD 73.7 Gbit/s at 3 dB, 3 waves 66.8)
 #ifndef LAYERED_PK16_WAVES_PER_EU
-#define LAYERED_PK16_WAVES_PER_EU 3
+#define LAYERED_PK16_WAVES_PER_EU 4   // (rows split between the groups: 140 registers wanted; at 128 it spills 3-11 per sweep and still gains 10 %)
 #endif
 template <class Plan, int SZ, class T>
 __global__ __launch_bounds__((SplitGeom<Plan, SZ>::THREADS), LAYERED_PK16_WAVES_PER_EU)

@@ -23,7 +23,7 @@ namespace lay {
 template <int D, bool FIRST, bool SYNDROME_ONLY, class Row>
 __device__ __forceinline__ bool layer_row(char *lds, Row tabrow, uint32_t p4, uint32_t vmask, float *m) {
     asm volatile("" : "+v"(p4));   // keeps the loop-invariant address arithmetic inside the sweep loop, row by row
-    if constexpr (SYNDROME_ONLY) LDPC_COLD_PATH();
+    if constexpr (SYNDROME_ONLY || FIRST) LDPC_COLD_PATH();   // (FIRST: one sweep per frame -- tools/isa_histogram.py prices the ordinary one)
     float l[D];
     uint32_t adr[D];
     static_for<0, D>([&](auto kc) {
@@ -64,9 +64,30 @@ __device__ __forceinline__ bool layer_row(char *lds, Row tabrow, uint32_t p4, ui
     return par || flip;
 }
 
-template <class Plan, int SZ, class T, int P>
+// ---- rows split between the two wave groups (plans with NP == 2) --------------------------------------------------------
+// With block rows dealt to the groups alternately, ONE group works per layer: of the 16 waves a CU holds, 8 compute at any time, and
+// the kernel issues at 0.32-0.36 of the VALU peak (profiles/r03_bench_matrix.txt) -- it waits on LDS round trips and barriers.  Here
+// thread (g, r) owns row r of EVERY block row, but only HALF of its edges (g = 0: the first D/2, g = 1: the rest): both groups work
+// in every layer.  A layer is then
+//     gather + t = lam - msg + partial (min1, min2, sign word, parity) over the own edges  ->  three words to LDS  ->  barrier
+//     the partner's three words  ->  the row's min1 / min2 / signs  ->  new messages and lam for the own edges  ->  barrier
+// Same values in the same operations as layer_row above (the minimum and second minimum of a set do not depend on how it is
+// split), so the kernel stays bit for bit the HBM layered kernel.
+#ifndef LAY_ROW_SPLIT
+#define LAY_ROW_SPLIT 1
+#endif
+template <class Plan> struct Halves {
+    static constexpr int cnt(int br, int g) { return g == 0 ? Plan::deg(br) / 2 : Plan::deg(br) - Plan::deg(br) / 2; }
+    static constexpr int k0(int br, int g) { return g == 0 ? 0 : Plan::deg(br) / 2; }
+    static constexpr int slot0(int br, int g) { int c = 0; for (int b = 0; b < br; b++) c += cnt(b, g); return c; }
+    static constexpr int NMSG = slot0(Plan::NBR, 0) > slot0(Plan::NBR, 1) ? slot0(Plan::NBR, 0) : slot0(Plan::NBR, 1);
+    static constexpr bool ok() { for (int b = 0; b < Plan::NBR; b++) if (Plan::deg(b) < 2) return false; return Plan::NP == 2; }
+};
+
+template <class Plan, int SZ, class T, int P, bool RS>
 __device__ __forceinline__ void body(const FusedArgs &A, char *lds, const uint32_t tid) {
     using S = Split<Plan, T>;
+    using H = Halves<Plan>;
     constexpr int CPW = QcGeom<SZ>::CPW, V = QcGeom<SZ>::V, VT = QcGeom<SZ>::VT;
     constexpr int N = Plan::NBC * SZ, THREADS = Plan::NP * VT, NW = THREADS / 64;
     constexpr uint32_t ES = 4, vmask = V * ES - 1;
@@ -86,9 +107,12 @@ __device__ __forceinline__ void body(const FusedArgs &A, char *lds, const uint32
             fN = (size_t)(valid ? frame : 0) * N;
         }
     };
-    float msg[S::NMSG];
+    constexpr int NM = RS ? H::NMSG : S::NMSG;
+    constexpr uint32_t EX0 = LAM_BYTES + 4 * NW + 12;            // RS: exchange area [word 0..2][group][VT] dwords
+    constexpr uint32_t EXW = 2 * VT * ES, EXG = VT * ES;
+    float msg[NM];
 #pragma unroll
-    for (int i = 0; i < S::NMSG; i++) msg[i] = 0.0f;
+    for (int i = 0; i < NM; i++) msg[i] = 0.0f;
     // ---- lam <- channel LLRs: group P fills the block columns bc with bc % NP == P; their hard decisions stay in `obits`
     typename SplitResult<NBCP>::Bits obits{};
     {
@@ -181,18 +205,80 @@ __device__ __forceinline__ void body(const FusedArgs &A, char *lds, const uint32
         done |= newly;
         if (A.trace || newly != 0u) __syncthreads();   // the rows copied / snapshotted above are rewritten by layer 0
     }
+    // RS: one layer, the own half of the row
+    auto half_layer = [&](auto brc, auto firstc, bool &any) {
+        constexpr int br = decltype(brc)::value;
+        constexpr bool FIRST = decltype(firstc)::value;
+        constexpr int D = Plan::deg(br), DH = H::cnt(br, P), K0 = H::k0(br, P), ms0 = H::slot0(br, P);
+        if constexpr (FIRST) LDPC_COLD_PATH();
+        StatRow<float, SZ, T, Plan::ebeg(br) + K0> row;
+        uint32_t pp = p4;
+        asm volatile("" : "+v"(pp));
+        float l[DH], t[DH];
+        uint32_t adr[DH];
+        static_for<0, DH>([&](auto kc) {
+            constexpr int k = decltype(kc)::value;
+            adr[k] = qc_wrap(pp + row.lo(k), vmask);
+            l[k] = lds_ld<float>(lds + row.hi(k), adr[k]);
+        });
+        bool par = false;
+        uint32_t X = 0;
+        float m1 = INFINITY, m2 = INFINITY;
+        static_for<0, DH>([&](auto kc) {
+            constexpr int k = decltype(kc)::value;
+            par ^= (l[k] > 0.0f);
+            t[k] = FIRST ? l[k] - 0.0f : l[k] - msg[ms0 + k];
+            X ^= __float_as_uint(t[k]);
+            const float a = fabsf(t[k]);
+            m2 = __builtin_amdgcn_fmed3f(m1, m2, a);
+            m1 = fminf(m1, a);
+        });
+        // sign word: bit 31 = parity of the signs of t, bit 0 = parity of the hard decisions
+        const uint32_t xw = (X & 0x80000000u) | (par ? 1u : 0u);
+        lds_st<float>(lds + EX0 + P * EXG, pp, m1);
+        lds_st<float>(lds + EX0 + EXW + P * EXG, pp, m2);
+        lds_st<uint32_t>(lds + EX0 + 2 * EXW + P * EXG, pp, xw);
+        __syncthreads();
+        const float q1 = lds_ld<float>(lds + EX0 + (1 - P) * EXG, pp);
+        const float q2 = lds_ld<float>(lds + EX0 + EXW + (1 - P) * EXG, pp);
+        const uint32_t xq = lds_ld<uint32_t>(lds + EX0 + 2 * EXW + (1 - P) * EXG, pp);
+        const float M1 = fminf(m1, q1);
+        const float M2 = fminf(fmaxf(m1, q1), fminf(m2, q2));     // the second smallest of the row
+        const uint32_t xa = xw ^ xq;
+        const uint32_t flipbit = (xa ^ ((D & 1) ? 0x80000000u : 0u)) & 0x80000000u;
+        const uint32_t c1 = __float_as_uint(0.75f * M1) ^ flipbit;
+        const uint32_t c2 = __float_as_uint(0.75f * M2) ^ flipbit;
+        bool flip = false;
+        static_for<0, DH>([&](auto kc) {
+            constexpr int k = decltype(kc)::value;
+            const uint32_t c = (fabsf(t[k]) == M1) ? c2 : c1;
+            const float nm = __uint_as_float(__builtin_amdgcn_bitop3_b32(c, __float_as_uint(t[k]), 0x80000000u, 0x78));
+            msg[ms0 + k] = nm;
+            const float nw = t[k] + nm;
+            flip |= (nw > 0.0f) != (l[k] > 0.0f);
+            lds_st<float>(lds + row.hi(k), adr[k], nw);
+        });
+        any |= ((xa & 1u) != 0u) || flip;
+        __syncthreads();
+    };
     for (int n = 1; done != FULL && n <= A.max_iters; n++) {
         bool any = false;
-        // ---- one sweep: layers in order; the group that owns the block row works, everybody meets at the barrier
+        // ---- one sweep: layers in order.  RS: both groups work on every layer (two barriers per layer); else the group that owns
+        // the block row works, everybody meets at the barrier
         static_for<0, Plan::NBR>([&](auto brc) {
             constexpr int br = decltype(brc)::value;
-            if constexpr (S::owner_br(br) == P) {
+            if constexpr (RS) {
+                if (n == 1) half_layer(brc, std::true_type{}, any);
+                else half_layer(brc, std::false_type{}, any);
+                return;
+            }
+            if constexpr (!RS && S::owner_br(br) == P) {
                 constexpr int D = Plan::deg(br), ms0 = S::slot(Plan::ebeg(br));
                 StatRow<float, SZ, T, Plan::ebeg(br)> row;
                 if (n == 1) any |= layer_row<D, true, false>(lds, row, p4, vmask, &msg[ms0]);
                 else any |= layer_row<D, false, false>(lds, row, p4, vmask, &msg[ms0]);
             }
-            __syncthreads();
+            if constexpr (!RS) __syncthreads();
         });
         const uint32_t moved = frames_with(any);
         trace_row(n);
@@ -231,12 +317,13 @@ __device__ __forceinline__ void body(const FusedArgs &A, char *lds, const uint32
 template <class Plan, int SZ, class T>
 __device__ __forceinline__ void kernel_body(const FusedArgs &A) {
     using G = SplitGeom<Plan, SZ>;
-    __shared__ __attribute__((aligned(16))) char lds[(Plan::NBC * G::V * 4 + 15) / 16 * 16 + 4 * G::NW];
+    constexpr bool RS = LAY_ROW_SPLIT && Halves<Plan>::ok();
+    __shared__ __attribute__((aligned(16))) char lds[(Plan::NBC * G::V * 4 + 15) / 16 * 16 + 4 * G::NW + (RS ? 16 + 3 * 2 * G::VT * 4 : 0)];
     const uint32_t tid = threadIdx.x;
     const uint32_t group = __builtin_amdgcn_readfirstlane(tid / G::VT);
     static_for<0, Plan::NP>([&](auto pc) {
         constexpr int P = decltype(pc)::value;
-        if (group == (uint32_t)P) body<Plan, SZ, T, P>(A, lds, tid);
+        if (group == (uint32_t)P) body<Plan, SZ, T, P, RS>(A, lds, tid);
     });
 }
 }  // namespace lay
@@ -266,7 +353,7 @@ __device__ __forceinline__ void loo_min_out(const uint32_t (&tn)[D], const uint3
 template <int D, bool FIRST, bool SYNDROME_ONLY, class Row>
 __device__ __forceinline__ uint32_t layer_row(char *lds, Row tabrow, uint32_t p4, uint32_t vmask, uint32_t *u) {
     asm volatile("" : "+v"(p4));
-    if constexpr (SYNDROME_ONLY) LDPC_COLD_PATH();
+    if constexpr (SYNDROME_ONLY || FIRST) LDPC_COLD_PATH();
     uint32_t l[D], adr[D];
     static_for<0, D>([&](auto kc) {
         constexpr int k = decltype(kc)::value;
@@ -296,9 +383,53 @@ __device__ __forceinline__ uint32_t layer_row(char *lds, Row tabrow, uint32_t p4
     return par | fl;     // bits 15 / 31: the row's parity was odd or a hard decision flipped, low / high frame
 }
 
-template <class Plan, int SZ, class T, int P>
+// leave-one-out minimum over the own D edges of a row whose OTHER edges (the partner thread's half, lay::Halves) have the minimum
+// `seed` (saturated at U16_MAX already): pk::loo_min_update with the running prefix started at `seed`.  D >= 1.
+template <int D>
+__device__ __forceinline__ void loo_min_seeded(const uint32_t (&tn)[D], const uint32_t (&a)[D], const uint32_t (&suf)[(D + 1) / 2], uint32_t xf, uint32_t seed, uint32_t (&out)[D]) {
+    auto put = [&](int k, uint32_t loo) { out[k] = xor3(loo, tn[k] ^ a[k], xf); };
+    constexpr int NB = (D + 1) / 2;
+    uint32_t pre = seed;
+    static_for<0, NB>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        constexpr bool has_suf = j < NB - 1, has_partner = 2 * j + 1 < D;
+        auto others = [&](uint32_t partner) -> uint32_t {
+            if constexpr (has_suf && has_partner) return min3(pre, suf[j], partner);
+            else if constexpr (has_suf) return min2(pre, suf[j]);
+            else if constexpr (has_partner) return min2(pre, partner);
+            else return pre;
+        };
+        if constexpr (has_partner) {
+            const uint32_t o0 = others(a[2 * j + 1]), o1 = others(a[2 * j]);
+            if constexpr (has_suf) pre = min3(pre, a[2 * j], a[2 * j + 1]);
+            put(2 * j, o0); put(2 * j + 1, o1);
+        } else {
+            put(2 * j, others(0u));
+        }
+    });
+}
+// suf[j] = min over the pairs after pair j (suf[NB - 1] unused); -> the minimum of all D magnitudes
+template <int D>
+__device__ __forceinline__ uint32_t suffix_minima(const uint32_t (&a)[D], uint32_t (&suf)[(D + 1) / 2]) {
+    constexpr int NB = (D + 1) / 2;
+    auto pair_min = [&](auto jc) -> uint32_t {
+        constexpr int j = decltype(jc)::value;
+        if constexpr (2 * j + 1 < D) return min2(a[2 * j], a[2 * j + 1]); else return a[2 * j];
+    };
+    suf[NB - 1] = INF2;
+    static_rfor<0, NB - 1>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        const uint32_t b = pair_min(std::integral_constant<int, j + 1>{});
+        if constexpr (j == NB - 2) suf[j] = b; else suf[j] = min2(suf[j + 1], b);
+    });
+    const uint32_t first = pair_min(std::integral_constant<int, 0>{});
+    if constexpr (NB >= 2) return min2(first, suf[0]); else return first;
+}
+
+template <class Plan, int SZ, class T, int P, bool RS>
 __device__ __forceinline__ void body(const FusedArgs &A, char *lds, const uint32_t tid) {
     using S = Split<Plan, T>;
+    using H = lay::Halves<Plan>;
     constexpr int CPW = QcGeom<SZ>::CPW, V = QcGeom<SZ>::V, VT = QcGeom<SZ>::VT;
     constexpr int N = Plan::NBC * SZ, THREADS = Plan::NP * VT, NW = THREADS / 64;
     constexpr uint32_t ES = 4, vmask = V * ES - 1;
@@ -319,9 +450,11 @@ __device__ __forceinline__ void body(const FusedArgs &A, char *lds, const uint32
             for (int h = 0; h < 2; h++) { valid[h] = frame0 + h < batch; fN[h] = (size_t)(valid[h] ? frame0 + h : 0) * N; }
         }
     };
-    uint32_t u[S::NMSG];
+    constexpr int NU = RS ? H::NMSG : S::NMSG;
+    constexpr uint32_t EX0 = LAM_BYTES + 4 * NW + 12, EXW = 2 * VT * ES, EXG = VT * ES;   // RS: exchange area [word 0..1][group][VT]
+    uint32_t u[NU];
 #pragma unroll
-    for (int i = 0; i < S::NMSG; i++) u[i] = 0u;
+    for (int i = 0; i < NU; i++) u[i] = 0u;
     typename SplitResult<NBCP>::Bits obits[2];
     {
         const Where w(p4, A.batch);
@@ -434,17 +567,65 @@ __device__ __forceinline__ void body(const FusedArgs &A, char *lds, const uint32
         done |= newly;
         if (A.trace || newly != 0u) __syncthreads();
     }
+    // RS: one layer, the own half of the row (lay::Halves has the scheme; here the partner's half enters the leave-one-out
+    // minimum as ONE value -- the minimum of its magnitudes -- so two words are exchanged: that minimum, and sign / parity bits)
+    auto half_layer = [&](auto brc, auto firstc, uint32_t &any) {
+        constexpr int br = decltype(brc)::value;
+        constexpr bool FIRST = decltype(firstc)::value;
+        constexpr int DH = H::cnt(br, P), K0 = H::k0(br, P), ms0 = H::slot0(br, P);
+        if constexpr (FIRST) LDPC_COLD_PATH();
+        StatRow<float, SZ, T, Plan::ebeg(br) + K0> row;
+        uint32_t pp = p4;
+        asm volatile("" : "+v"(pp));
+        uint32_t l[DH], adr[DH], tn[DH], a[DH], suf[(DH + 1) / 2], un[DH];
+        static_for<0, DH>([&](auto kc) {
+            constexpr int k = decltype(kc)::value;
+            adr[k] = qc_wrap(pp + row.lo(k), vmask);
+            l[k] = lds_ld<uint32_t>(lds + row.hi(k), adr[k]);
+        });
+        uint32_t par = 0, X = 0;
+#pragma unroll
+        for (int k = 0; k < DH; k++) {
+            par ^= l[k];
+            tn[k] = FIRST ? l[k] : fma_k(u[ms0 + k], K75, l[k]);
+            X ^= tn[k];
+            a[k] = tn[k] & ABS;
+        }
+        const uint32_t own_min = suffix_minima<DH>(a, suf);
+        const uint32_t xw = (X & SGN) | ((par & SGN) >> 1);      // bits 15 / 31: sign parity of tN; bits 14 / 30: parity of the hard decisions
+        lds_st<uint32_t>(lds + EX0 + P * EXG, pp, own_min);
+        lds_st<uint32_t>(lds + EX0 + EXW + P * EXG, pp, xw);
+        __syncthreads();
+        const uint32_t qmin = lds_ld<uint32_t>(lds + EX0 + (1 - P) * EXG, pp);
+        const uint32_t xa = xw ^ lds_ld<uint32_t>(lds + EX0 + EXW + (1 - P) * EXG, pp);
+        loo_min_seeded<DH>(tn, a, suf, ~xa & SGN, min2_umax(qmin), un);
+        uint32_t fl = 0;
+        static_for<0, DH>([&](auto kc) {
+            constexpr int k = decltype(kc)::value;
+            u[ms0 + k] = un[k];
+            const uint32_t ln = fma_k(un[k], KN75, tn[k]);
+            fl |= ln ^ l[k];
+            lds_st<uint32_t>(lds + row.hi(k), adr[k], ln);
+        });
+        any |= ((xa << 1) & SGN) | fl;
+        __syncthreads();
+    };
     for (int n = 1; done != FULL && n <= A.max_iters; n++) {
         uint32_t any = 0;
         static_for<0, Plan::NBR>([&](auto brc) {
             constexpr int br = decltype(brc)::value;
-            if constexpr (S::owner_br(br) == P) {
+            if constexpr (RS) {
+                if (n == 1) half_layer(brc, std::true_type{}, any);
+                else half_layer(brc, std::false_type{}, any);
+                return;
+            }
+            if constexpr (!RS && S::owner_br(br) == P) {
                 constexpr int D = Plan::deg(br), ms0 = S::slot(Plan::ebeg(br));
                 StatRow<float, SZ, T, Plan::ebeg(br)> row;
                 if (n == 1) any |= layer_row<D, true, false>(lds, row, p4, vmask, &u[ms0]);
                 else any |= layer_row<D, false, false>(lds, row, p4, vmask, &u[ms0]);
             }
-            __syncthreads();
+            if constexpr (!RS) __syncthreads();
         });
         const uint32_t moved = frames_with(any);
         trace_row(n);
@@ -486,12 +667,13 @@ __device__ __forceinline__ void body(const FusedArgs &A, char *lds, const uint32
 template <class Plan, int SZ, class T>
 __device__ __forceinline__ void kernel_body(const FusedArgs &A) {
     using G = SplitGeom<Plan, SZ>;
-    __shared__ __attribute__((aligned(16))) char lds[(Plan::NBC * G::V * 4 + 15) / 16 * 16 + 4 * G::NW];
+    constexpr bool RS = LAY_ROW_SPLIT && lay::Halves<Plan>::ok();
+    __shared__ __attribute__((aligned(16))) char lds[(Plan::NBC * G::V * 4 + 15) / 16 * 16 + 4 * G::NW + (RS ? 16 + 2 * 2 * G::VT * 4 : 0)];
     const uint32_t tid = threadIdx.x;
     const uint32_t group = __builtin_amdgcn_readfirstlane(tid / G::VT);
     static_for<0, Plan::NP>([&](auto pc) {
         constexpr int P = decltype(pc)::value;
-        if (group == (uint32_t)P) body<Plan, SZ, T, P>(A, lds, tid);
+        if (group == (uint32_t)P) body<Plan, SZ, T, P, RS>(A, lds, tid);
     });
 }
 }  // namespace laypk

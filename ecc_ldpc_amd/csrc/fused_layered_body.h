@@ -76,9 +76,17 @@ __device__ __forceinline__ bool layer_row(char *lds, Row tabrow, uint32_t p4, ui
 #ifndef LAY_ROW_SPLIT
 #define LAY_ROW_SPLIT 1
 #endif
+#ifndef LAY_SPLIT_MIN_DEG
+#define LAY_SPLIT_MIN_DEG 4    // rows lighter than this stay whole with the group that owns the block row: one barrier instead of two
+                               // (jpl.4096, weight-3 rows split / whole: f32 45.9 / 48.1, f16pk 74.6 / 80.0 Gbit/s at 3 dB -- profiles/r03_layered_rs_ab.txt)
+#endif
 template <class Plan> struct Halves {
-    static constexpr int cnt(int br, int g) { return g == 0 ? Plan::deg(br) / 2 : Plan::deg(br) - Plan::deg(br) / 2; }
-    static constexpr int k0(int br, int g) { return g == 0 ? 0 : Plan::deg(br) / 2; }
+    static constexpr bool split(int br) { return Plan::deg(br) >= LAY_SPLIT_MIN_DEG; }
+    static constexpr int cnt(int br, int g) {
+        if (!split(br)) return Plan::owner_br(br) == g ? Plan::deg(br) : 0;
+        return g == 0 ? Plan::deg(br) / 2 : Plan::deg(br) - Plan::deg(br) / 2;
+    }
+    static constexpr int k0(int br, int g) { return (split(br) && g == 1) ? Plan::deg(br) / 2 : 0; }
     static constexpr int slot0(int br, int g) { int c = 0; for (int b = 0; b < br; b++) c += cnt(b, g); return c; }
     static constexpr int NMSG = slot0(Plan::NBR, 0) > slot0(Plan::NBR, 1) ? slot0(Plan::NBR, 0) : slot0(Plan::NBR, 1);
     static constexpr bool ok() { for (int b = 0; b < Plan::NBR; b++) if (Plan::deg(b) < 2) return false; return Plan::NP == 2; }
@@ -267,18 +275,18 @@ __device__ __forceinline__ void body(const FusedArgs &A, char *lds, const uint32
         // the block row works, everybody meets at the barrier
         static_for<0, Plan::NBR>([&](auto brc) {
             constexpr int br = decltype(brc)::value;
-            if constexpr (RS) {
+            if constexpr (RS && H::split(br)) {
                 if (n == 1) half_layer(brc, std::true_type{}, any);
                 else half_layer(brc, std::false_type{}, any);
                 return;
             }
-            if constexpr (!RS && S::owner_br(br) == P) {
-                constexpr int D = Plan::deg(br), ms0 = S::slot(Plan::ebeg(br));
+            if constexpr (!(RS && H::split(br)) && S::owner_br(br) == P) {
+                constexpr int D = Plan::deg(br), ms0 = RS ? H::slot0(br, P) : S::slot(Plan::ebeg(br));
                 StatRow<float, SZ, T, Plan::ebeg(br)> row;
                 if (n == 1) any |= layer_row<D, true, false>(lds, row, p4, vmask, &msg[ms0]);
                 else any |= layer_row<D, false, false>(lds, row, p4, vmask, &msg[ms0]);
             }
-            if constexpr (!RS) __syncthreads();
+            if constexpr (!(RS && H::split(br))) __syncthreads();
         });
         const uint32_t moved = frames_with(any);
         trace_row(n);
@@ -614,18 +622,18 @@ __device__ __forceinline__ void body(const FusedArgs &A, char *lds, const uint32
         uint32_t any = 0;
         static_for<0, Plan::NBR>([&](auto brc) {
             constexpr int br = decltype(brc)::value;
-            if constexpr (RS) {
+            if constexpr (RS && H::split(br)) {
                 if (n == 1) half_layer(brc, std::true_type{}, any);
                 else half_layer(brc, std::false_type{}, any);
                 return;
             }
-            if constexpr (!RS && S::owner_br(br) == P) {
-                constexpr int D = Plan::deg(br), ms0 = S::slot(Plan::ebeg(br));
+            if constexpr (!(RS && H::split(br)) && S::owner_br(br) == P) {
+                constexpr int D = Plan::deg(br), ms0 = RS ? H::slot0(br, P) : S::slot(Plan::ebeg(br));
                 StatRow<float, SZ, T, Plan::ebeg(br)> row;
                 if (n == 1) any |= layer_row<D, true, false>(lds, row, p4, vmask, &u[ms0]);
                 else any |= layer_row<D, false, false>(lds, row, p4, vmask, &u[ms0]);
             }
-            if constexpr (!RS) __syncthreads();
+            if constexpr (!(RS && H::split(br))) __syncthreads();
         });
         const uint32_t moved = frames_with(any);
         trace_row(n);

@@ -308,7 +308,11 @@ PROFILE_TAGS = {   # committed rocprofv3 PMC passes (tools/profile.sh): (code, v
     ("jpl.4096.4.5", "tanh", "f32", "fused"): ("jpl4096_f32_tanh", 16384), ("1920.1280.3.303", "tanh", "f32", "fused"): ("mackay_f32_tanh", 65536),
     ("jpl.4096.4.5", "minsum", "f16pk", "fused"): ("jpl4096_f16pk_minsum", 65536),
     ("jpl.4096.4.5", "minsum", "f32", "flood_qc"): ("floodqc_jpl4096_f32_minsum", 16384),
-    ("dvbs2like.64800.1.2", "minsum", "f32", "layered_qc"): ("dvbs2like_layered_f32_minsum", 32768)}
+    ("dvbs2like.64800.1.2", "minsum", "f32", "layered_qc"): ("dvbs2like_layered_f32_minsum", 32768),
+    # the on-chip layered kernels (family "fused_layered": another kernel than the flooding one of the same code and type)
+    ("jpl.4096.4.5", "minsum", "f32", "fused_layered"): ("jpl4096_layered_f32_minsum", 65536),
+    ("jpl.4096.4.5", "minsum", "f16pk", "fused_layered"): ("jpl4096_layered_f16pk_minsum", 65536),
+    ("1920.1280.A", "minsum", "f32", "fused"): ("1920A_f32_minsum", 16384)}
 
 
 def committed_traffic(args, dec, B):
@@ -319,6 +323,8 @@ def committed_traffic(args, dec, B):
     (For a kernel with early exit the scaling by frames assumes the profiled Eb/N0.)"""
     kname = dec.kernel_name
     family = "fused" if dec.path == "fused" else ("flood_qc" if "flood_qc_kernel" in kname else ("layered_qc" if "layered_qc_kernel" in kname else None))
+    if family == "fused" and args.schedule == "layered":
+        family = "fused_layered"
     ent = PROFILE_TAGS.get((args.code, args.variant, args.dtype, family))
     if ent is None:
         return None, None
@@ -327,7 +333,9 @@ def committed_traffic(args, dec, B):
         path = os.path.join(ROOT, "profiles", rnd + tag + "_pmc.json")
         try:
             prof = json.load(open(path))
-            if family != "fused" and family.replace("_qc", "_qc_kernel") not in prof["kernel"]:
+            if family in ("flood_qc", "layered_qc") and family.replace("_qc", "_qc_kernel") not in prof["kernel"]:
+                continue
+            if family == "fused_layered" and "layered" not in prof["kernel"]:
                 continue
             h = prof["hbm_bytes_per_launch"]
             fetch = h.get("FETCH_SIZE_corrected_bytes", 2 * h["FETCH_SIZE_raw_bytes"])

@@ -17,7 +17,8 @@ run --steps 3 --warmup 1 --batch 32768 --code dvbs2like.64800.1.2 --rate none --
 run --steps 3 --warmup 1 --batch 8192 --code dvbs2like.64800.1.2 --rate none --ebn0 2                            # the same code, flooding (frame-per-workgroup HBM kernel)
 run --steps 4 --warmup 2 --schedule layered --ebn0 3                                                             # jpl.4096 layered ON-CHIP in the waterfall
 run --steps 4 --warmup 2 --schedule layered --ebn0 2                                                             # ... and below it
-run --steps 4 --warmup 2 --schedule layered --dtype f16pk --ebn0 3                                               # layered on-chip in packed fp16
+run --steps 4 --warmup 2 --schedule layered --dtype f16pk --ebn0 3.4                                             # layered on-chip in packed fp16
+run --steps 4 --warmup 2 --schedule layered --dtype f16pk --ebn0 3
 run --steps 4 --warmup 2 --schedule layered --dtype f16pk --ebn0 2
 LDPC_HIP_PATH=flood run --steps 3 --warmup 1 --batch 16384 --schedule layered --ebn0 3                           # jpl.4096 layered from HBM
 run --steps 3 --warmup 1 --batch 65536 --ebn0 3                                                                  # jpl.4096 flooding (on-chip) at the same point
@@ -34,5 +35,5 @@ import json
 for l in open('gpurun_out/bench_matrix.jsonl'):
     d = json.loads(l)
     r = d['roofline']
-    print(f"{d['config']['code_name']:52s} {d['config']['path']:5s} {d['dtype']} {d['metric'].split('Eb/N0=')[1]:6s} B={d['config']['batch_per_gpu']:6d} {d['value']:9.1f} Mbit/s  {d['ms_per_step']:8.2f} ms  {r['bound']} roofline {r['frac'] if r['frac'] is not None else float('nan'):.3f}  ber {d['ber']:.3e} fer {d['fer']:.3f} it {d['mean_iters']:.1f}  {r['kernel'][:46]}")
+    print(f"{d['config']['code_name']:52s} {d['config']['path']:5s} {d['dtype']} {d['metric'].split('Eb/N0=')[1]:6s} B={d['config']['batch_per_gpu']:6d} {d['value']:9.1f} Mbit/s  {d['ms_per_step']:8.2f} ms  {r['bound']} roofline {('%.3f' % r['frac']) if r['frac'] is not None else 'n/a'}  ber {d['ber']:.3e} fer {d['fer']:.3f} it {d['mean_iters']:.1f}  {r['kernel'][:46]}")
 PY

@@ -46,7 +46,7 @@ def main():
     ap.add_argument("--schedule", default="flooding", choices=["flooding", "layered"], help="layered: extension (BASELINE configs[4])")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the cpu_baseline sample (0 = skip)")
     ap.add_argument("--seed", type=lambda s: int(s, 0), default=0x5EEDC0DE)
-    ap.add_argument("--fp16-leg", type=int, default=1, help="0: skip the second measurement of the same workload with the packed-fp16 decoder "
+    ap.add_argument("--fp16-leg", type=int, default=1, help="0: skip the extra, separately labelled measurements of the same workload (packed-fp16 decoder; layered schedule f32 / packed fp16) "
                     "(BASELINE configs[3]; reported next to the f32 headline as `fp16_packed`, never as `value`)")
     ap.add_argument("--proof", type=int, default=1, help="0: skip the untimed proof-of-work sample (tools/profile.sh does, so that the "
                     "kernel-trace average covers full-size launches only)")
@@ -194,6 +194,9 @@ def main():
             out["cpu_baseline"] = cpu_baseline(args, ecc, llr[0], value)
         if world == 1 and args.dtype == "f32" and args.variant == "minsum" and args.schedule == "flooding" and args.path == "auto" and args.fp16_leg:
             out["fp16_packed"] = fp16_packed_leg(args, E, torch, dev, sp, B)
+            # the row-layered schedule (an extension: the reference has flooding only) on the same code, on-chip, f32 and packed fp16,
+            # at the headline Eb/N0 and in the waterfall -- labelled measurements next to `value`, never instead of it
+            out["layered_extension"] = [layered_leg(args, E, torch, dev, sp, B, f16pk, db) for f16pk in (False, True) for db in sorted({args.ebn0, 3.0})]
         print(json.dumps(out), flush=True)
     # release the device objects in a known order before interpreter teardown
     torch.cuda.synchronize()
@@ -202,6 +205,39 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def layered_leg(args, E, torch, dev, sp, B, f16pk, ebn0):
+    name = f"ldpc/hip-minsum-layered{'-f16pk' if f16pk else ''}/{args.code}/{args.iters}"
+    if args.rate not in ("", "none"):
+        x, y = args.rate.split("/")
+        name += f"/{x}/{y}"
+    try:
+        ecc = E.ECC(os.path.join(ROOT, "codes"), name, max_batch=B)
+    except E.LdpcError as e:
+        return {"code_name": name, "error": str(e)}
+    dec, sim, k, N = ecc.decoder, ecc.sim, ecc.message_length, ecc.code.N
+    llr = torch.empty((B, N), dtype=torch.float16 if f16pk else torch.float32, device=dev)
+    msg = torch.empty((B, k), dtype=torch.uint8, device=dev)
+    bits = torch.empty((B, N), dtype=torch.uint8, device=dev)
+    its = torch.empty((B,), dtype=torch.int32, device=dev)
+    sim.generate(args.seed, 0, B, ebn0, llr.data_ptr(), msg.data_ptr(), sp, llr_f16=f16pk)
+    step = lambda: dec.decode_batch_dev(llr.data_ptr(), bits.data_ptr(), B, args.iters, its.data_ptr(), None, sp, llr_f16=f16pk)
+    step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    wrong = (bits[:, :k] != msg).sum(dim=1)
+    res = {"code_name": name, "ebn0_db": ebn0, "value": round(args.steps * B * k / dt / 1e6, 2), "unit": "Mbit/s", "ms_per_step": round(dt / args.steps * 1e3, 3),
+           "path": dec.path, "kernel": dec.kernel_name, "ber": float(wrong.sum().item()) / (B * k), "fer": float((wrong > 0).sum().item()) / B,
+           "mean_sweeps": float(its.float().mean().item()),
+           "checked_by": "tests/test_pk16_gpu.py (emulation, bit for bit)" if f16pk else "tests/test_layered_fused_gpu.py (HBM layered kernel bit for bit; oracle_decode_layered hard bits)"}
+    ecc.close()
+    del llr, msg, bits, its
+    return res
 
 
 def fp16_packed_leg(args, E, torch, dev, sp, B):

@@ -1,12 +1,14 @@
 // fused_layered_body.h -- the row-layered schedule ON-CHIP for the codes the split kernel takes (EXTENSION: the reference has
 // no layered decoder; specification = oracle/ldpc_oracle.c oracle_decode_layered, HBM implementation = layered_qc.hip).
 //
-// Same workgroup as the flooding split kernel (fused_split_body.h): lam in LDS, a frame's block rows dealt to NP wave groups,
-// thread (group, r) = row r of every circulant of its group's block rows, its messages in registers.  A LAYER = a block row;
-// layers run in order, so at any moment ONE group of the workgroup works (its 128 rows read the lam cells of their columns,
-// apply the check rule, and write lam back -- the rows of a block row touch distinct columns) while the other waits at the
-// barrier that ends the layer; the SIMDs are kept busy by the other workgroups of the CU.  No column "rounds", no second
-// pass over LDS, no channel-LLR registers: a sweep is NBR x {gather, rule, scatter, barrier}.
+// Same workgroup as the flooding split kernel (fused_split_body.h): lam in LDS, NP wave groups, messages in registers.  A LAYER = a
+// block row; layers run in order.  Two ways to give the groups work:
+//   * block rows dealt to the groups (plans with NP /= 2, and rows lighter than LAY_SPLIT_MIN_DEG): thread (group, r) = row r of
+//     every circulant of its group's block rows; ONE group works per layer (its rows read the lam cells of their columns, apply
+//     the check rule, write lam back -- the rows of a block row touch distinct columns), the others wait at the barrier that
+//     ends the layer;
+//   * rows split between the two groups (NP == 2, the default: Halves below): both groups work on every layer, two barriers.
+// No column "rounds", no second pass over LDS, no channel-LLR registers: a sweep is NBR x {gather, rule, scatter, barrier(s)}.
 //   t_k = lam[c_k] - msg_k;  odd |= XOR_k hard(lam[c_k]);  msg' = rule(t);  new_k = t_k + msg'_k;  flip |= hard(new_k) != hard(lam[c_k])
 // Stopping rule (the specification's): before the first sweep the syndrome of the channel decisions; after a sweep "no check
 // it saw was odd and no hard decision changed"; out of sweeps -> the channel's hard decisions, as Orig.hs:70.

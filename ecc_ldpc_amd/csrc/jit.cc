@@ -1,5 +1,7 @@
-// jit.cc -- run-time specialisation of the fused quasi-cyclic split kernel (see jit.h).
-//   source   : generated plan + rotation table + one extern "C" kernel around split_kernel_body (fused_split_body.h);
+// jit.cc -- run-time specialisation of the fused quasi-cyclic kernels (see jit.h): the f32 split kernel and, since r03, the
+// packed-fp16 and the two on-chip layered kernels (JitKind).
+//   source   : generated plan + rotation table + one extern "C" kernel around the body (fused_split_body.h, fused_pk16_body.h,
+//              fused_layered_body.h);
 //              the device headers are embedded in the library at build time (jit_embed.inc, build.py)
 //   compiler : `hipcc --genco` in a child process when the tool chain is installed, else hiprtc in-process (dlopen'ed:
 //              no link-time dependency); LDPC_JIT_COMPILER=hipcc|hiprtc forces one.  See jit_compile_cached for why.

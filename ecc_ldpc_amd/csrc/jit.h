@@ -2,10 +2,11 @@
 //
 // The fused kernels want the graph as COMPILE-TIME constants (rotations as literals, block-column bases in the DS
 // offset field, register slots named statically).  For the shipped matrices those instances are built ahead of time
-// (fused_split.hip); for any other single-circulant quasi-cyclic H -- what the reference's QC decoders take,
-// src/ECC/Code/LDPC/Fast/Arraylet.hs:68-79 -- the same device source (fused_split_body.h) is compiled at context
-// creation by hiprtc with a plan and a rotation table generated from the code's description, and the code object is
-// cached on disk (key = hash of the generated source and the options).
+// (fused_split.hip, fused_pk16.hip, fused_layered.hip); for any other single-circulant quasi-cyclic H -- what the reference's
+// QC decoders take, src/ECC/Code/LDPC/Fast/Arraylet.hs:68-79 -- the same device source (fused_split_body.h, fused_pk16_body.h,
+// fused_layered_body.h) is compiled at context creation (hipcc --genco in a child process, or hiprtc) with a plan and a rotation
+// table generated from the code's description, and the code object is cached on disk (key = hash of the generated source, the
+// options and the compiler route).
 #pragma once
 #include <string>
 #include <vector>

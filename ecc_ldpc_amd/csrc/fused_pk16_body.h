@@ -30,6 +30,10 @@
 // p + rotation never wraps (address = the lane's base register + an immediate: 945 -> 855 VALU instructions per wave-turn, LDS
 // 45 KB per workgroup, column updates storing both copies).  jpl.4096, 65 536 frames, 2 dB: 13.2 ms per launch against 11.85 --
 // the doubled LDS write traffic (both copies on the same bank) costs more than the 10 % of VALU issue it saves.
+// Also tried in r03 and dropped (compile-time evidence only): a register diet for 4 waves per SIMD -- heavy rows gathered nine edges
+// at a time, tN written over u at once, |tN| recomputed where the leave-one-out minimum uses it instead of being held: 152 VGPRs
+// wanted (162 today), at 128 still 12-24 spilled registers per turn, and 1 105 VALU per wave-turn instead of 949 (+13 % issue cost).
+// The layered kernel's step from 3 to 4 waves bought 10 % with NO extra instructions; this one would start 13 % behind.
 #pragma once
 #include "fused_split_body.h"
 

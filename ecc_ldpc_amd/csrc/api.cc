@@ -405,7 +405,11 @@ ldpc_ctx *ldpc_ctx_create_cfg(const ldpc_code *code_c, const ldpc_ctx_config *cf
     }
     const bool layered_fused_ok = schedule == LDPC_SCHED_LAYERED && sum_order == LDPC_SUM_REFERENCE && ldpc::fused_layered_why_not(*code, variant, dtype) == nullptr;
     if (schedule == LDPC_SCHED_LAYERED) {
-        if (dtype == LDPC_F16 && (!layered_fused_ok || path == LDPC_PATH_FLOOD)) { set_error(LDPC_EUNSUPPORTED, "the layered schedule from HBM exists for f32 and f64"); return nullptr; }
+        if (dtype == LDPC_F16 && (!layered_fused_ok || path == LDPC_PATH_FLOOD)) {
+            // from HBM: lam stored in fp16 for the frame-per-workgroup min-sum record kernel of QC codes (r03); nothing else
+            const char *why = sum_order == LDPC_SUM_REFERENCE ? ldpc::layered_qc_why_not(*code, variant, dtype, 0) : "parity modes are f64";
+            if (why) { set_error(LDPC_EUNSUPPORTED, "the layered schedule from HBM with fp16 storage: %s", why); return nullptr; }
+        }
         if (code->max_row_deg > 32) { set_error(LDPC_EUNSUPPORTED, "layered schedule: check rows above weight 32 (this code has %d)", code->max_row_deg); return nullptr; }
     }
     const bool fused_ok = layered_fused_ok ||

@@ -49,10 +49,20 @@ struct QcLayerArgs {
     const double *st_lam, *st_ne_in; double *st_ne_out, *st_lam_out; uint8_t *st_syn;   // teacher-forced sweep (CSR edge order)
 };
 
+// lam may be STORED in another type than the arithmetic's (LT = __half with CT = float: LDPC_F16 + LDPC_SCHED_LAYERED, r03 --
+// half the bytes of the dominant stream of the record kernel); Store<> converts, saturating on the way to fp16
+template <typename CT, typename LT> __device__ __forceinline__ CT ldlam(const LT *lam, int i) { return (CT)Store<LT>::ld(lam + i); }
+template <typename CT, typename LT> __device__ __forceinline__ void stlam(LT *lam, int i, CT v) { Store<LT>::st(lam + i, v); }
+// the value a lam cell holds after v was stored into it
+template <typename LT, typename CT> __device__ __forceinline__ CT lam_round(CT v) {
+    if constexpr (std::is_same<LT, CT>::value) return v;
+    else { LT tmp; Store<LT>::st(&tmp, v); return (CT)Store<LT>::ld(&tmp); }
+}
+
 // MODE 0: layered sweep, 1: first layered sweep (messages are zero), 2: syndrome only,
 //      3: flooding check-node pass (new messages written, lam untouched), 4: the same on the first turn (messages are zero)
-template <typename CT, int VARIANT, int DEG, int MODE>
-__device__ __forceinline__ void qc_row(const QcLayerDev &g, CT *__restrict__ lam, CT *__restrict__ msg, int e0, int r, bool live, bool &odd, bool &flip) {
+template <typename CT, int VARIANT, int DEG, int MODE, typename LT>
+__device__ __forceinline__ void qc_row(const QcLayerDev &g, LT *__restrict__ lam, CT *__restrict__ msg, int e0, int r, bool live, bool &odd, bool &flip) {
     int idx[DEG];
     CT l[DEG], t[DEG];
 #pragma unroll
@@ -63,7 +73,7 @@ __device__ __forceinline__ void qc_row(const QcLayerDev &g, CT *__restrict__ lam
         idx[k] = cb + c;
     }
 #pragma unroll
-    for (int k = 0; k < DEG; k++) l[k] = live ? lam[idx[k]] : CT(0);
+    for (int k = 0; k < DEG; k++) l[k] = live ? ldlam<CT>(lam, idx[k]) : CT(0);
     constexpr bool kReadMsg = MODE == 0 || MODE == 3, kFlooding = MODE >= 3;
     if constexpr (kReadMsg) {
 #pragma unroll
@@ -83,15 +93,15 @@ __device__ __forceinline__ void qc_row(const QcLayerDev &g, CT *__restrict__ lam
         if constexpr (kFlooding) {
             if (live) msg[(size_t)(e0 + k) * g.sz + r] = nm[k];
         } else {
-            const CT nw = t[k] + nm[k];
+            const CT nw = lam_round<LT>(t[k] + nm[k]);
             flip |= live && (hard(nw) != hard(l[k]));
-            if (live) { lam[idx[k]] = nw; msg[(size_t)(e0 + k) * g.sz + r] = nm[k]; }
+            if (live) { stlam(lam, idx[k], nw); msg[(size_t)(e0 + k) * g.sz + r] = nm[k]; }
         }
     }
 }
 
-template <typename CT, int VARIANT, int DMAX, int MODE>
-__device__ __forceinline__ void qc_row_padded(const QcLayerDev &g, CT *__restrict__ lam, CT *__restrict__ msg, int e0, int deg, int r, bool live,
+template <typename CT, int VARIANT, int DMAX, int MODE, typename LT>
+__device__ __forceinline__ void qc_row_padded(const QcLayerDev &g, LT *__restrict__ lam, CT *__restrict__ msg, int e0, int deg, int r, bool live,
                                               bool &odd, bool &flip) {
     int idx[DMAX];
     CT l[DMAX], t[DMAX];
@@ -104,7 +114,7 @@ __device__ __forceinline__ void qc_row_padded(const QcLayerDev &g, CT *__restric
         idx[k] = cb + c;
     }
 #pragma unroll
-    for (int k = 0; k < DMAX; k++) l[k] = (live && k < deg) ? lam[idx[k]] : CT(0);
+    for (int k = 0; k < DMAX; k++) l[k] = (live && k < deg) ? ldlam<CT>(lam, idx[k]) : CT(0);
     constexpr bool kReadMsg = MODE == 0 || MODE == 3, kFlooding = MODE >= 3;
     if constexpr (kReadMsg) {
 #pragma unroll
@@ -125,9 +135,9 @@ __device__ __forceinline__ void qc_row_padded(const QcLayerDev &g, CT *__restric
             if constexpr (kFlooding) {
                 if (live) msg[(size_t)(e0 + k) * g.sz + r] = nm[k];
             } else {
-                const CT nw = t[k] + nm[k];
+                const CT nw = lam_round<LT>(t[k] + nm[k]);
                 flip |= live && (hard(nw) != hard(l[k]));
-                if (live) { lam[idx[k]] = nw; msg[(size_t)(e0 + k) * g.sz + r] = nm[k]; }
+                if (live) { stlam(lam, idx[k], nw); msg[(size_t)(e0 + k) * g.sz + r] = nm[k]; }
             }
         }
     }
@@ -139,8 +149,8 @@ __device__ __forceinline__ void qc_row_padded(const QcLayerDev &g, CT *__restric
 // bytes per row (f32) instead of 4 per edge: on the DVB-S2-shaped code (weight-7 rows) a sweep moves 0.39 MB of
 // records instead of 1.81 MB of messages.  The rebuilt messages are the per-edge kernel's bit for bit (same
 // comparisons, first arg-min wins, the one rounding of Min.hs:78 applied once).  Rows up to weight 27.
-template <typename CT, int DMAX, bool FIRST>
-__device__ __forceinline__ void qc_row_rec(const QcLayerDev &g, CT *__restrict__ lam, CT *__restrict__ rc1, CT *__restrict__ rc2, uint32_t *__restrict__ rmeta,
+template <typename CT, int DMAX, bool FIRST, typename LT>
+__device__ __forceinline__ void qc_row_rec(const QcLayerDev &g, LT *__restrict__ lam, CT *__restrict__ rc1, CT *__restrict__ rc2, uint32_t *__restrict__ rmeta,
                                            int e0, int deg, int row, int r, bool live, bool &odd, bool &flip) {
     int idx[DMAX];
     CT l[DMAX], t[DMAX];
@@ -153,7 +163,7 @@ __device__ __forceinline__ void qc_row_rec(const QcLayerDev &g, CT *__restrict__
         idx[k] = cb + c;
     }
 #pragma unroll
-    for (int k = 0; k < DMAX; k++) l[k] = (live && k < deg) ? lam[idx[k]] : CT(0);
+    for (int k = 0; k < DMAX; k++) l[k] = (live && k < deg) ? ldlam<CT>(lam, idx[k]) : CT(0);
     CT c1 = CT(0), c2 = CT(0);
     uint32_t meta = 0;
     if constexpr (!FIRST) {
@@ -190,16 +200,16 @@ __device__ __forceinline__ void qc_row_rec(const QcLayerDev &g, CT *__restrict__
             const CT mag = (k == i1) ? n2 : n1;
             const CT nm = neg ? mag : -mag;
             nsig |= (neg ? 0u : 1u) << k;                               // sign bit of the message
-            const CT nw = t[k] + nm;
+            const CT nw = lam_round<LT>(t[k] + nm);
             flip |= live && (hard(nw) != hard(l[k]));
-            if (live) lam[idx[k]] = nw;
+            if (live) stlam(lam, idx[k], nw);
         }
     }
     if (live) { rc1[row] = n1; rc2[row] = n2; rmeta[row] = nsig | ((uint32_t)i1 << 27); }
 }
 
-template <typename CT, int DCLASS, bool FIRST>
-__device__ __forceinline__ void qc_layer_rec(const QcLayerDev &g, CT *lam, CT *rc1, CT *rc2, uint32_t *rmeta, int layer, int r, bool live, bool &odd, bool &flip) {
+template <typename CT, int DCLASS, bool FIRST, typename LT>
+__device__ __forceinline__ void qc_layer_rec(const QcLayerDev &g, LT *lam, CT *rc1, CT *rc2, uint32_t *rmeta, int layer, int r, bool live, bool &odd, bool &flip) {
     const int e0 = ((cidx_t)g.lbeg)[layer], deg = ((cidx_t)g.lbeg)[layer + 1] - e0;
     const int row = layer * g.sz + r;
     if (deg <= 0) return;
@@ -208,8 +218,8 @@ __device__ __forceinline__ void qc_layer_rec(const QcLayerDev &g, CT *lam, CT *r
     if constexpr (DCLASS >= 32) { qc_row_rec<CT, 27, FIRST>(g, lam, rc1, rc2, rmeta, e0, deg, row, r, live, odd, flip); }
 }
 
-template <typename CT, int VARIANT, int DCLASS, int MODE>
-__device__ __forceinline__ void qc_layer(const QcLayerDev &g, CT *lam, CT *msg, int layer, int r, bool live, bool &odd, bool &flip) {
+template <typename CT, int VARIANT, int DCLASS, int MODE, typename LT>
+__device__ __forceinline__ void qc_layer(const QcLayerDev &g, LT *lam, CT *msg, int layer, int r, bool live, bool &odd, bool &flip) {
     const int e0 = ((cidx_t)g.lbeg)[layer], deg = ((cidx_t)g.lbeg)[layer + 1] - e0;
     switch (deg) {
         case 0: return;
@@ -248,12 +258,12 @@ __device__ __forceinline__ void qc_layer(const QcLayerDev &g, CT *lam, CT *msg, 
 #ifndef LQC_WAVES_LIGHT
 #define LQC_WAVES_LIGHT 8
 #endif
-template <typename CT, int VARIANT, int DCLASS, bool RECORDS>
-__global__ __launch_bounds__(1024, (DCLASS <= 8 && sizeof(CT) == 4 ? LQC_WAVES_LIGHT : 4)) void layered_qc_kernel(QcLayerDev g, CT *lam_all, CT *msg_all, QcLayerArgs A) {
+template <typename CT, int VARIANT, int DCLASS, bool RECORDS, typename LT = CT>
+__global__ __launch_bounds__(1024, (DCLASS <= 8 && sizeof(CT) == 4 ? LQC_WAVES_LIGHT : 4)) void layered_qc_kernel(QcLayerDev g, LT *lam_all, CT *msg_all, QcLayerArgs A) {
     const int r = threadIdx.x;
     const bool live = r < g.sz;
     const size_t frame = blockIdx.x;
-    CT *lam = lam_all + frame * (size_t)g.N;
+    LT *lam = lam_all + frame * (size_t)g.N;
     const int Mrows = g.nbr * g.sz;
     CT *msg = msg_all + frame * (RECORDS ? (size_t)3 * Mrows : (size_t)g.E);
     CT *rc1 = msg, *rc2 = msg + Mrows;
@@ -261,14 +271,14 @@ __global__ __launch_bounds__(1024, (DCLASS <= 8 && sizeof(CT) == 4 ? LQC_WAVES_L
     const size_t fN = frame * (size_t)g.N;
     // ---- lam <- channel LLRs (or the given state)
     if (A.step_mode) {
-        for (int i = r; i < g.N; i += blockDim.x) lam[i] = (CT)A.st_lam[fN + i];
+        for (int i = r; i < g.N; i += blockDim.x) stlam(lam, i, (CT)A.st_lam[fN + i]);
         for (int l = 0; l < g.nbr; l++) {       // messages arrive in CSR edge order: row-major, ascending column
             const int e0 = g.lbeg[l], deg = g.lbeg[l + 1] - e0;
             if (live)
                 for (int k = 0; k < deg; k++) msg[(size_t)(e0 + k) * g.sz + r] = (CT)A.st_ne_in[frame * (size_t)g.E + (size_t)e0 * g.sz + (size_t)r * deg + k];
         }
     } else {
-        for (int i = r; i < g.N; i += blockDim.x) lam[i] = load_llr<CT>(A.llr, fN + i, A.llr_fmt);
+        for (int i = r; i < g.N; i += blockDim.x) stlam(lam, i, load_llr<CT>(A.llr, fN + i, A.llr_fmt));
     }
     __syncthreads();
     bool conv = false;
@@ -281,7 +291,7 @@ __global__ __launch_bounds__(1024, (DCLASS <= 8 && sizeof(CT) == 4 ? LQC_WAVES_L
         else conv = !any;
     }
     if (A.trace && !A.step_mode) {   // (uniform condition)
-        for (int i = r; i < g.N; i += blockDim.x) A.trace[(frame * (A.max_iters + 1)) * (size_t)g.N + i] = (double)lam[i];
+        for (int i = r; i < g.N; i += blockDim.x) A.trace[(frame * (A.max_iters + 1)) * (size_t)g.N + i] = (double)ldlam<CT>(lam, i);
         __syncthreads();             // no wave starts layer 0 (which writes lam) while another still copies row 0
     }
     if (!conv) {
@@ -297,7 +307,7 @@ __global__ __launch_bounds__(1024, (DCLASS <= 8 && sizeof(CT) == 4 ? LQC_WAVES_L
             }
             const int any = __syncthreads_or((odd || flip) ? 1 : 0);
             if (A.trace && !A.step_mode) {
-                for (int i = r; i < g.N; i += blockDim.x) A.trace[(frame * (A.max_iters + 1) + n) * (size_t)g.N + i] = (double)lam[i];
+                for (int i = r; i < g.N; i += blockDim.x) A.trace[(frame * (A.max_iters + 1) + n) * (size_t)g.N + i] = (double)ldlam<CT>(lam, i);
                 __syncthreads();
             }
             if (A.step_mode) break;
@@ -306,7 +316,7 @@ __global__ __launch_bounds__(1024, (DCLASS <= 8 && sizeof(CT) == 4 ? LQC_WAVES_L
         if (n > A.max_iters) n = A.max_iters;
     }
     if (A.step_mode) {
-        for (int i = r; i < g.N; i += blockDim.x) A.st_lam_out[fN + i] = (double)lam[i];
+        for (int i = r; i < g.N; i += blockDim.x) A.st_lam_out[fN + i] = (double)ldlam<CT>(lam, i);
         for (int l = 0; l < g.nbr; l++) {
             const int e0 = g.lbeg[l], deg = g.lbeg[l + 1] - e0;
             if (live)
@@ -316,7 +326,7 @@ __global__ __launch_bounds__(1024, (DCLASS <= 8 && sizeof(CT) == 4 ? LQC_WAVES_L
     }
     // ---- result: hard(lam) of a frame that stopped by the rule, the channel's decisions otherwise (as Orig.hs:69-70)
     for (int i = r; i < g.N; i += blockDim.x) {
-        const CT v = conv ? lam[i] : load_llr<CT>(A.llr, fN + i, A.llr_fmt);
+        const CT v = conv ? ldlam<CT>(lam, i) : lam_round<LT>(load_llr<CT>(A.llr, fN + i, A.llr_fmt));   // (an LLR counts as stored in LT)
         A.bits[fN + i] = v > CT(0) ? 1 : 0;
         if (A.final_lam) A.final_lam[fN + i] = (double)v;
     }
@@ -434,7 +444,11 @@ struct LayeredQcState {
 const char *layered_qc_why_not(const ldpc_code &c, int variant, int dtype, int flooding) {
     if (c.sz <= 0) return "code was not created from a quasi-cyclic description";
     if (c.sz > 1024) return "circulant size above 1024";
-    if (dtype != LDPC_F32 && dtype != LDPC_F64) return "the frame-per-workgroup HBM kernels exist for f32 and f64";
+    if (dtype == LDPC_F16) {   // fp16 STORAGE of lam (f32 arithmetic, f32 row records): the layered min-sum record kernel only
+        if (flooding || variant != LDPC_MINSUM || c.max_row_deg > 27) return "fp16 lam storage exists for the layered min-sum kernel with row records (rows up to weight 27)";
+        const char *re = getenv("LDPC_LAYERED_RECORDS");
+        if (re && !strcmp(re, "0")) return "fp16 lam storage needs the row-record kernel (LDPC_LAYERED_RECORDS=0 disables it)";
+    } else if (dtype != LDPC_F32 && dtype != LDPC_F64) return "the frame-per-workgroup HBM kernels exist for f32, f64 and (layered min-sum) fp16 lam storage";
     if (variant != LDPC_TANH && variant != LDPC_MINSUM) return "tanh and min-sum rules only";
     if (c.max_row_deg > 32) return "check rows above weight 32";
     if (!flooding) {
@@ -474,7 +488,7 @@ LayeredQcState *layered_qc_create(const ldpc_code &c, int variant, int dtype, in
         const size_t es = dtype == LDPC_F64 ? 8 : 4;
         hipError_t e = hipMalloc((void **)&s->d_tab, sizeof(int32_t) * std::max<size_t>(tab.size(), 2));
         if (e == hipSuccess) e = hipMalloc((void **)&s->d_lbeg, sizeof(int32_t) * lbeg.size());
-        if (e == hipSuccess) e = hipMalloc(&s->lam, (size_t)max_batch * c.N * es);
+        if (e == hipSuccess) e = hipMalloc(&s->lam, (size_t)max_batch * c.N * (dtype == LDPC_F16 ? 2 : es));
         {
             const char *re = getenv("LDPC_LAYERED_RECORDS");
             s->records = !flooding && variant == LDPC_MINSUM && c.max_row_deg <= 27 && !(re && !strcmp(re, "0"));
@@ -499,9 +513,9 @@ LayeredQcState *layered_qc_create(const ldpc_code &c, int variant, int dtype, in
             return nullptr;
         }
         s->g.tab = s->d_tab; s->g.lbeg = s->d_lbeg; s->g.ctab = s->d_ctab; s->g.cbeg = s->d_cbeg;
-        snprintf(s->info.name, sizeof(s->info.name), "ldpc::%s<%s, %d, %d%s>", flooding ? "flood_qc_kernel" : "layered_qc_kernel", dtype == LDPC_F64 ? "double" : "float",
+        snprintf(s->info.name, sizeof(s->info.name), "ldpc::%s<%s, %d, %d%s%s>", flooding ? "flood_qc_kernel" : "layered_qc_kernel", dtype == LDPC_F64 ? "double" : "float",
                  variant == LDPC_MINSUM ? LDPC_V_MINSUM : LDPC_V_TANH, c.max_row_deg <= 8 ? 8 : (c.max_row_deg <= 20 ? 20 : 32),
-                 flooding ? "" : (s->records ? ", true" : ", false"));
+                 flooding ? "" : (s->records ? ", true" : ", false"), dtype == LDPC_F16 ? ", __half" : "");
         s->info.threads = s->threads; s->info.frames_per_wg = 1;
         return s;
     } catch (...) { layered_qc_destroy(s); set_error(LDPC_ENOMEM, "out of host memory"); return nullptr; }
@@ -533,7 +547,21 @@ static int launch(LayeredQcState &s, hipStream_t st, QcLayerArgs &a) {
     return LDPC_OK;
 }
 
+static int launch_f16(LayeredQcState &s, hipStream_t st, QcLayerArgs &a) {
+    if (a.step_mode) return set_error(LDPC_EUNSUPPORTED, "no teacher-forced step with fp16 lam storage (the record kernel keeps no per-edge messages)");
+    const dim3 grid(a.batch), block(s.threads);
+    if (s.timer) s.timer->begin(st);
+    if (s.max_row_deg <= 8) hipLaunchKernelGGL((layered_qc_kernel<float, LDPC_V_MINSUM, 8, true, __half>), grid, block, 0, st, s.g, (__half *)s.lam, (float *)s.msg, a);
+    else if (s.max_row_deg <= 20) hipLaunchKernelGGL((layered_qc_kernel<float, LDPC_V_MINSUM, 20, true, __half>), grid, block, 0, st, s.g, (__half *)s.lam, (float *)s.msg, a);
+    else hipLaunchKernelGGL((layered_qc_kernel<float, LDPC_V_MINSUM, 32, true, __half>), grid, block, 0, st, s.g, (__half *)s.lam, (float *)s.msg, a);
+    if (s.timer) s.timer->end(st);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return set_error(LDPC_EHIP, "layered_qc launch: %s", hipGetErrorString(e));
+    return LDPC_OK;
+}
+
 static int run(LayeredQcState &s, hipStream_t st, QcLayerArgs &a) {
+    if (s.dtype == LDPC_F16) return launch_f16(s, st, a);
     if (s.dtype == LDPC_F64) return s.variant == LDPC_MINSUM ? launch<double, LDPC_V_MINSUM>(s, st, a) : launch<double, LDPC_V_TANH>(s, st, a);
     return s.variant == LDPC_MINSUM ? launch<float, LDPC_V_MINSUM>(s, st, a) : launch<float, LDPC_V_TANH>(s, st, a);
 }

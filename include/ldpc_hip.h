@@ -59,7 +59,8 @@ typedef enum { LDPC_TANH = 0, LDPC_MINSUM = 1, LDPC_TANH_CM = 2 } ldpc_variant;
  *      every LLR given to an F16 context counts as stored in fp16 (saturating round-to-nearest-even on load);
  *      the flood path also keeps lam and the messages in fp16 between its kernels, the fused paths keep them
  *      on-chip in f32 -- so for F16 the two paths are two different (documented) decoders, each with its own
- *      emulation in oracle/emulate_f16.py, whereas for F32/F64 they agree bit for bit. */
+ *      emulation in oracle/emulate_f16.py, whereas for F32/F64 they agree bit for bit.  With LDPC_SCHED_LAYERED from HBM
+ *      (quasi-cyclic codes, min-sum): lam stored in fp16, f32 row records (emulation decode_minsum_f16_layered). */
 /* F16PK (extension, BASELINE.json configs[3] "min-sum fp16 LLRs"): ARITHMETIC in IEEE binary16, two frames per lane in
  *      packed instructions (csrc/fused_pk16_body.h holds the specification: the loop of Min.hs:54-104 on fp16 values, the 3/4
  *      applied inside fused multiply-adds; channel LLRs saturate at +-16384 and message magnitudes at 2048, so that no sum

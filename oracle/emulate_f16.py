@@ -239,3 +239,49 @@ def decode_minsum_pk16_layered(g, llr, max_iters):
             live &= moved
     iters[live] = max_iters
     return out.astype(np.uint8), iters, conv, trace
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# LDPC_F16 + LDPC_SCHED_LAYERED from HBM (csrc/layered_qc.hip, layered_qc_kernel<float, 1, D, true, __half>): the row-layered
+# schedule of oracle_decode_layered with lam STORED in fp16 (saturating round to nearest even at every write), f32 arithmetic,
+# f32 messages (the kernel keeps them as row records {3/4 min1, 3/4 min2, signs | arg-min}: the same values)
+def decode_minsum_f16_layered(g, llr, max_iters):
+    """llr [F, N] float32 -> bits [F, N] u8, sweeps [F], converged [F], lam [F, N] float32 as each frame stopped (the fp16-rounded
+    channel LLRs for a frame out of sweeps).  Rows in ascending order = layer by layer (the rows of a layer share no column)."""
+    llr = np.asarray(llr, np.float32)
+    F = llr.shape[0]
+    orig = r16(llr)
+    lam = orig.copy()
+    msg = np.zeros((F, g.E), np.float32)
+    rows = _rows(g)
+    hard0 = lam > 0
+    ok = np.ones(F, bool)
+    for m, cols, e0 in rows:
+        ok &= ~np.logical_xor.reduce(hard0[:, cols], axis=1)
+    conv = ok.copy()
+    live = ~ok
+    iters = np.zeros(F, np.int32)
+    out = lam.copy()
+    for n in range(1, max_iters + 1):
+        if not live.any():
+            break
+        moved = np.zeros(F, bool)
+        L, M = lam.copy(), msg.copy()
+        for m, cols, e0 in rows:
+            d = len(cols)
+            l = L[:, cols]
+            moved |= np.logical_xor.reduce(l > 0, axis=1)                        # odd
+            t = (l - M[:, e0:e0 + d]).astype(np.float32)
+            nm = cn_minsum_f32(t)
+            nw = r16((t + nm).astype(np.float32))                                # what the lam cell holds afterwards
+            moved |= ((nw > 0) != (l > 0)).any(axis=1)                           # flip
+            L[:, cols] = nw
+            M[:, e0:e0 + d] = nm
+        lam = np.where(live[:, None], L, lam)
+        msg = np.where(live[:, None], M, msg)
+        fin = live & ~moved
+        out[fin] = lam[fin]; conv[fin] = True; iters[fin] = n
+        live &= moved
+    iters[live] = max_iters
+    out[live] = orig[live]
+    return (out > 0).astype(np.uint8), iters, conv, out

@@ -135,10 +135,12 @@ def test_edge_cases_and_custom_layers(hip):
         code_csr.set_layers(np.arange(c.M + 1))
     b0, i0, c0 = dec.decode_batch(llr[:3].astype(np.float32), 0)     # no sweeps allowed: channel decisions
     assert np.array_equal(b0, (llr[:3] > 0).astype(np.uint8)) and not c0.any()
-    with pytest.raises(hip.LdpcError) as e:                 # fp16 STORAGE of a layered decoder's HBM state does not exist ...
-        hip.Decoder(c.hip_code(hip), "min", "f16", 8, schedule="layered", path="flood")
+    with pytest.raises(hip.LdpcError) as e:                 # fp16 STORAGE of a layered decoder's HBM state: min-sum row records of QC codes only
+        hip.Decoder(c.hip_code(hip), "tanh", "f16", 8, schedule="layered", path="flood")
     assert e.value.code == -5
-    from oracle import emulate_f16 as em                    # ... on-chip the only thing in HBM is the LLRs: the f32 decoder on fp16-rounded LLRs
+    with pytest.raises(hip.LdpcError):
+        hip.Decoder(code_csr, "min", "f16", 8, schedule="layered", path="flood")
+    from oracle import emulate_f16 as em                    # on-chip the only thing in HBM is the LLRs: the f32 decoder on fp16-rounded LLRs
     d16 = hip.Decoder(c.hip_code(hip), "min", "f16", 70, schedule="layered")
     d32 = hip.Decoder(c.hip_code(hip), "min", "f32", 70, schedule="layered")
     assert d16.path == "fused"
@@ -207,3 +209,28 @@ def test_row_records_equal_per_edge_messages(hip, name, monkeypatch):
     for f in range(4):
         o = oracle.decode_layered(c.graph, lp, "min", 25, llr[f], trace=True)
         assert ta[1][f] == o["iters"] and np.array_equal(ta[3][f, : o["iters"] + 1], o["trace_lam"])
+
+
+@pytest.mark.parametrize("name,F,dbs", [("jpl.1024.4.5", 40, (2.5, 3.5)), ("jpl.4096.4.5", 12, (2.8, 3.4))])
+def test_fp16_lam_storage_from_hbm(hip, name, F, dbs):
+    """LDPC_F16 + LDPC_SCHED_LAYERED + LDPC_PATH_FLOOD (r03): lam stored in fp16 by the frame-per-workgroup record kernel, f32 arithmetic
+    and records -- against oracle/emulate_f16.py decode_minsum_f16_layered: bits, sweeps, flags and the LLRs a frame stops with, exactly"""
+    from oracle import emulate_f16 as em
+    c = load(name)
+    llr = np.concatenate([c.frames(F // 2, db, 7300 + i)[1] for i, db in enumerate(dbs)]).astype(np.float32)
+    llr[0, :8] = [7e4, -7e4, 1e-9, -1e-9, 0.0, 65504.0, 3.0e-8, -6.0e-8]     # saturation, underflow to zero (hard 0 = False), subnormal
+    dec = hip.Decoder(c.hip_code(hip), "min", "f16", F, schedule="layered", path="flood")
+    assert dec.path == "flood" and "layered_qc_kernel" in dec.kernel_name and "__half" in dec.kernel_name, dec.kernel_name
+    bits, its, conv, lam = dec.decode_batch(llr, 30, want_lam=True)
+    eb, ei, ec, el = em.decode_minsum_f16_layered(c.graph, llr, 30)
+    assert np.array_equal(bits, eb) and np.array_equal(its, ei) and np.array_equal(conv.astype(bool), ec)
+    assert np.array_equal(lam, el.astype(np.float64))
+    assert 0 < conv.sum() < F and len(set(its.tolist())) > 3
+    b16 = dec.decode_batch(em.r16(llr).astype(np.float16), 30)                     # fp16 input buffer: the same decoder
+    assert np.array_equal(b16[0], bits) and np.array_equal(b16[1], its)
+    f32 = hip.Decoder(c.hip_code(hip), "min", "f32", F, schedule="layered", path="flood").decode_batch(llr, 30)
+    both = conv.astype(bool) & f32[2].astype(bool)
+    assert both.sum() >= 0.8 * f32[2].sum() and np.array_equal(bits[both], f32[0][both])   # same codewords as the f32-state kernel
+    with pytest.raises(hip.LdpcError):
+        dec.debug_step(np.zeros((1, c.N)), np.zeros((1, c.N)), np.zeros((1, c.E)))
+    dec.close()

@@ -211,21 +211,32 @@ def test_row_records_equal_per_edge_messages(hip, name, monkeypatch):
         assert ta[1][f] == o["iters"] and np.array_equal(ta[3][f, : o["iters"] + 1], o["trace_lam"])
 
 
-@pytest.mark.parametrize("name,F,dbs", [("jpl.1024.4.5", 40, (2.5, 3.5)), ("jpl.4096.4.5", 12, (2.8, 3.4))])
-def test_fp16_lam_storage_from_hbm(hip, name, F, dbs):
+@pytest.mark.parametrize("name,F,dbs", [("jpl.1024.4.5", 41, (2.5, 3.5)), ("jpl.4096.4.5", 13, (2.8, 3.4))])
+def test_fp16_lam_storage_from_hbm(hip, name, F, dbs, monkeypatch):
     """LDPC_F16 + LDPC_SCHED_LAYERED + LDPC_PATH_FLOOD (r03): lam stored in fp16 by the frame-per-workgroup record kernel, f32 arithmetic
     and records -- against oracle/emulate_f16.py decode_minsum_f16_layered: bits, sweeps, flags and the LLRs a frame stops with, exactly"""
     from oracle import emulate_f16 as em
     c = load(name)
-    llr = np.concatenate([c.frames(F // 2, db, 7300 + i)[1] for i, db in enumerate(dbs)]).astype(np.float32)
+    llr = np.concatenate([c.frames(F // 2 + 1, db, 7300 + i)[1] for i, db in enumerate(dbs)])[:F].astype(np.float32)   # odd batch: the last pair has one frame
+    llr = llr[np.random.default_rng(4).permutation(F)]                        # partners from different Eb/N0 stop at different sweeps
     llr[0, :8] = [7e4, -7e4, 1e-9, -1e-9, 0.0, 65504.0, 3.0e-8, -6.0e-8]     # saturation, underflow to zero (hard 0 = False), subnormal
     dec = hip.Decoder(c.hip_code(hip), "min", "f16", F, schedule="layered", path="flood")
     assert dec.path == "flood" and "layered_qc_kernel" in dec.kernel_name and "__half" in dec.kernel_name, dec.kernel_name
     bits, its, conv, lam = dec.decode_batch(llr, 30, want_lam=True)
+    assert "layered_qc2_kernel" in dec.kernel_name                           # two frames per workgroup, lam cells sharing a dword
     eb, ei, ec, el = em.decode_minsum_f16_layered(c.graph, llr, 30)
     assert np.array_equal(bits, eb) and np.array_equal(its, ei) and np.array_equal(conv.astype(bool), ec)
     assert np.array_equal(lam, el.astype(np.float64))
     assert 0 < conv.sum() < F and len(set(its.tolist())) > 3
+    pairs = its[: F // 2 * 2].reshape(-1, 2)
+    assert (pairs[:, 0] != pairs[:, 1]).any()
+    monkeypatch.setenv("LDPC_LAYERED_F16_PAIRS", "0")                        # the one-frame kernel (2-byte lam accesses): the same decoder
+    one = dec.decode_batch(llr, 30, want_lam=True)
+    monkeypatch.delenv("LDPC_LAYERED_F16_PAIRS")
+    assert all(np.array_equal(x, y) for x, y in zip(one, (bits, its, conv, lam)))
+    for nf in (1, 2, 3):                                                      # small and odd batches
+        b1 = dec.decode_batch(llr[:nf], 30)
+        assert np.array_equal(b1[0], bits[:nf]) and np.array_equal(b1[1], its[:nf])
     b16 = dec.decode_batch(em.r16(llr).astype(np.float16), 30)                     # fp16 input buffer: the same decoder
     assert np.array_equal(b16[0], bits) and np.array_equal(b16[1], its)
     f32 = hip.Decoder(c.hip_code(hip), "min", "f32", F, schedule="layered", path="flood").decode_batch(llr, 30)

@@ -245,3 +245,20 @@ def test_fp16_lam_storage_from_hbm(hip, name, F, dbs, monkeypatch):
     with pytest.raises(hip.LdpcError):
         dec.debug_step(np.zeros((1, c.N)), np.zeros((1, c.N)), np.zeros((1, c.E)))
     dec.close()
+
+
+@pytest.mark.parametrize("name", ["wifi-12x24-sz27", "wimax-12x24-sz96", "dvbs2short-20x45-sz360", "irregular-20x30-sz64"])
+def test_fp16_lam_storage_other_shapes(hip, name):
+    """the two-frames-per-workgroup kernel on circulant sizes that are not powers of two and on rows above weight 8 (its weight-20
+    row instance), against the emulation"""
+    from oracle import emulate_f16 as em
+    c = synthetic(name)
+    F = 9
+    llr = np.concatenate([c.frames(5, db, 7500 + i)[1] for i, db in enumerate((2.5, 5.0) if c.N > 1000 else (4.0, 7.0))])[:F].astype(np.float32)
+    dec = hip.Decoder(c.hip_code(hip), "min", "f16", F, schedule="layered", path="flood")
+    bits, its, conv, lam = dec.decode_batch(llr, 25, want_lam=True)
+    assert "layered_qc2_kernel" in dec.kernel_name, dec.kernel_name
+    eb, ei, ec, el = em.decode_minsum_f16_layered(c.graph, llr, 25)
+    assert np.array_equal(bits, eb) and np.array_equal(its, ei) and np.array_equal(conv.astype(bool), ec), name
+    assert np.array_equal(lam, el.astype(np.float64))
+    dec.close()

@@ -3,7 +3,7 @@
 //
 // Same workgroup as the flooding split kernel (fused_split_body.h): lam in LDS, NP wave groups, messages in registers.  A LAYER = a
 // block row; layers run in order.  Two ways to give the groups work:
-//   * block rows dealt to the groups (plans with NP /= 2, and rows lighter than LAY_SPLIT_MIN_DEG): thread (group, r) = row r of
+//   * block rows dealt to the groups (plans with NP /= 2, and rows lighter than LAY_SPLIT_MIN_DEG = 8): thread (group, r) = row r of
 //     every circulant of its group's block rows; ONE group works per layer (its rows read the lam cells of their columns, apply
 //     the check rule, write lam back -- the rows of a block row touch distinct columns), the others wait at the barrier that
 //     ends the layer;
@@ -79,8 +79,9 @@ __device__ __forceinline__ bool layer_row(char *lds, Row tabrow, uint32_t p4, ui
 #define LAY_ROW_SPLIT 1
 #endif
 #ifndef LAY_SPLIT_MIN_DEG
-#define LAY_SPLIT_MIN_DEG 4    // rows lighter than this stay whole with the group that owns the block row: one barrier instead of two
-                               // (jpl.4096, weight-3 rows split / whole: f32 45.9 / 48.1, f16pk 74.6 / 80.0 Gbit/s at 3 dB -- profiles/r03_layered_rs_ab.txt)
+#define LAY_SPLIT_MIN_DEG 8    // rows lighter than this stay whole with the group that owns the block row: one barrier instead of two
+                               // (jpl.4096, weight-3 rows split / whole: f32 45.9 / 48.1, f16pk 74.6 / 80.0 Gbit/s at 3 dB -- profiles/r03_layered_rs_ab.txt;
+                               //  codes with rows of weight 3..13, thresholds 2..33: 8 is the best or within 2 % of it -- profiles/r03_layered_mindeg_jit.txt)
 #endif
 template <class Plan> struct Halves {
     static constexpr bool split(int br) { return Plan::deg(br) >= LAY_SPLIT_MIN_DEG; }

@@ -457,8 +457,9 @@ const char *choose_plan(const ldpc_code &c, int variant, PlanChoice &p, int kind
     else if (kind == JIT_LAYERED_PK16) est = msgs + 4 * p.dmax + 8;
     // two wave groups: the layered bodies split every row between them (fused_layered_body.h, Halves) -- half the transient
     // registers; the packed kernel then runs best at 4 waves/SIMD with ~10 spilled registers (jpl.4096: 66.8 -> 73.7 Gbit/s at 3 dB)
-    if (p.np == 2 && kind == JIT_LAYERED) est = msgs + p.dmax + (p.dmax + 1) / 2 + 14;
-    if (p.np == 2 && kind == JIT_LAYERED_PK16) est = msgs + 2 * p.dmax + 10;
+    // (rows of weight >= 8 = LAY_SPLIT_MIN_DEG; lighter rows stay whole, and they are what sets dmax only in codes of light rows)
+    if (p.np == 2 && p.dmax >= 8 && kind == JIT_LAYERED) est = msgs + p.dmax + (p.dmax + 1) / 2 + 14;
+    if (p.np == 2 && p.dmax >= 8 && kind == JIT_LAYERED_PK16) est = msgs + 2 * p.dmax + 10;
     int w = est <= 64 ? 8 : est <= 80 ? 6 : est <= 96 ? 5 : est <= 128 ? 4 : est <= 168 ? 3 : 2;
     const int threads = p.np * p.v;
     const int wg_per_cu = (int)std::max<size_t>(1, (160 * 1024) / lds);

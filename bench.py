@@ -436,14 +436,22 @@ def rooflines(args, dec, B, Eg, N, n_tx, k, s_bytes, launches, kernel_ms, turns_
         # layered schedule from HBM: ONE launch is the whole decode of the batch; per sweep every edge reads and writes its
         # lam cell and its message (4E*s), plus the syndrome pass before the first sweep (E*s); priced with the sweeps run
         records = dec.kernel_name.endswith(", true>")   # min-sum rows as {c1, c2, meta} records: 2*s + 4 bytes per ROW instead of s per edge
-        per_sweep = 2 * Eg * s_bytes + (2 * dec.code.M * (2 * s_bytes + 4) if records else 2 * Eg * s_bytes)
-        bytes_timed = turns_timed * per_sweep + frames_timed * Eg * s_bytes
+        on_chip_lam = "layered_lds_kernel" in dec.kernel_name   # r04: lam in LDS (fp16), only the 12-byte row records stream (layered_lds.hip)
+        if on_chip_lam:
+            llr_bytes = s_bytes                      # (dtype f16: the frame source writes fp16 LLRs)
+            per_sweep = 24 * dec.code.M
+            # the first sweep of a frame writes its records without reading any; LLRs read once (twice by a frame out of sweeps), N result bytes
+            bytes_timed = turns_timed * per_sweep - frames_timed * 12 * dec.code.M + frames_timed * (N * llr_bytes + N)
+        else:
+            per_sweep = 2 * Eg * s_bytes + (2 * dec.code.M * (2 * s_bytes + 4) if records else 2 * Eg * s_bytes)
+            bytes_timed = turns_timed * per_sweep + frames_timed * Eg * s_bytes
         ach = bytes_timed / (kernel_ms * 1e-3) / 1e9 if kernel_ms else 0.0
         r = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
              "traffic": traffic, "traffic_source": tsrc and f"{tsrc} (committed PMC pass, not measured in this run)",
              "kernel": dec.kernel_name, "launches": launches, "avg_launch_ms": round(avg_ms, 4),
              "algorithmic_bytes_timed": bytes_timed, "algorithmic_bytes_per_launch": bytes_timed // steps, "frame_sweeps_timed": turns_timed,
-             "bytes_model": ("sum_frames(sweeps_f)*(2E*s + 2M*(2s+4)) + frames*E*s: lam cells read+written per edge, one record per row read+written"
+             "bytes_model": ("sum_frames(sweeps_f)*24M - frames*12M + frames*(N*llr_bytes + N): one 12-byte record per row read+written per sweep (lam stays in LDS as fp16), LLRs in, bits out"
+                             if on_chip_lam else "sum_frames(sweeps_f)*(2E*s + 2M*(2s+4)) + frames*E*s: lam cells read+written per edge, one record per row read+written"
                              if records else "sum_frames(sweeps_f)*4E*s + frames*E*s: lam cells and messages read+written per edge") +
                             " (one launch decodes the batch; state in HBM)"}
         return r, None

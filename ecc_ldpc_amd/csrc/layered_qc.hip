@@ -336,177 +336,6 @@ __global__ __launch_bounds__(1024, (DCLASS <= 8 && sizeof(CT) == 4 ? LQC_WAVES_L
     }
 }
 
-// ==================================================================== fp16 lam, TWO FRAMES PER WORKGROUP (r03)
-// layered_qc_kernel<float, 1, D, true, __half> above moves two bytes per lane and is bound by memory instructions, not bytes
-// (profiles/r03_dvbs2like_layered_f16_minsum_pmc.json: 36 % fewer bytes, 43 % more time).  Here a workgroup decodes frames 2p
-// and 2p + 1 together and their lam cells share a dword (low / high half), as in the packed on-chip kernels: one 4-byte gather
-// and one 4-byte scatter per edge serve both frames, graph indices and addresses are computed once.  Arithmetic (f32), records
-// (per frame, f32) and every rounding are those of the one-frame kernel: same specification (oracle/emulate_f16.py
-// decode_minsum_f16_layered), same results bit for bit.  A frame that has stopped keeps its half of every dword unchanged.
-__device__ __forceinline__ float half_lo(uint32_t w) { return __half2float(__ushort_as_half((unsigned short)(w & 0xffffu))); }
-__device__ __forceinline__ float half_hi(uint32_t w) { return __half2float(__ushort_as_half((unsigned short)(w >> 16))); }
-__device__ __forceinline__ uint32_t half_bits(float v) {   // saturating round to nearest even (Store<__half>::st)
-    __half h;
-    Store<__half>::st(&h, v);
-    return (uint32_t)__half_as_ushort(h);
-}
-
-template <int DMAX, bool FIRST>
-__device__ __forceinline__ void qc_row_rec2(const QcLayerDev &g, uint32_t *__restrict__ lam2, float *const (&rc1)[2], float *const (&rc2)[2], uint32_t *const (&rmeta)[2],
-                                            int e0, int deg, int row, int r, bool live, const bool (&act)[2], bool (&odd)[2], bool (&flip)[2]) {
-    int idx[DMAX];
-    uint32_t w[DMAX];
-#pragma unroll
-    for (int k = 0; k < DMAX; k++) {
-        const int kk = k < deg ? k : 0;
-        const int cb = ((cidx_t)g.tab)[2 * (e0 + kk)], rot = ((cidx_t)g.tab)[2 * (e0 + kk) + 1];
-        int c = r + rot;
-        c -= (c >= g.sz) ? g.sz : 0;
-        idx[k] = cb + c;
-    }
-#pragma unroll
-    for (int k = 0; k < DMAX; k++) w[k] = (live && k < deg) ? lam2[idx[k]] : 0u;
-    uint32_t nw2[DMAX];
-#pragma unroll
-    for (int k = 0; k < DMAX; k++) nw2[k] = w[k];
-#pragma unroll
-    for (int h = 0; h < 2; h++) {
-        if (!act[h]) continue;                      // (workgroup-uniform)
-        float l[DMAX], t[DMAX];
-#pragma unroll
-        for (int k = 0; k < DMAX; k++) l[k] = h ? half_hi(w[k]) : half_lo(w[k]);
-        float c1 = 0.f, c2 = 0.f;
-        uint32_t meta = 0;
-        if constexpr (!FIRST) {
-            if (live) { c1 = rc1[h][row]; c2 = rc2[h][row]; meta = rmeta[h][row]; }
-        }
-        bool par = false;
-#pragma unroll
-        for (int k = 0; k < DMAX; k++) par ^= (k < deg) && hard(l[k]);
-        odd[h] |= par && live;
-        const uint32_t oidx = meta >> 27;
-#pragma unroll
-        for (int k = 0; k < DMAX; k++) {
-            float old = 0.f;
-            if constexpr (!FIRST) { const float mag = ((uint32_t)k == oidx) ? c2 : c1; old = ((meta >> k) & 1u) ? -mag : mag; }
-            t[k] = (k < deg) ? l[k] - old : INFINITY;
-        }
-        float m1 = fabsf(t[0]), m2 = INFINITY;
-        int i1 = 0;
-        unsigned parity = (t[0] > 0.f) ? 1u : 0u;
-#pragma unroll
-        for (int k = 1; k < DMAX; k++) {
-            const float a = fabsf(t[k]);
-            parity ^= (k < deg && t[k] > 0.f) ? 1u : 0u;
-            if (a < m1) { m2 = m1; m1 = a; i1 = k; }
-            else if (a < m2) { m2 = a; }
-        }
-        const float n1 = 0.75f * m1, n2 = 0.75f * m2;
-        uint32_t nsig = 0;
-#pragma unroll
-        for (int k = 0; k < DMAX; k++) {
-            if (k < deg) {
-                const unsigned neg = parity ^ ((t[k] > 0.f) ? 1u : 0u);
-                const float mag = (k == i1) ? n2 : n1;
-                const float nm = neg ? mag : -mag;
-                nsig |= (neg ? 0u : 1u) << k;
-                const uint32_t nb = half_bits(t[k] + nm);
-                const float nw = __half2float(__ushort_as_half((unsigned short)nb));
-                flip[h] |= live && (hard(nw) != hard(l[k]));
-                nw2[k] = h ? ((nw2[k] & 0x0000ffffu) | (nb << 16)) : ((nw2[k] & 0xffff0000u) | nb);
-            }
-        }
-        if (live) { rc1[h][row] = n1; rc2[h][row] = n2; rmeta[h][row] = nsig | ((uint32_t)i1 << 27); }
-    }
-#pragma unroll
-    for (int k = 0; k < DMAX; k++)
-        if (live && k < deg) lam2[idx[k]] = nw2[k];
-}
-
-template <int DCLASS>
-__global__ __launch_bounds__(1024, 4) void layered_qc2_kernel(QcLayerDev g, uint32_t *lam_all, float *msg_all, QcLayerArgs A) {
-    const int r = threadIdx.x;
-    const bool live = r < g.sz;
-    const size_t pair = blockIdx.x;
-    uint32_t *lam2 = lam_all + pair * (size_t)g.N;
-    const int Mrows = g.nbr * g.sz;
-    float *rc1[2], *rc2[2];
-    uint32_t *rmeta[2];
-    bool present[2];
-    size_t fN[2];
-#pragma unroll
-    for (int h = 0; h < 2; h++) {
-        const size_t frame = 2 * pair + h;
-        present[h] = frame < (size_t)A.batch;
-        const size_t f = present[h] ? frame : 2 * pair;          // (an absent partner shadows frame 2p: never stored)
-        float *msg = msg_all + f * (size_t)3 * Mrows;
-        rc1[h] = msg; rc2[h] = msg + Mrows; rmeta[h] = reinterpret_cast<uint32_t *>(msg + 2 * (size_t)Mrows);
-        fN[h] = f * (size_t)g.N;
-    }
-    for (int i = r; i < g.N; i += blockDim.x) {
-        const uint32_t a = half_bits(load_llr<float>(A.llr, fN[0] + i, A.llr_fmt));
-        const uint32_t b = present[1] ? half_bits(load_llr<float>(A.llr, fN[1] + i, A.llr_fmt)) : 0u;
-        lam2[i] = a | (b << 16);
-    }
-    __syncthreads();
-    bool conv[2] = {false, false}, act[2];
-    int ndone[2] = {0, 0};
-    {   // syndrome of the hard decisions before the first sweep, both frames
-        bool odd[2] = {false, false};
-        for (int l = 0; l < g.nbr; l++) {
-            const int e0 = ((cidx_t)g.lbeg)[l], deg = ((cidx_t)g.lbeg)[l + 1] - e0;
-            bool p0 = false, p1 = false;
-            for (int k = 0; k < deg; k++) {
-                const int cb = ((cidx_t)g.tab)[2 * (e0 + k)], rot = ((cidx_t)g.tab)[2 * (e0 + k) + 1];
-                int c = r + rot;
-                c -= (c >= g.sz) ? g.sz : 0;
-                const uint32_t w = live ? lam2[cb + c] : 0u;
-                p0 ^= hard(half_lo(w)); p1 ^= hard(half_hi(w));
-            }
-            odd[0] |= p0 && live; odd[1] |= p1 && live;
-        }
-        const int any0 = __syncthreads_or(odd[0] ? 1 : 0), any1 = __syncthreads_or(odd[1] ? 1 : 0);
-        conv[0] = !any0; conv[1] = !any1;
-    }
-    act[0] = !conv[0]; act[1] = present[1] && !conv[1];
-    for (int n = 1; n <= A.max_iters && (act[0] || act[1]); n++) {
-        bool odd[2] = {false, false}, flip[2] = {false, false};
-        for (int l = 0; l < g.nbr; l++) {
-            const int e0 = ((cidx_t)g.lbeg)[l], deg = ((cidx_t)g.lbeg)[l + 1] - e0;
-            const int row = l * g.sz + r;
-            if (deg > 0) {
-                if (n == 1) {
-                    if (deg <= 8) qc_row_rec2<8, true>(g, lam2, rc1, rc2, rmeta, e0, deg, row, r, live, act, odd, flip);
-                    else if constexpr (DCLASS >= 20) qc_row_rec2<20, true>(g, lam2, rc1, rc2, rmeta, e0, deg, row, r, live, act, odd, flip);
-                } else {
-                    if (deg <= 8) qc_row_rec2<8, false>(g, lam2, rc1, rc2, rmeta, e0, deg, row, r, live, act, odd, flip);
-                    else if constexpr (DCLASS >= 20) qc_row_rec2<20, false>(g, lam2, rc1, rc2, rmeta, e0, deg, row, r, live, act, odd, flip);
-                }
-            }
-            __syncthreads();
-        }
-        const int any0 = __syncthreads_or((odd[0] || flip[0]) ? 1 : 0), any1 = __syncthreads_or((odd[1] || flip[1]) ? 1 : 0);
-        if (act[0] && !any0) { conv[0] = true; ndone[0] = n; act[0] = false; }
-        if (act[1] && !any1) { conv[1] = true; ndone[1] = n; act[1] = false; }
-    }
-    // ---- results: hard(lam) of a frame that stopped by the rule, the channel's decisions (as stored: fp16) otherwise
-#pragma unroll
-    for (int h = 0; h < 2; h++) {
-        if (!present[h]) continue;
-        for (int i = r; i < g.N; i += blockDim.x) {
-            const uint32_t w = lam2[i];
-            const float stored = h ? half_hi(w) : half_lo(w);
-            const float v = conv[h] ? stored : lam_round<__half>(load_llr<float>(A.llr, fN[h] + i, A.llr_fmt));
-            A.bits[fN[h] + i] = v > 0.f ? 1 : 0;
-            if (A.final_lam) A.final_lam[fN[h] + i] = (double)v;
-        }
-        if (r == 0) {
-            if (A.iters) A.iters[2 * pair + h] = conv[h] ? ndone[h] : A.max_iters;
-            if (A.conv) A.conv[2 * pair + h] = conv[h] ? 1 : 0;
-        }
-    }
-}
-
 // ==================================================================== flooding schedule, same mapping
 // The reference's own schedule (Orig.hs:67-98) for QC codes whose frame does not fit on-chip: per turn a check-node pass
 // over the block rows (syndrome of hard(lam) from the gathered values, new messages in place), then a variable-node
@@ -608,6 +437,7 @@ struct LayeredQcState {
     int32_t *d_tab = nullptr;
     int32_t *d_lbeg = nullptr, *d_ctab = nullptr, *d_cbeg = nullptr;
     void *lam = nullptr, *msg = nullptr;
+    LayeredLdsState *lds = nullptr;   // fp16 lam storage and the frame fits LDS: lam on-chip, records streamed (layered_lds.hip); then lam / msg above stay null
     KernelTimer *timer = nullptr;
     LaunchInfo info;
 };
@@ -634,6 +464,7 @@ const char *layered_qc_why_not(const ldpc_code &c, int variant, int dtype, int f
 void layered_qc_destroy(LayeredQcState *s) {
     if (!s) return;
     (void)hipFree(s->d_tab); (void)hipFree(s->d_lbeg); (void)hipFree(s->d_ctab); (void)hipFree(s->d_cbeg); (void)hipFree(s->lam); (void)hipFree(s->msg);
+    layered_lds_destroy(s->lds);
     delete s;
 }
 
@@ -644,6 +475,12 @@ LayeredQcState *layered_qc_create(const ldpc_code &c, int variant, int dtype, in
     if (!s) { set_error(LDPC_ENOMEM, "out of host memory"); return nullptr; }
     try {
         s->variant = variant; s->dtype = dtype; s->max_batch = max_batch; s->max_row_deg = c.max_row_deg; s->flooding = flooding != 0;
+        if (!flooding && layered_lds_why_not(c, variant, dtype) == nullptr) {
+            s->lds = layered_lds_create(c, variant, dtype, max_batch);
+            if (!s->lds) { layered_qc_destroy(s); return nullptr; }
+            s->info = layered_lds_launch_info(*s->lds);
+            return s;
+        }
         std::vector<int32_t> tab;
         std::vector<int32_t> lbeg(1, 0);
         std::vector<std::vector<std::pair<int, int>>> cols((size_t)c.block_cols);   // per block column: (circulant index, rotation), ascending block row
@@ -659,7 +496,7 @@ LayeredQcState *layered_qc_create(const ldpc_code &c, int variant, int dtype, in
         const size_t es = dtype == LDPC_F64 ? 8 : 4;
         hipError_t e = hipMalloc((void **)&s->d_tab, sizeof(int32_t) * std::max<size_t>(tab.size(), 2));
         if (e == hipSuccess) e = hipMalloc((void **)&s->d_lbeg, sizeof(int32_t) * lbeg.size());
-        if (e == hipSuccess) e = hipMalloc(&s->lam, dtype == LDPC_F16 ? (size_t)((max_batch + 1) / 2) * c.N * 4 : (size_t)max_batch * c.N * es);
+        if (e == hipSuccess) e = hipMalloc(&s->lam, dtype == LDPC_F16 ? (size_t)max_batch * c.N * 2 : (size_t)max_batch * c.N * es);
         {
             const char *re = getenv("LDPC_LAYERED_RECORDS");
             s->records = !flooding && variant == LDPC_MINSUM && c.max_row_deg <= 27 && !(re && !strcmp(re, "0"));
@@ -692,7 +529,7 @@ LayeredQcState *layered_qc_create(const ldpc_code &c, int variant, int dtype, in
     } catch (...) { layered_qc_destroy(s); set_error(LDPC_ENOMEM, "out of host memory"); return nullptr; }
 }
 
-void layered_qc_set_timer(LayeredQcState *s, KernelTimer *t) { if (s) s->timer = t; }
+void layered_qc_set_timer(LayeredQcState *s, KernelTimer *t) { if (s) { s->timer = t; layered_lds_set_timer(s->lds, t); } }
 const LaunchInfo &layered_qc_launch_info(const LayeredQcState &s) { return s.info; }
 
 template <typename CT, int VARIANT>
@@ -721,20 +558,6 @@ static int launch(LayeredQcState &s, hipStream_t st, QcLayerArgs &a) {
 static int launch_f16(LayeredQcState &s, hipStream_t st, QcLayerArgs &a) {
     if (a.step_mode) return set_error(LDPC_EUNSUPPORTED, "no teacher-forced step with fp16 lam storage (the record kernel keeps no per-edge messages)");
     const dim3 grid(a.batch), block(s.threads);
-    // two frames per workgroup, their lam cells sharing a dword (rows up to weight 20; no per-sweep trace): LDPC_LAYERED_F16_PAIRS=0 = one frame
-    const char *pz = getenv("LDPC_LAYERED_F16_PAIRS");
-    if (!a.trace && s.max_row_deg <= 20 && !(pz && !strcmp(pz, "0"))) {
-        const dim3 grid2((a.batch + 1) / 2);
-        snprintf(s.info.name, sizeof(s.info.name), "ldpc::layered_qc2_kernel<%d>", s.max_row_deg <= 8 ? 8 : 20);
-        s.info.frames_per_wg = 2;
-        if (s.timer) s.timer->begin(st);
-        if (s.max_row_deg <= 8) hipLaunchKernelGGL((layered_qc2_kernel<8>), grid2, block, 0, st, s.g, (uint32_t *)s.lam, (float *)s.msg, a);
-        else hipLaunchKernelGGL((layered_qc2_kernel<20>), grid2, block, 0, st, s.g, (uint32_t *)s.lam, (float *)s.msg, a);
-        if (s.timer) s.timer->end(st);
-        hipError_t e2 = hipGetLastError();
-        if (e2 != hipSuccess) return set_error(LDPC_EHIP, "layered_qc2 launch: %s", hipGetErrorString(e2));
-        return LDPC_OK;
-    }
     if (s.timer) s.timer->begin(st);
     if (s.max_row_deg <= 8) hipLaunchKernelGGL((layered_qc_kernel<float, LDPC_V_MINSUM, 8, true, __half>), grid, block, 0, st, s.g, (__half *)s.lam, (float *)s.msg, a);
     else if (s.max_row_deg <= 20) hipLaunchKernelGGL((layered_qc_kernel<float, LDPC_V_MINSUM, 20, true, __half>), grid, block, 0, st, s.g, (__half *)s.lam, (float *)s.msg, a);
@@ -756,6 +579,7 @@ int layered_qc_decode(LayeredQcState &s, hipStream_t st, int max_iters, int batc
     QcLayerArgs a{};
     a.llr = d_llr; a.llr_fmt = llr_fmt; a.bits = d_bits; a.iters = d_iters; a.conv = d_conv; a.final_lam = d_final; a.trace = d_trace;
     a.batch = batch; a.max_iters = max_iters;
+    if (s.lds) return layered_lds_decode(*s.lds, st, max_iters, batch, d_llr, llr_fmt, d_bits, d_iters, d_conv, d_final, d_trace);
     return run(s, st, a);
 }
 
@@ -764,6 +588,7 @@ int layered_qc_step(LayeredQcState &s, hipStream_t st, int batch, const double *
     QcLayerArgs a{};
     a.llr = d_orig; a.llr_fmt = LLR_F64; a.batch = batch; a.max_iters = 1; a.step_mode = 1;
     a.st_lam = d_lam; a.st_ne_in = d_ne; a.st_ne_out = d_ne_out; a.st_lam_out = d_lam_out; a.st_syn = d_syn;
+    if (s.lds) return set_error(LDPC_EUNSUPPORTED, "no teacher-forced step with fp16 lam storage (the record kernels keep no per-edge messages)");
     return run(s, st, a);
 }
 

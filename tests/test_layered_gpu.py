@@ -213,52 +213,95 @@ def test_row_records_equal_per_edge_messages(hip, name, monkeypatch):
 
 @pytest.mark.parametrize("name,F,dbs", [("jpl.1024.4.5", 41, (2.5, 3.5)), ("jpl.4096.4.5", 13, (2.8, 3.4))])
 def test_fp16_lam_storage_from_hbm(hip, name, F, dbs, monkeypatch):
-    """LDPC_F16 + LDPC_SCHED_LAYERED + LDPC_PATH_FLOOD (r03): lam stored in fp16 by the frame-per-workgroup record kernel, f32 arithmetic
-    and records -- against oracle/emulate_f16.py decode_minsum_f16_layered: bits, sweeps, flags and the LLRs a frame stops with, exactly"""
+    """LDPC_F16 + LDPC_SCHED_LAYERED + LDPC_PATH_FLOOD: lam stored in fp16, f32 arithmetic and row records -- against
+    oracle/emulate_f16.py decode_minsum_f16_layered: bits, sweeps, flags and the LLRs a frame stops with, exactly.  Two kernels
+    implement it: lam in LDS with the records streamed from HBM (r04, layered_lds.hip: whenever a frame's fp16 LLRs fit the LDS) and
+    lam in HBM too (layered_qc_kernel<..., __half>, LDPC_LAYERED_LDS=0)."""
     from oracle import emulate_f16 as em
     c = load(name)
-    llr = np.concatenate([c.frames(F // 2 + 1, db, 7300 + i)[1] for i, db in enumerate(dbs)])[:F].astype(np.float32)   # odd batch: the last pair has one frame
-    llr = llr[np.random.default_rng(4).permutation(F)]                        # partners from different Eb/N0 stop at different sweeps
+    llr = np.concatenate([c.frames(F // 2 + 1, db, 7300 + i)[1] for i, db in enumerate(dbs)])[:F].astype(np.float32)
+    llr = llr[np.random.default_rng(4).permutation(F)]
     llr[0, :8] = [7e4, -7e4, 1e-9, -1e-9, 0.0, 65504.0, 3.0e-8, -6.0e-8]     # saturation, underflow to zero (hard 0 = False), subnormal
     dec = hip.Decoder(c.hip_code(hip), "min", "f16", F, schedule="layered", path="flood")
-    assert dec.path == "flood" and "layered_qc_kernel" in dec.kernel_name and "__half" in dec.kernel_name, dec.kernel_name
+    assert dec.path == "flood" and "layered_lds_kernel" in dec.kernel_name, dec.kernel_name
     bits, its, conv, lam = dec.decode_batch(llr, 30, want_lam=True)
-    assert "layered_qc2_kernel" in dec.kernel_name                           # two frames per workgroup, lam cells sharing a dword
     eb, ei, ec, el = em.decode_minsum_f16_layered(c.graph, llr, 30)
     assert np.array_equal(bits, eb) and np.array_equal(its, ei) and np.array_equal(conv.astype(bool), ec)
     assert np.array_equal(lam, el.astype(np.float64))
     assert 0 < conv.sum() < F and len(set(its.tolist())) > 3
-    pairs = its[: F // 2 * 2].reshape(-1, 2)
-    assert (pairs[:, 0] != pairs[:, 1]).any()
-    monkeypatch.setenv("LDPC_LAYERED_F16_PAIRS", "0")                        # the one-frame kernel (2-byte lam accesses): the same decoder
-    one = dec.decode_batch(llr, 30, want_lam=True)
-    monkeypatch.delenv("LDPC_LAYERED_F16_PAIRS")
+    monkeypatch.setenv("LDPC_LAYERED_LDS", "0")                               # lam in HBM as well (2-byte accesses): the same decoder
+    hbm = hip.Decoder(c.hip_code(hip), "min", "f16", F, schedule="layered", path="flood")
+    monkeypatch.delenv("LDPC_LAYERED_LDS")
+    assert "layered_qc_kernel" in hbm.kernel_name and "__half" in hbm.kernel_name, hbm.kernel_name
+    one = hbm.decode_batch(llr, 30, want_lam=True)
     assert all(np.array_equal(x, y) for x, y in zip(one, (bits, its, conv, lam)))
-    for nf in (1, 2, 3):                                                      # small and odd batches
+    monkeypatch.setenv("LDPC_LAYERED_LDS_PREFETCH", "0")                      # records loaded where they are used: the same decoder
+    nopf = hip.Decoder(c.hip_code(hip), "min", "f16", F, schedule="layered", path="flood")
+    monkeypatch.delenv("LDPC_LAYERED_LDS_PREFETCH")
+    assert nopf.kernel_name.endswith(", 0>") and dec.kernel_name.endswith(", 4>"), (nopf.kernel_name, dec.kernel_name)
+    assert all(np.array_equal(x, y) for x, y in zip(nopf.decode_batch(llr, 30, want_lam=True), (bits, its, conv, lam)))
+    for nf in (1, 2, 3):                                                      # small batches
         b1 = dec.decode_batch(llr[:nf], 30)
         assert np.array_equal(b1[0], bits[:nf]) and np.array_equal(b1[1], its[:nf])
-    b16 = dec.decode_batch(em.r16(llr).astype(np.float16), 30)                     # fp16 input buffer: the same decoder
+    b16 = dec.decode_batch(em.r16(llr).astype(np.float16), 30)                # fp16 input buffer: the same decoder
     assert np.array_equal(b16[0], bits) and np.array_equal(b16[1], its)
     f32 = hip.Decoder(c.hip_code(hip), "min", "f32", F, schedule="layered", path="flood").decode_batch(llr, 30)
     both = conv.astype(bool) & f32[2].astype(bool)
     assert both.sum() >= 0.8 * f32[2].sum() and np.array_equal(bits[both], f32[0][both])   # same codewords as the f32-state kernel
     with pytest.raises(hip.LdpcError):
         dec.debug_step(np.zeros((1, c.N)), np.zeros((1, c.N)), np.zeros((1, c.E)))
-    dec.close()
+    for d in (dec, hbm, nopf):
+        d.close()
 
 
-@pytest.mark.parametrize("name", ["wifi-12x24-sz27", "wimax-12x24-sz96", "dvbs2short-20x45-sz360", "irregular-20x30-sz64"])
-def test_fp16_lam_storage_other_shapes(hip, name):
-    """the two-frames-per-workgroup kernel on circulant sizes that are not powers of two and on rows above weight 8 (its weight-20
-    row instance), against the emulation"""
+@pytest.mark.parametrize("name", ["wifi-12x24-sz27", "wimax-12x24-sz96", "dvbs2short-20x45-sz360", "irregular-20x30-sz64", "latin-16x16-sz64", "latin-12x9-sz40"])
+def test_fp16_lam_storage_other_shapes(hip, name, monkeypatch):
+    """the lam-in-LDS kernel on circulant sizes that are not powers of two (idle lanes shadow rows of their own wave) and on rows above
+    weight 8 (its padded row instances), with more frames than persistent workgroups would need and a per-sweep trace, against the emulation"""
     from oracle import emulate_f16 as em
     c = synthetic(name)
     F = 9
     llr = np.concatenate([c.frames(5, db, 7500 + i)[1] for i, db in enumerate((2.5, 5.0) if c.N > 1000 else (4.0, 7.0))])[:F].astype(np.float32)
     dec = hip.Decoder(c.hip_code(hip), "min", "f16", F, schedule="layered", path="flood")
     bits, its, conv, lam = dec.decode_batch(llr, 25, want_lam=True)
-    assert "layered_qc2_kernel" in dec.kernel_name, dec.kernel_name
+    assert "layered_lds_kernel" in dec.kernel_name, dec.kernel_name
     eb, ei, ec, el = em.decode_minsum_f16_layered(c.graph, llr, 25)
     assert np.array_equal(bits, eb) and np.array_equal(its, ei) and np.array_equal(conv.astype(bool), ec), name
     assert np.array_equal(lam, el.astype(np.float64))
-    dec.close()
+    monkeypatch.setenv("LDPC_LAYERED_LDS", "0")
+    hbm = hip.Decoder(c.hip_code(hip), "min", "f16", F, schedule="layered", path="flood")
+    monkeypatch.delenv("LDPC_LAYERED_LDS")
+    assert all(np.array_equal(x, y) for x, y in zip(hbm.decode_batch(llr, 25, want_lam=True), (bits, its, conv, lam)))
+    monkeypatch.setenv("LDPC_LAYERED_LDS_GROUPS", "0")                       # one block row at a time: the same results
+    one = hip.Decoder(c.hip_code(hip), "min", "f16", F, schedule="layered", path="flood")
+    monkeypatch.delenv("LDPC_LAYERED_LDS_GROUPS")
+    assert all(np.array_equal(x, y) for x, y in zip(one.decode_batch(llr, 25, want_lam=True), (bits, its, conv, lam)))
+    if name.startswith("latin"):                                              # groups were formed: more threads than one block row has
+        assert dec.kernel_geometry[0] > one.kernel_geometry[0], (dec.kernel_geometry, one.kernel_geometry)
+    dec.close(); hbm.close(); one.close()
+
+
+def test_fp16_lam_on_chip_long_code(hip):
+    """BASELINE.json configs[4] through LDPC_PATH_AUTO: the DVB-S2-shaped n = 64 800 code with fp16 LLR storage takes the lam-in-LDS
+    kernel (130 KB of LDS per frame, one workgroup per CU, more frames than workgroups: the work counter runs) -- bit for bit the
+    emulation, and the same codewords as the f32-state kernel"""
+    from oracle import emulate_f16 as em, channel
+    ecc = hip.ECC(CODES, "ldpc/hip-minsum-layered-f16/dvbs2like.64800.1.2/50", max_batch=600)
+    dec = ecc.decoder
+    assert dec.schedule == "layered" and dec.path == "flood" and "layered_lds_kernel<8, 4>" in dec.kernel_name, dec.kernel_name
+    rp, ci = ecc.code.csr()
+    g = oracle.Graph(rp, ci, ecc.code.N)
+    llr = np.concatenate([channel.frames(np.zeros((3, g.N), np.uint8), db, 32400, 64800, g.N, seed=30 + i) for i, db in enumerate((1.0, 1.5, 2.0))]).astype(np.float32)
+    llr[1, :6] = [7e4, -7e4, 1e-9, -1e-9, 0.0, 65504.0]
+    eb, ei, ec, el = em.decode_minsum_f16_layered(g, llr, 20)
+    # 600 frames (the nine, repeated in a shuffled order): more frames than resident workgroups
+    order = np.random.default_rng(8).integers(0, len(llr), 600)
+    bits, its, conv, lam = dec.decode_batch(llr[order], 20, want_lam=True)
+    assert np.array_equal(bits, eb[order]) and np.array_equal(its, ei[order]) and np.array_equal(conv.astype(bool), ec[order])
+    assert np.array_equal(lam, el[order].astype(np.float64))
+    assert 0 < ec.sum() < len(llr)
+    assert dec.kernel_geometry[0] == 768                                       # two block rows (6 waves each) at a time
+    f32 = hip.Decoder(ecc.code, "min", "f32", 9, schedule="layered").decode_batch(llr, 20)
+    both = ec & f32[2].astype(bool)
+    assert both.any() and np.array_equal(eb[both], f32[0][both])
+    print(f"dvbs2like f16 lam on-chip: sweeps {ei.tolist()} (f32 state {f32[1].tolist()})")

@@ -510,7 +510,9 @@ LayeredLdsState *layered_lds_create(const ldpc_code &c, int variant, int dtype, 
         s->lds = lds_bytes_for(c);
         const char *pe = getenv("LDPC_LAYERED_LDS_PREFETCH");           // =0: records loaded where they are used, one block row at a time (A/B)
         const size_t lds_pipe = s->lds + (size_t)s->nslot * kLtab * 4;  // + the per-slot graph entries
-        s->prefetch = (s->ng >= 4 && lds_pipe <= 160 * 1024 && !(pe && !strcmp(pe, "0"))) ? 4 : 0;
+        // (more groups than records in flight: the record requested for group gi + P -- of the next sweep when that wraps -- must have been
+        //  stored already in this sweep, so gi + P - ng < gi)
+        s->prefetch = (s->ng > 4 && lds_pipe <= 160 * 1024 && !(pe && !strcmp(pe, "0"))) ? 4 : 0;
         if (s->prefetch) s->lds = lds_pipe; else { s->gsz = 1; s->nslot = c.block_rows; }
         const int dclass = c.max_row_deg <= 8 ? 8 : (c.max_row_deg <= 20 ? 20 : 32);
         const void *kern = pick_kernel(dclass, s->prefetch);

@@ -203,17 +203,18 @@ def synthetic(name) -> SyntheticQC:
             if br:
                 off[br, K + br - 1] = 0
         return SyntheticQC(name, sz, off)
-    if name in ("latin-16x16-sz64", "latin-12x9-sz40"):
+    if name in ("latin-24x16-sz64", "latin-18x9-sz40"):
         # block rows in GROUPS whose members share no block column (each group partitions the block columns): what csrc/layered_lds.hip
-        # runs together.  sz64: four groups of four (four waves of one block row each); sz40: four groups of three, idle lanes in every wave
-        Rg, Cs, sz = (4, 4, 64) if name.startswith("latin-16") else (3, 3, 40)
-        nbc = Rg * Cs
-        cls = [lambda c: c // Cs, lambda c: c % Cs, lambda c: (c // Cs + c % Cs) % Rg, lambda c: (c // Cs + 2 * (c % Cs)) % Rg]
-        mask = np.zeros((4 * Rg, nbc), bool)
-        for gi, f in enumerate(cls):
+        # runs together.  sz64: six groups of four (four waves of one block row each); sz40: six groups of three, idle lanes in every wave
+        Rg, Cs, sz = (4, 4, 64) if name.startswith("latin-24") else (3, 3, 40)
+        nbc, NG = Rg * Cs, 6                 # six groups (the pipelined loop wants more groups than it keeps records in flight)
+        rng = np.random.default_rng(22 + sz)
+        mask = np.zeros((NG * Rg, nbc), bool)
+        for gi in range(NG):                 # every group deals the block columns out to its block rows: Cs each, none shared
+            perm = rng.permutation(nbc)
             for c in range(nbc):
-                mask[gi * Rg + f(c) % Rg, c] = True
-        assert all(not (mask[gi * Rg + a] & mask[gi * Rg + b]).any() for gi in range(4) for a in range(Rg) for b in range(a))
+                mask[gi * Rg + perm[c] // Cs, c] = True
+        assert all(not (mask[gi * Rg + a] & mask[gi * Rg + b]).any() for gi in range(NG) for a in range(Rg) for b in range(a))
         return SyntheticQC(name, sz, _random_offsets(mask, sz, 23 + sz), rate=(nbc * sz // 4, nbc * sz))   # (M >= N here: a nominal rate for the channel)
     raise KeyError(name)
 

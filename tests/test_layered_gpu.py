@@ -254,7 +254,7 @@ def test_fp16_lam_storage_from_hbm(hip, name, F, dbs, monkeypatch):
         d.close()
 
 
-@pytest.mark.parametrize("name", ["wifi-12x24-sz27", "wimax-12x24-sz96", "dvbs2short-20x45-sz360", "irregular-20x30-sz64", "latin-16x16-sz64", "latin-12x9-sz40"])
+@pytest.mark.parametrize("name", ["wifi-12x24-sz27", "wimax-12x24-sz96", "dvbs2short-20x45-sz360", "irregular-20x30-sz64", "latin-24x16-sz64", "latin-18x9-sz40"])
 def test_fp16_lam_storage_other_shapes(hip, name, monkeypatch):
     """the lam-in-LDS kernel on circulant sizes that are not powers of two (idle lanes shadow rows of their own wave) and on rows above
     weight 8 (its padded row instances), with more frames than persistent workgroups would need and a per-sweep trace, against the emulation"""

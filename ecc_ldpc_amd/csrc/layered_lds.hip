@@ -220,8 +220,12 @@ __device__ __forceinline__ void load_ltab(uint32_t ltab0, int layer, int &e0, in
 
 // block = ceil(sz / 64) waves, thread r = row r of every block row; grid = resident workgroups (persistent)
 // P = layers of record prefetch (0: the record is loaded where it is used, waits left to the compiler; this instance also writes traces)
+// The pipelined instances must not spill: a scratch access counts in vmcnt like any other and would fall between a record load and its
+// hand-counted wait (ecc_ldpc_amd/build.py refuses a build in which one does).  Rows above weight 8 keep up to 27 addresses, LLRs and
+// differences per lane: those instances are built for at most 512 threads (256 registers per lane).
+constexpr int lds_max_threads(int dclass, int p) { return (p > 0 && dclass > 8) ? 512 : 1024; }
 template <int DCLASS, int P>
-__global__ __launch_bounds__(1024) void layered_lds_kernel(LdsDev g, LdsRec *rec_all, LdsArgs A) {
+__global__ __launch_bounds__(lds_max_threads(DCLASS, P)) void layered_lds_kernel(LdsDev g, LdsRec *rec_all, LdsArgs A) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     _Float16 *lam = reinterpret_cast<_Float16 *>(smem);
     // [0] next frame; [1..3] "sweep n moved" at 1 + n % 3 (cleared by thread 0 two sweeps before its use: every thread has
@@ -339,28 +343,31 @@ __global__ __launch_bounds__(1024) void layered_lds_kernel(LdsDev g, LdsRec *rec
             u32x3 q[P];
 #pragma unroll
             for (int j = 0; j < P; j++) q[j] = u32x3{0u, 0u, 0u};
-            const uint32_t voff = (uint32_t)tin * (uint32_t)sizeof(LdsRec);
-            int gi = 0, e0c, degc, tbc[16];       // gi: the group being run; this wave's slot is gi * gsz + sub
+            static_assert(P % 2 == 0, "the graph entries alternate between two register sets");
+            // byte offsets of this wave's record slots inside the workgroup's area: where group gi stores, where group gi + P loads from
+            const uint32_t gstep = (uint32_t)g.gsz * (uint32_t)TL * (uint32_t)sizeof(LdsRec), gend = gstep * (uint32_t)g.ng;
+            const uint32_t voff = (uint32_t)sub * (uint32_t)TL * (uint32_t)sizeof(LdsRec) + (uint32_t)tin * (uint32_t)sizeof(LdsRec);
+            uint32_t soff = 0, loff = gstep * (uint32_t)P;       // (P < ng)
+            int gi = 0, e0v[2], degv[2], tbv[2][16];             // gi: the group being run; this wave's slot is gi * gsz + sub
             bool odd = false, flip = false;
             n = 1;
-            load_ltab(ltab0, sub, e0c, degc, tbc);
+            load_ltab(ltab0, sub, e0v[0], degv[0], tbv[0]);
             auto group_step = [&](auto J) -> bool {     // -> the frame is finished
-                constexpr int j = decltype(J)::value;
+                constexpr int j = decltype(J)::value, cur = j & 1, nxt = cur ^ 1;
                 LDPC_TURN_LOOP();
                 const int gn = (gi + 1 == g.ng) ? 0 : gi + 1;
-                int e0n = 0, degn = 0, tbn[16];
                 rec_wait<2 * P - 1>(q[j]);
                 LdsRec in;
                 in.c1 = n > 1 ? __uint_as_float(q[j].x) : 0.f; in.c2 = n > 1 ? __uint_as_float(q[j].y) : 0.f; in.meta = n > 1 ? q[j].z : 0u;
-                int gp = gi + P;
-                gp -= gp >= g.ng ? g.ng : 0;
-                rec_load(q[j], voff, wbase + (size_t)(gp * g.gsz + sub) * TL);
+                rec_load(q[j], voff + loff, wbase);
                 LdsRec out = in;
-                const int deg = __builtin_amdgcn_readfirstlane(degc);
-                auto next = [&]() { load_ltab(ltab0, gn * g.gsz + sub, e0n, degn, tbn); };
-                if (deg > 0) lds_layer_at<DCLASS, false>(g, in, out, __builtin_amdgcn_readfirstlane(e0c), deg, tbc, r, rb, rw, odd, flip, next);
+                const int deg = __builtin_amdgcn_readfirstlane(degv[cur]);
+                auto next = [&]() { load_ltab(ltab0, gn * g.gsz + sub, e0v[nxt], degv[nxt], tbv[nxt]); };
+                if (deg > 0) lds_layer_at<DCLASS, false>(g, in, out, __builtin_amdgcn_readfirstlane(e0v[cur]), deg, tbv[cur], r, rb, rw, odd, flip, next);
                 else next();                            // (no block row for this wave in this group: it only keeps the counts)
-                rec_store(u32x3{__float_as_uint(out.c1), __float_as_uint(out.c2), out.meta}, voff, wbase + (size_t)(gi * g.gsz + sub) * TL);
+                rec_store(u32x3{__float_as_uint(out.c1), __float_as_uint(out.c2), out.meta}, voff + soff, wbase);
+                soff += gstep; soff -= soff >= gend ? gend : 0u;
+                loff += gstep; loff -= loff >= gend ? gend : 0u;
                 const bool last = gi == g.ng - 1;
                 if (last && __builtin_amdgcn_ballot_w64(odd || flip) != 0 && (tid & 63) == 0) ctl[1 + n % 3] = 1;
                 lds_barrier();
@@ -370,9 +377,7 @@ __global__ __launch_bounds__(1024) void layered_lds_kernel(LdsDev g, LdsRec *rec
                     else if (n == A.max_iters) fin = true;
                     else { n++; odd = false; flip = false; if (tid == 0) ctl[1 + (n + 1) % 3] = 0; }   // (that flag was last read a sweep ago)
                 }
-                gi = gn; e0c = e0n; degc = degn;
-#pragma unroll
-                for (int i = 0; i < 16; i++) tbc[i] = tbn[i];
+                gi = gn;
                 return fin;
             };
             for (;;) {
@@ -483,7 +488,9 @@ LayeredLdsState *layered_lds_create(const ldpc_code &c, int variant, int dtype, 
         // groups: maximal runs of CONSECUTIVE block rows that pairwise share no block column, up to what 1024 threads hold (and four):
         // the rows of a group touch distinct lam cells, so running them together gives what running them in order gives
         const char *ge = getenv("LDPC_LAYERED_LDS_GROUPS");             // =0: one block row at a time (A/B)
-        const int gcap = (ge && !strcmp(ge, "0")) ? 1 : std::max(1, std::min(4, 1024 / s->threads));
+        const int dclass = c.max_row_deg <= 8 ? 8 : (c.max_row_deg <= 20 ? 20 : 32);
+        const int tmax = lds_max_threads(dclass, 4);                    // what the pipelined instance of this row class is built for
+        const int gcap = (ge && !strcmp(ge, "0")) ? 1 : std::max(1, std::min(4, tmax / s->threads));
         std::vector<std::vector<int>> groups;
         {
             std::vector<char> used((size_t)c.block_cols, 0);
@@ -512,9 +519,8 @@ LayeredLdsState *layered_lds_create(const ldpc_code &c, int variant, int dtype, 
         const size_t lds_pipe = s->lds + (size_t)s->nslot * kLtab * 4;  // + the per-slot graph entries
         // (more groups than records in flight: the record requested for group gi + P -- of the next sweep when that wraps -- must have been
         //  stored already in this sweep, so gi + P - ng < gi)
-        s->prefetch = (s->ng > 4 && lds_pipe <= 160 * 1024 && !(pe && !strcmp(pe, "0"))) ? 4 : 0;
+        s->prefetch = (s->ng > 4 && lds_pipe <= 160 * 1024 && s->threads <= tmax && !(pe && !strcmp(pe, "0"))) ? 4 : 0;
         if (s->prefetch) s->lds = lds_pipe; else { s->gsz = 1; s->nslot = c.block_rows; }
-        const int dclass = c.max_row_deg <= 8 ? 8 : (c.max_row_deg <= 20 ? 20 : 32);
         const void *kern = pick_kernel(dclass, s->prefetch);
         hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->lds);
         if (e == hipSuccess && s->prefetch) e = hipFuncSetAttribute(pick_kernel(dclass, 0), hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->lds);   // (traces)

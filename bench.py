@@ -345,6 +345,7 @@ PROFILE_TAGS = {   # committed rocprofv3 PMC passes (tools/profile.sh): (code, v
     ("jpl.4096.4.5", "minsum", "f16pk", "fused"): ("jpl4096_f16pk_minsum", 65536),
     ("jpl.4096.4.5", "minsum", "f32", "flood_qc"): ("floodqc_jpl4096_f32_minsum", 16384),
     ("dvbs2like.64800.1.2", "minsum", "f32", "layered_qc"): ("dvbs2like_layered_f32_minsum", 32768),
+    ("dvbs2like.64800.1.2", "minsum", "f16", "layered_lds"): ("dvbs2like_layered_f16_minsum", 32768),   # r04: lam on-chip, records streamed
     # the on-chip layered kernels (family "fused_layered": another kernel than the flooding one of the same code and type)
     ("jpl.4096.4.5", "minsum", "f32", "fused_layered"): ("jpl4096_layered_f32_minsum", 65536),
     ("jpl.4096.4.5", "minsum", "f16pk", "fused_layered"): ("jpl4096_layered_f16pk_minsum", 65536),
@@ -358,18 +359,21 @@ def committed_traffic(args, dec, B):
     read from inside the process; this value is therefore NOT measured in this run and says which file it is from.
     (For a kernel with early exit the scaling by frames assumes the profiled Eb/N0.)"""
     kname = dec.kernel_name
-    family = "fused" if dec.path == "fused" else ("flood_qc" if "flood_qc_kernel" in kname else ("layered_qc" if "layered_qc_kernel" in kname else None))
+    family = "fused" if dec.path == "fused" else ("flood_qc" if "flood_qc_kernel" in kname else ("layered_qc" if "layered_qc_kernel" in kname else
+                                                  ("layered_lds" if "layered_lds_kernel" in kname else None)))
     if family == "fused" and args.schedule == "layered":
         family = "fused_layered"
     ent = PROFILE_TAGS.get((args.code, args.variant, args.dtype, family))
     if ent is None:
         return None, None
     tag, frames = ent
-    for rnd in ("r03_final_", "r02_final_", "r01_final_"):
+    for rnd in ("r04_final_", "r04_", "r03_final_", "r02_final_", "r01_final_"):
         path = os.path.join(ROOT, "profiles", rnd + tag + "_pmc.json")
         try:
             prof = json.load(open(path))
             if family in ("flood_qc", "layered_qc") and family.replace("_qc", "_qc_kernel") not in prof["kernel"]:
+                continue
+            if family == "layered_lds" and "layered_lds_kernel" not in prof["kernel"]:
                 continue
             if family == "fused_layered" and "layered" not in prof["kernel"]:
                 continue

@@ -334,6 +334,7 @@ void ldpc_ctx_destroy(ldpc_ctx *ctx) {
     ldpc::flood_graph_release(ctx->flood);
     hipFree(ctx->flood.msg); hipFree(ctx->flood.scratch); hipFree(ctx->flood.lam); hipFree(ctx->flood.orig);
     hipFree(ctx->flood.dev.unsat); hipFree(ctx->flood.dev.iters); hipFree(ctx->flood.dev.conv); hipFree(ctx->flood.dev.done);
+    (void)hipFree(ctx->flood.dev.big); (void)hipFree(ctx->flood.dev.kexp);
     (void)hipFree(ctx->flood.d_layer_ptr);
     for (int i = 1; i < ldpc_ctx::kSlots; i++) if (ctx->pstream[i]) hipStreamSynchronize(ctx->pstream[i]);
     for (int i = 0; i < ldpc_ctx::kSlots; i++) { hipFree(ctx->d_in[i]); hipFree(ctx->d_bits[i]); hipFree(ctx->d_iters[i]); hipFree(ctx->d_conv[i]); hipFree(ctx->d_final[i]); }
@@ -369,7 +370,9 @@ ldpc_ctx *ldpc_ctx_create_cfg(const ldpc_code *code_c, const ldpc_ctx_config *cf
     if (!cfg || cfg->struct_size < offsetof(ldpc_ctx_config, schedule)) { set_error(LDPC_EINVAL, "ldpc_ctx_create_cfg: bad config"); return nullptr; }
     ldpc_code *code = const_cast<ldpc_code *>(code_c);
     const int variant = cfg->variant, dtype = cfg->dtype, max_batch = cfg->max_batch, path = cfg->path;
-    const int schedule = cfg->struct_size >= sizeof(ldpc_ctx_config) ? cfg->schedule : LDPC_SCHED_FLOODING;
+    // every field added after `path` is read when struct_size covers THAT field (a caller built against an older header passes the
+    // size its structure had: 32 bytes with `schedule` as its last member before `sum_order` was added)
+    const int schedule = cfg->struct_size >= offsetof(ldpc_ctx_config, schedule) + sizeof(int) ? cfg->schedule : LDPC_SCHED_FLOODING;
     if (schedule != LDPC_SCHED_FLOODING && schedule != LDPC_SCHED_LAYERED) { set_error(LDPC_EINVAL, "unknown schedule %d", schedule); return nullptr; }
     const int sum_order = cfg->struct_size >= offsetof(ldpc_ctx_config, sum_order) + sizeof(int) ? cfg->sum_order : LDPC_SUM_REFERENCE;
     if (sum_order != LDPC_SUM_REFERENCE && sum_order != LDPC_SUM_ARRAYLET && sum_order != LDPC_SUM_SPARSE) { set_error(LDPC_EINVAL, "unknown sum order %d", sum_order); return nullptr; }
@@ -444,13 +447,19 @@ ldpc_ctx *ldpc_ctx_create_cfg(const ldpc_code *code_c, const ldpc_ctx_config *cf
     d.unsat = nullptr; d.iters = nullptr; d.conv = nullptr; d.done = nullptr;
     d.wide_rows = 0;
     d.cm_order = variant == LDPC_TANH_CM ? LDPC_SUM_ARRAYLET : sum_order;
-    d.saturate = (variant == LDPC_MINSUM && dtype != LDPC_F64) ? 1 : 0;
-    d.pairs4 = (variant == LDPC_TANH && dtype != LDPC_F64 && code->sz == 0 && code->max_row_deg <= 4) ? 1 : 0;
+    d.saturate = (variant == LDPC_MINSUM && dtype == LDPC_F32) ? 1 : 0;   // (fp16 storage saturates at +-65504 by its own rule)
+    d.big = nullptr; d.kexp = nullptr;
+    // ONE predicate for both paths: rows of weight <= 4 take the pair-product form of the tanh rule exactly when the on-chip path of
+    // this code is the generic kernel (whose DMAX = 4 instance is written that way) -- a plain graph, or a QC description the
+    // split family does not take (circulant size below 16, LDPC_JIT=0, ...).  Such a QC code then also runs its flood path on the
+    // batch-major kernels, which know the form; a QC code of the split family uses the chained form everywhere (flood_qc_kernel too).
+    d.pairs4 = (variant == LDPC_TANH && dtype != LDPC_F64 && code->max_row_deg <= 4 &&
+                (code->sz == 0 || ldpc::jit_split_why_not(*code, variant, LDPC_F32) != nullptr)) ? 1 : 0;
     ctx->flood.variant = variant; ctx->flood.dtype = dtype; ctx->flood.timer = &ctx->timer;
     // (the staging buffers of the host-pointer entry points are allocated on first use: a context driven
     //  through ldpc_decode_batch_dev with 65 536 frames would otherwise park 3 GB of HBM)
     const int qc_flooding = schedule == LDPC_SCHED_FLOODING ? 1 : 0;
-    if (ctx->path == LDPC_PATH_FLOOD && sum_order == LDPC_SUM_REFERENCE && ldpc::layered_qc_why_not(*code, variant, dtype, qc_flooding) == nullptr) {
+    if (ctx->path == LDPC_PATH_FLOOD && sum_order == LDPC_SUM_REFERENCE && !(d.pairs4 && qc_flooding) && ldpc::layered_qc_why_not(*code, variant, dtype, qc_flooding) == nullptr) {
         // QC code, either schedule: one workgroup per frame, state in HBM (a frame stops when ITS rule fires);
         // any other H, fp16 storage and the arraylet-cm parity mode: the batch-major kernels below
         ctx->lqc = ldpc::layered_qc_create(*code, variant, dtype, max_batch, qc_flooding);
@@ -475,6 +484,7 @@ ldpc_ctx *ldpc_ctx_create_cfg(const ldpc_code *code_c, const ldpc_ctx_config *cf
         CTX_HIP(hipMalloc((void **)&d.iters, sizeof(int32_t) * Bp));
         CTX_HIP(hipMalloc((void **)&d.conv, Bp));
         CTX_HIP(hipMalloc((void **)&d.done, Bp));
+        if (d.saturate) { CTX_HIP(hipMalloc((void **)&d.big, sizeof(int32_t) * Bp)); CTX_HIP(hipMalloc((void **)&d.kexp, sizeof(int32_t) * Bp)); }
         if (schedule == LDPC_SCHED_LAYERED) {
             ctx->flood.layered = true;
             ctx->flood.n_layers = (int)code->layer_ptr.size() - 1;
@@ -484,6 +494,18 @@ ldpc_ctx *ldpc_ctx_create_cfg(const ldpc_code *code_c, const ldpc_ctx_config *cf
         }
     } else {
         ctx->fused = schedule == LDPC_SCHED_LAYERED ? ldpc::fused_layered_create(*code, variant, dtype, max_batch) : ldpc::fused_create(*code, variant, dtype, max_batch);
+        if (!ctx->fused && schedule == LDPC_SCHED_LAYERED && path == LDPC_PATH_AUTO && dtype != LDPC_F16PK &&
+            ldpc::layered_qc_why_not(*code, variant, dtype, 0) == nullptr) {
+            // the on-chip layered kernel of this code is compiled at run time and that failed (no compiler on this host, or it
+            // rejected the instance): under LDPC_PATH_AUTO the context keeps its state in HBM instead, as fused_create() falls back
+            // to its table-driven kernels for the flooding schedule
+            fprintf(stderr, "libldpc_hip: on-chip layered kernel unavailable (%s); the context runs the layered schedule from HBM\n", ldpc_last_error());
+            ctx->path = LDPC_PATH_FLOOD;
+            ctx->lqc = ldpc::layered_qc_create(*code, variant, dtype, max_batch, 0);
+            if (!ctx->lqc) { ldpc_ctx_destroy(ctx); return nullptr; }
+            ldpc::layered_qc_set_timer(ctx->lqc, &ctx->timer);
+            return ctx;
+        }
         if (!ctx->fused) { ldpc_ctx_destroy(ctx); return nullptr; }
         ldpc::fused_set_timer(ctx->fused, &ctx->timer);
     }

@@ -308,6 +308,9 @@ __global__ __launch_bounds__(256) void flood_vn_kernel(FloodDev d, const ST *__r
         }
     }
     CT acc = Store<ST>::ld(orig + (size_t)col * d.Bp + b);
+    if constexpr (sizeof(ST) == 4) {
+        if (d.saturate) acc = ldexpf(acc, -d.kexp[b]);   // min-sum f32: the frame has been rescaled by 2^-kexp (ldpc_math.h); exact
+    }
     const int qb = d.col_ptr[col], qe = d.col_ptr[col + 1];
     const int deg = qe - qb;   // wave-uniform
     if (d.cm_order) {   // parity modes of the other registered decoders (uniform branch)
@@ -320,9 +323,7 @@ __global__ __launch_bounds__(256) void flood_vn_kernel(FloodDev d, const ST *__r
             for (int q = qb; q < qe; q++) sum = sum + Store<ST>::ld(msg + (size_t)d.csc_edge[q] * d.Bp + b);
             acc = acc + sum;
         }
-        Store<ST>::st(lam + (size_t)col * d.Bp + b, acc);
-        return;
-    }
+    } else
     // Two ways of getting a column's message loads in flight together (a plain loop pays one memory round trip per
     // edge): a function per weight, or predicated loads after clustered index loads.  Measured on one box, jpl.4096,
     // 16 384 frames, whole flood path: f32 1 050 (predicated) vs 990 Mbit/s (per weight), fp16 storage 1 110 vs
@@ -349,8 +350,27 @@ __global__ __launch_bounds__(256) void flood_vn_kernel(FloodDev d, const ST *__r
     } else {
         acc = vn_sum_pred<ST, 8>(d, msg, qe, deg, b, acc);
     }
-    if (d.saturate) acc = sat_lam<CT, LDPC_V_MINSUM>(acc);   // (uniform; min-sum below f64 only: ldpc_math.h)
+    if constexpr (sizeof(ST) == 4) {
+        if (d.saturate && fabsf(acc) > kLamBig) d.big[b] = 1;   // (uniform branch; benign race: every writer stores 1) -> flood_rescale_kernel
+    }
     Store<ST>::st(lam + (size_t)col * d.Bp + b, acc);
+}
+
+// min-sum f32: after a variable-node pass, the frames in which some |lam| passed 2^60 are multiplied by 2^-40 -- lam and
+// every message; the channel LLRs keep their values and enter later column sums through kexp (flood_vn_kernel).  One block per
+// slab of 64 frames, lane = frame; a slab without such a frame costs one load per lane.
+template <typename ST>
+__global__ __launch_bounds__(1024) void flood_rescale_kernel(FloodDev d, ST *__restrict__ msg, ST *__restrict__ lam) {
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const size_t b = (size_t)blockIdx.x * kWave + lane;
+    const bool hit = d.big[b] != 0;
+    if (!__builtin_amdgcn_ballot_w64(hit)) return;       // (the same answer in every wave of the block)
+    if (hit) {
+        for (int e = wave; e < d.E; e += nw) msg[(size_t)e * d.Bp + b] *= (ST)kRescale;
+        for (int c = wave; c < d.N; c += nw) lam[(size_t)c * d.Bp + b] *= (ST)kRescale;
+    }
+    __syncthreads();                                     // every wave has read the flags
+    if (hit && wave == 0) { d.big[b] = 0; d.kexp[b] += kRescaleExp; }
 }
 
 // after the last turn: frames still open get the n = max_iters syndrome verdict (Orig.hs:69-70)
@@ -366,6 +386,7 @@ __global__ void flood_reset_kernel(FloodDev d, int batch) {
     size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= (size_t)d.Bp) return;
     d.unsat[b] = 0;
+    if (d.big) { d.big[b] = 0; d.kexp[b] = 0; }
     d.iters[b] = 0;
     d.conv[b] = 0;
     d.done[b] = (b < (size_t)batch) ? 0 : 1; // padding lanes are born finished
@@ -422,7 +443,7 @@ __global__ __launch_bounds__(256) void store_bits_kernel(FloodDev d, const ST *_
             double v;
             if constexpr (sizeof(ST) == 8) v = tiled[tx][r]; else v = tile[tx][r];
             bits[(size_t)b * d.N + n] = v > 0.0 ? 1 : 0;
-            if (final_lam) final_lam[(size_t)b * d.N + n] = v;
+            if (final_lam) final_lam[(size_t)b * d.N + n] = (d.kexp && d.conv[b]) ? ldexp(v, d.kexp[b]) : v;   // (a rescaled min-sum frame: ldpc_math.h)
         }
     }
 }
@@ -441,7 +462,7 @@ __global__ __launch_bounds__(256) void trace_store_kernel(FloodDev d, const ST *
     __syncthreads();
     for (int r = ty; r < 64; r += 4) {
         int b = b0 + r, col = n0 + tx;
-        if (b < batch && col < d.N && !d.done[b]) trace[((size_t)b * turns + n) * d.N + col] = tile[tx][r];
+        if (b < batch && col < d.N && !d.done[b]) trace[((size_t)b * turns + n) * d.N + col] = d.kexp ? ldexp(tile[tx][r], d.kexp[b]) : tile[tx][r];
     }
 }
 
@@ -739,6 +760,9 @@ static void enqueue_turns(FloodState &s, hipStream_t st, int max_iters, int batc
         if (s.timer) s.timer->end(st);
         if (s.has_wide_rows) hipLaunchKernelGGL((flood_cn_kernel<ST, VARIANT, true>), cn_grid, cn_block, 0, st, d, msg, scr, lam, n + 1, 0, 0);
         hipLaunchKernelGGL((flood_vn_kernel<ST>), vn_grid, vn_block, 0, st, d, msg, orig, lam, n, 0);
+        if constexpr (sizeof(ST) == 4) {
+            if (d.saturate) hipLaunchKernelGGL((flood_rescale_kernel<ST>), dim3(slabs), dim3(1024), 0, st, d, msg, lam);
+        }
     }
     if (d_trace) hipLaunchKernelGGL((trace_store_kernel<ST>), tr_grid, dim3(256), 0, st, d, lam, d_trace, max_iters, max_iters + 1, batch);
     hipLaunchKernelGGL((flood_cn_kernel<ST, VARIANT, false>), cn_grid, cn_block, 0, st, d, msg, scr, lam, max_iters + 1, 1, 0);

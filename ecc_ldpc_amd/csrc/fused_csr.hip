@@ -129,12 +129,16 @@ __global__ __launch_bounds__(THREADS) void fused_csr_kernel(CsrArgs A) {
     bool converged = false;
     int n_done = 0;
     const int turns = A.step_mode ? 1 : A.max_iters;
+    constexpr bool kResc = kRescales<CT, VARIANT>;   // min-sum in f32: the frame is rescaled by 2^-40 when an LLR passes 2^60 (ldpc_math.h)
+    float osc = 1.0f;                                // the factor the channel LLRs enter a column sum with; the frame's LLRs are 2^kexp x lam
+    int kexp = 0;
     for (int n = 0;; n++) {
         if (A.trace) {
             LDPC_COLD_PATH();
-            for (int c = tid; c < N; c += THREADS) A.trace[((size_t)frame * (A.max_iters + 1) + n) * N + c] = (double)lam[c];
+            for (int c = tid; c < N; c += THREADS) A.trace[((size_t)frame * (A.max_iters + 1) + n) * N + c] = ldexp((double)lam[c], kexp);
         }
         const bool last = n >= turns;
+        bool big = false;
         // ---- rows: syndrome + check-node update
         int unsat = 0;
         if constexpr (kCached) {
@@ -161,16 +165,17 @@ __global__ __launch_bounds__(THREADS) void fused_csr_kernel(CsrArgs A) {
             for (int i = 0; i < CPT; i++) {
                 const int c = tid + i * THREADS;
                 if (c < N) {
-                    CT acc = orig[c];
+                    CT acc = kResc ? orig[c] * (CT)osc : orig[c];
 #pragma unroll
                     for (int j = 0; j < kCdMax; j++)
                         if (cslot[i][j] >= 0) acc = msg[cslot[i][j]] + acc;
-                    lam[c] = sat_lam<CT, VARIANT>(acc);
+                    lam[c] = acc;
+                    if constexpr (kResc) big |= fabsf((float)acc) > kLamBig;
                 }
             }
         } else {
             for (int c = tid; c < N; c += THREADS) {
-                CT acc = orig[c];
+                CT acc = kResc ? orig[c] * (CT)osc : orig[c];
                 if (A.cdmax <= kCdMax) {   // slots first, then the message reads, then the sum (descending rows)
                     int slot[kCdMax];
                     CT v[kCdMax];
@@ -196,25 +201,34 @@ __global__ __launch_bounds__(THREADS) void fused_csr_kernel(CsrArgs A) {
                             if (slot[j] >= 0) acc = v[j] + acc;
                     }
                 }
-                lam[c] = sat_lam<CT, VARIANT>(acc);
+                lam[c] = acc;
+                if constexpr (kResc) big |= fabsf((float)acc) > kLamBig;
             }
         }
-        __syncthreads();
+        if constexpr (kResc) {
+            if (__syncthreads_or(big ? 1 : 0)) {     // (also the barrier that ends the turn)
+                LDPC_COLD_PATH();
+                for (int c = tid; c < N; c += THREADS) lam[c] *= (CT)kRescale;
+                for (int e = tid; e < DMAX * M; e += THREADS) msg[e] *= (CT)kRescale;
+                osc *= kRescale; kexp += kRescaleExp;
+                __syncthreads();
+            }
+        } else __syncthreads();
         if (A.step_mode) break;
     }
 
     if (A.step_mode) {
-        for (int c = tid; c < N; c += THREADS) A.final_lam[fN + c] = (double)lam[c];
+        for (int c = tid; c < N; c += THREADS) A.final_lam[fN + c] = ldexp((double)lam[c], kexp);
         for (int m = tid; m < M; m += THREADS) {
             const int e0 = A.row_ptr[m], deg = A.row_ptr[m + 1] - e0;
-            for (int k = 0; k < deg; k++) A.st_ne_out[fE + e0 + k] = (double)msg[k * M + m];
+            for (int k = 0; k < deg; k++) A.st_ne_out[fE + e0 + k] = ldexp((double)msg[k * M + m], kexp);
         }
         return;
     }
     for (int c = tid; c < N; c += THREADS) {
         CT v = converged ? lam[c] : orig[c];
         A.bits[fN + c] = v > CT(0) ? 1 : 0;
-        if (A.final_lam) A.final_lam[fN + c] = (double)v;
+        if (A.final_lam) A.final_lam[fN + c] = converged ? ldexp((double)v, kexp) : (double)v;
     }
     if (tid == 0) {
         if (A.iters) A.iters[frame] = n_done;
@@ -355,14 +369,18 @@ __global__ __launch_bounds__(THREADS, (DMAX <= 8 ? (THREADS > 512 ? 4 : THREADS 
     bool converged = false;
     int n_done = 0;
     const int turns = A.step_mode ? 1 : A.max_iters;
+    constexpr bool kResc = kRescales<CT, VARIANT>;   // min-sum in f32: the frame is rescaled by 2^-40 when an LLR passes 2^60 (ldpc_math.h)
+    float osc = 1.0f;                                // the factor the channel LLRs enter a column sum with; the frame's LLRs are 2^kexp x lam
+    int kexp = 0;
     if constexpr (RP_MEM) load_pack(A.rpack_tab, rpack, std::integral_constant<int, RPT * (DMAX / 2)>{}, std::integral_constant<int, DMAX / 2>{});
     for (int n = 0;; n++) {
         LDPC_TURN_LOOP();
         if (A.trace) {
             LDPC_COLD_PATH();
-            for (int c = tid; c < N; c += THREADS) A.trace[((size_t)frame * (A.max_iters + 1) + n) * N + A.col_of_pos[c]] = (double)lam[c];
+            for (int c = tid; c < N; c += THREADS) A.trace[((size_t)frame * (A.max_iters + 1) + n) * N + A.col_of_pos[c]] = ldexp((double)lam[c], kexp);
         }
         const bool last = n >= turns;
+        bool big = false;
         // ---- rows: every lam gather of the thread first, then syndrome + check-node updates out of registers
         int unsat = 0;
 #pragma unroll
@@ -449,18 +467,32 @@ __global__ __launch_bounds__(THREADS, (DMAX <= 8 ? (THREADS > 512 ? 4 : THREADS 
 #pragma unroll
         for (int i = g; i < g + CG && i < CPT; i++) {
             const int c = tid + i * THREADS;
-            CT acc = oreg[i];
+            CT acc = kResc ? oreg[i] * (CT)osc : oreg[i];
 #pragma unroll
             for (int j = 0; j < CD; j++) acc = v[i - g][j] + acc;   // absent slots add 0 (they follow the present ones)
-            if (c < N) lam[c] = sat_lam<CT, VARIANT>(acc);
+            if (c < N) lam[c] = acc;
+            if constexpr (kResc) big |= c < N && fabsf((float)acc) > kLamBig;
         }
         }
-        __syncthreads();
+        if constexpr (kResc) {
+            if (__syncthreads_or(big ? 1 : 0)) {     // (also the barrier that ends the turn)
+                LDPC_COLD_PATH();
+#pragma unroll
+                for (int i = 0; i < CPT; i++)
+                    if (tid + i * THREADS < N) lam[tid + i * THREADS] *= (CT)kRescale;       // this thread's own columns
+#pragma unroll
+                for (int i = 0; i < RPT; i++)
+#pragma unroll
+                    for (int k = 0; k < DMAX; k++) mreg[i][k] *= (CT)kRescale;               // (their LDS copies are rewritten by the next row phase)
+                osc *= kRescale; kexp += kRescaleExp;
+                __syncthreads();
+            }
+        } else __syncthreads();
         if (A.step_mode) break;
     }
 
     if (A.step_mode) {
-        for (int c = tid; c < N; c += THREADS) A.final_lam[fN + A.col_of_pos[c]] = (double)lam[c];
+        for (int c = tid; c < N; c += THREADS) A.final_lam[fN + A.col_of_pos[c]] = ldexp((double)lam[c], kexp);
 #pragma unroll
         for (int i = 0; i < RPT; i++) {
             const int m = tid + i * THREADS;
@@ -468,7 +500,7 @@ __global__ __launch_bounds__(THREADS, (DMAX <= 8 ? (THREADS > 512 ? 4 : THREADS 
                 const int e0 = A.row_ptr[A.row_of_pos[m]];
 #pragma unroll
                 for (int k = 0; k < DMAX; k++)
-                    if (k < rdeg_of(i)) A.st_ne_out[fE + e0 + k] = (double)mreg[i][k];
+                    if (k < rdeg_of(i)) A.st_ne_out[fE + e0 + k] = ldexp((double)mreg[i][k], kexp);
             }
         }
     } else {
@@ -479,7 +511,7 @@ __global__ __launch_bounds__(THREADS, (DMAX <= 8 ? (THREADS > 512 ? 4 : THREADS 
                 const int col = A.col_of_pos[c];
                 CT vv = converged ? lam[c] : oreg[i];
                 A.bits[fN + col] = vv > CT(0) ? 1 : 0;
-                if (A.final_lam) A.final_lam[fN + col] = (double)vv;
+                if (A.final_lam) A.final_lam[fN + col] = converged ? ldexp((double)vv, kexp) : (double)vv;
             }
         }
         if (tid == 0) {
@@ -501,6 +533,9 @@ struct CsrState {
     // batched kernel: the same tables in POSITION space (conflict-aware placement of rows and columns in LDS)
     int32_t *d_ell_b = nullptr, *d_csc_b = nullptr, *d_row_of_pos = nullptr, *d_col_of_pos = nullptr;
     int *d_counter = nullptr;     // work counter of the persistent batched kernel
+    int resident = 0, resident_dev = -1;   // workgroups of the batched kernel resident at once on resident_dev with resident_lds bytes of LDS
+    size_t resident_lds = 0;
+    const void *resident_kern = nullptr;
     uint32_t *d_cpack = nullptr, *d_rpack = nullptr;  // OSH instance: packed column-slot / row-slot offsets per thread
     KernelTimer *timer = nullptr;
     LaunchInfo info;
@@ -802,17 +837,20 @@ static int launch_csr_batched(CsrState &s, hipStream_t st, CsrArgs &a) {
         s.info.threads = THREADS; s.info.frames_per_wg = 1;
     }
     // persistent workgroups: as many as are resident at once (LDPC_CSR_PERSIST=0: one workgroup per frame)
-    static int resident = 0;
-    if (!resident) {
-        int per_cu = 0, dev = 0;
+    // (kept in the context's state: it depends on this graph's LDS size and on the device the context lives on)
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (!s.resident || s.resident_dev != dev || s.resident_lds != lds || s.resident_kern != (const void *)kern) {
+        int per_cu = 0;
         hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess &&
+        if (hipGetDeviceProperties(&prop, dev) == hipSuccess &&
             hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)kern, THREADS, lds) == hipSuccess && per_cu > 0)
-            resident = per_cu * prop.multiProcessorCount;
-        else { (void)hipGetLastError(); resident = 256 * 2; }
+            s.resident = per_cu * prop.multiProcessorCount;
+        else { (void)hipGetLastError(); s.resident = 256 * 2; }
+        s.resident_dev = dev; s.resident_lds = lds; s.resident_kern = (const void *)kern;
     }
     const char *pz = getenv("LDPC_CSR_PERSIST");
-    const int grid = (pz && !strcmp(pz, "0")) ? a.batch : std::min(a.batch, resident);
+    const int grid = (pz && !strcmp(pz, "0")) ? a.batch : std::min(a.batch, s.resident);
     a.work_counter = nullptr;
     if (grid < a.batch) {
         if (!s.d_counter && hipMalloc((void **)&s.d_counter, sizeof(int)) != hipSuccess) { (void)hipGetLastError(); s.d_counter = nullptr; }

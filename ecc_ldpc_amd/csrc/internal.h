@@ -24,7 +24,7 @@ struct FloodDev {
                              // CachedMult.hs:261-262); 2 orig + sum from 0 (Reference/Sparse.hs:112-114)
     int pairs4;              // tanh rule, f32 arithmetic, a plain-graph code whose heaviest row has weight <= 4: rows use ldpc_math.h
                              // cn_tanh_f32_pairs4, as the on-chip kernels' DMAX = 4 instances do (the paths stay bit-identical)
-    int saturate;            // min-sum below f64: a column's new LLR is kept within +-2^100 (ldpc_math.h sat_lam)
+    int saturate;            // min-sum with f32 state: a frame is rescaled by 2^-40 when an LLR passes 2^60 (ldpc_math.h kRescales; flood_rescale_kernel)
     const int32_t *row_ptr;  // [M+1]
     const int32_t *col_idx;  // [E]   CSR, ascending column inside a row
     const int32_t *col_ptr;  // [N+1]
@@ -33,6 +33,8 @@ struct FloodDev {
     int32_t *iters;          // [Bp]
     uint8_t *conv;           // [Bp]
     uint8_t *done;           // [Bp]
+    int32_t *big;            // [Bp]  (saturate) set by the variable-node pass of a frame that has to be rescaled
+    int32_t *kexp;           // [Bp]  (saturate) the frame's LLRs are 2^kexp x lam
 };
 
 // HIP-event bracket around every launch of a context's dominant kernel (bench.py roofline leg)

@@ -382,7 +382,9 @@ const char *choose_plan(const ldpc_code &c, int variant, PlanChoice &p, int kind
         for (int b : p.bc) hit[b] = 1;
         for (char h : hit) if (!h) return "an empty block column";
     }
-    const size_t lds = (size_t)p.nbc * vpos * 4 + 64;
+    // lam + flags, and for the layered kernels the exchange area of rows split between two wave groups (fused_layered_body.h:
+    // 16 + up to 3 words x 2 groups x VT lanes) and a flag word per wave
+    const size_t lds = (size_t)p.nbc * vpos * 4 + 64 + ((kind == JIT_LAYERED || kind == JIT_LAYERED_PK16) ? 16 + 24 * (size_t)p.v + 4 * 16 : 0);
     if (lds > 160 * 1024) return "a frame's LLRs do not fit in 160 KB of LDS";
     const int cap = variant == LDPC_TANH ? kMsgCapTanh : kMsgCapMinsum;
     const int max_np = std::min(1024 / p.v, p.nbr);

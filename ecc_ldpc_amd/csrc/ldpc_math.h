@@ -113,17 +113,19 @@ template <typename CT> __device__ __forceinline__ CT maybe_round_f16(CT v, int o
 // 3/4 (column weight - 1) per turn -- codes/1920.1280.A (weight 18): x6 per turn measured, 3e9 after 12 turns, past
 // FLT_MAX before turn 50.  The reference's Double never gets there (1e39 after 50 turns); a float does, and then
 // inf - inf = NaN, hard(NaN) = False on every bit, an all-zero "codeword" whose syndrome is zero: a frame the reference
-// reports as failed would come back "converged".  So the kernels that take ANY matrix (fused_csr.hip, flood.hip) keep a
-// column's new LLR within +-2^100 in their f32 / f16-storage min-sum instances: then |t| = |lam - ne| <= 2^101, every
-// message <= 3/4 * 2^101 and a column sum of any weight below 2^20 stays finite.  Nothing changes while |lam| < 2^100
-// (1.3e30); beyond it the float trajectory leaves the Double one, as it would have anyway.  The tanh rule needs none
-// of this (|ne'| <= 37.43, atanh' Utils.hs:113-117), nor does f64 (parity mode: the reference's arithmetic, overflow and all).
-constexpr float kLamSat = 1.2676506002282294e30f;   // 2^100
-template <typename CT, int VARIANT>
-__device__ __forceinline__ CT sat_lam(CT v) {
-    if constexpr (VARIANT == LDPC_V_MINSUM && sizeof(CT) == 4) return __builtin_amdgcn_fmed3f(v, -kLamSat, kLamSat);
-    else return v;
-}
+// reports as failed would come back "converged".  Because the rule is homogeneous -- (lam, ne, orig) -> 2^-k (lam, ne, orig) maps
+// a trajectory onto itself, and a multiplication by a power of two is exact -- the kernels that take ANY matrix (fused_csr.hip,
+// flood.hip) RESCALE a frame instead of clipping it (r04; r03 clipped at +-2^100, which left the float trajectory where the
+// Double one goes on): when a variable-node pass leaves some |lam| above 2^60, the frame's lam and messages are multiplied by
+// 2^-40 and its channel LLRs enter later sums with the accumulated factor.  Hard decisions, syndromes and turn counts are those
+// of a float with unbounded exponent; LLRs are handed out multiplied back (in double).  Only when the CHANNEL term falls below
+// the subnormal range (after ~3 rescalings, LLRs 120 binary orders below the messages they are added to) does anything
+// differ, and then by less than an ulp of any sum it enters.  f32 state only: fp16 storage saturates by its own rule, f64 is the
+// parity mode (the reference's arithmetic, overflow and all), the tanh rule is bounded (|ne'| <= 37.43, Utils.hs:113-117).
+constexpr float kLamBig = 0x1p60f;        // rescale when a column's new LLR passes this ...
+constexpr int kRescaleExp = 40;           // ... by 2^-40
+constexpr float kRescale = 0x1p-40f;
+template <typename CT, int VARIANT> constexpr bool kRescales = (VARIANT == LDPC_V_MINSUM && sizeof(CT) == 4);
 
 // ---------------------------------------------------------------- check-node update, DEG known
 // t[k] = lam_k - ne_k (the reference's list element is -(t[k]) for min-sum and

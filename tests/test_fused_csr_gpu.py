@@ -151,3 +151,32 @@ def test_wide_workgroups_change_nothing_but_speed(hip, monkeypatch):
             outs.append(hip.Decoder(code, variant, "f32", len(llr), path="fused").decode_batch(llr.astype(np.float64), 50, want_lam=True))
     for x, y in ((outs[0], outs[2]), (outs[1], outs[3])):
         assert all(np.array_equal(p, q) for p, q in zip(x, y))
+
+
+def test_tiny_circulant_qc_tanh_paths_agree(hip):
+    """a QC-described code the split family does not take (circulant size 8) with rows of weight <= 4: its on-chip path is the generic
+    kernel, whose weight-4 instance evaluates the tanh rule by pair products -- the flood path of the same code must use that form too
+    (one predicate, api.cc): f32 tanh results identical bit for bit, LLRs included"""
+    from tests.helpers import SyntheticQC
+    rng = np.random.default_rng(31)
+    mask = np.zeros((6, 12), bool)
+    for br in range(6):
+        mask[br, rng.choice(12, 4 if br % 2 else 3, replace=False)] = True
+    for bc in range(12):
+        if not mask[:, bc].any():
+            mask[rng.integers(0, 6), bc] = True
+    mask[mask.sum(1) > 4] = False                       # (keep every row at weight <= 4)
+    for br in range(6):
+        while mask[br].sum() < 2:
+            mask[br, rng.integers(0, 12)] = True
+    off = np.where(mask, rng.integers(0, 8, mask.shape), -1).astype(np.int32)
+    c = SyntheticQC("tiny-6x12-sz8", 8, off, rate=(48, 96))
+    assert c.graph.row_ptr[1:].max() - 0 > 0 and np.diff(c.graph.row_ptr).max() <= 4
+    llr = np.concatenate([c.frames(40, db, 3100 + i)[1] for i, db in enumerate((1.0, 4.0))]).astype(np.float32)
+    fu = hip.Decoder(c.hip_code(hip), "tanh", "f32", len(llr), path="fused")
+    fl = hip.Decoder(c.hip_code(hip), "tanh", "f32", len(llr), path="flood")
+    assert "fused_csr" in fu.kernel_name and "flood_qc_kernel" not in fl.kernel_name, (fu.kernel_name, fl.kernel_name)
+    a, b = fu.decode_batch(llr, 30, want_lam=True), fl.decode_batch(llr, 30, want_lam=True)
+    assert all(np.array_equal(x, y) for x, y in zip(a, b)) and len(set(a[1].tolist())) > 2
+    ob, oi, oc = oracle.decode_batch(c.graph, "tanh", 30, llr.astype(np.float64), nthreads=4)
+    assert np.array_equal(a[0], ob) and np.array_equal(a[2].astype(bool), oc.astype(bool))

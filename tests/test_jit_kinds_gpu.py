@@ -109,3 +109,22 @@ def test_what_has_no_run_time_instance_says_why(hip):
         hip.Decoder(c.hip_code(hip), "tanh", "f32", 4, schedule="layered", path="fused")
     assert e.value.code == -5
     assert hip.Decoder(c.hip_code(hip), "tanh", "f32", 4, schedule="layered").path == "flood"
+
+
+def test_layered_auto_falls_back_to_hbm_when_the_compiler_fails(hip, monkeypatch, capfd):
+    """LDPC_SCHED_LAYERED + LDPC_PATH_AUTO on a code whose on-chip layered kernel is compiled at run time: when that compilation fails
+    the context keeps its state in HBM (the r02 behaviour) instead of failing -- same decoder, other kernel; LDPC_PATH_FUSED still fails"""
+    c = synthetic("ira-12x24-sz64")
+    _, llr = c.frames(12, 2.5, seed=8800)
+    llr = llr.astype(np.float32)
+    ok = hip.Decoder(c.hip_code(hip), "min", "f32", 12, schedule="layered")
+    assert ok.path == "fused"
+    ref = ok.decode_batch(llr, 30)
+    monkeypatch.setenv("LDPC_JIT_EXTRA_OPTS", "--no-such-option-for-the-test")      # (experimental builds are never cached: the compiler runs and fails)
+    dec = hip.Decoder(c.hip_code(hip), "min", "f32", 12, schedule="layered")
+    assert dec.path == "flood" and "layered_qc_kernel" in dec.kernel_name, (dec.path, dec.kernel_name)
+    assert "on-chip layered kernel unavailable" in capfd.readouterr().err
+    assert all(np.array_equal(x, y) for x, y in zip(dec.decode_batch(llr, 30), ref))
+    with pytest.raises(hip.LdpcError):
+        hip.Decoder(c.hip_code(hip), "min", "f32", 12, schedule="layered", path="fused")
+    dec.close(); ok.close()

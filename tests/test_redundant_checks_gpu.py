@@ -1,7 +1,7 @@
 """codes/1920.1280.A: the reference's fourth shipped matrix (= src/1920.1280.A), 5760 redundant checks of rank 1280 over 1920
 bits (row weights 4/6, column weights 14/18, E = 32 000) -- the SAME code as 1920.1280.3.303 seen through six times as many
 checks.  CPU: both loaders against the oracle parser, the rank that gives k = 640.  GPU: every path that takes it against
-the oracle (f64 min-sum trajectories bit-exact, f32 bits/flags, teacher-forced LLRs within 1e-5), the on-chip instance that
+the oracle (f64 min-sum trajectories bit-exact, f32 bits/flags of EVERY frame, teacher-forced LLRs within a backward-stable bound), the on-chip instance that
 holds its 150 KB of state in LDS, the record by name."""
 import os
 
@@ -55,31 +55,31 @@ def test_record_by_name(hip):
 @pytest.mark.gpu
 @pytest.mark.parametrize("variant", ["min", "tanh"])
 def test_every_path_against_the_oracle(hip, variant):
-    """f32 against the Double oracle.  Min-sum on this matrix multiplies the LLRs of an unconverged frame by ~6 per turn
-    (3/4 x 17 other checks per column at most): past turn ~35 they pass 2^100, where the float kernels saturate
-    (ldpc_math.h sat_lam) and the reference's Double does not -- frames the oracle decodes that late are required to come
-    back either identical or as failures carrying the channel's hard decisions, never as a different 'codeword'."""
+    """f32 against the Double oracle, EVERY frame: hard bits, flags, and the turn a frame stops at.  Min-sum on this matrix multiplies
+    the LLRs of an unconverged frame by ~6 per turn (3/4 x 17 other checks per column at most): they would leave the float range
+    before turn 50.  The any-H kernels rescale such a frame by an exact power of two (min-sum is homogeneous: ldpc_math.h
+    kRescales; r03 clipped at 2^100 and lost the frames the reference decodes after turn ~35), so the float trajectory goes on where
+    the Double one does -- including for the frames decoded late, which this batch has."""
     c = load(NAME)
     llr = np.concatenate([c.frames(10, db, 3100)[1] for db in (1.5, 2.5, 3.0)])
     code = c.hip_code(hip)
     ob, oi, oc = oracle.decode_batch(c.graph, variant, 50, llr, nthreads=8)
     assert 0 < oc.sum() < len(llr) and len(set(oi.tolist())) > 3                  # a mixed batch
-    early = (oi <= 35) | ~oc.astype(bool) if variant == "min" else np.ones(len(llr), bool)
-    hard_in = (llr > 0).astype(np.uint8)
+    late = oc.astype(bool) & (oi > 35)
     outs = {}
     for path in ("fused", "flood", "auto"):
         dec = hip.Decoder(code, variant, "f32", len(llr), path=path)
-        outs[path] = dec.decode_batch(llr.astype(np.float32), 50)
+        outs[path] = dec.decode_batch(llr.astype(np.float32), 50, want_lam=True)
         if path == "fused":   # row degree class 6: lam + 6M message cells = 146 KB of LDS, one 1024-thread workgroup per CU
             assert dec.kernel_name in (f"ldpc::fused_csr_batched_kernel<float, {1 if variant == 'min' else 0}, 6, 6, 2, 18, 1024, 2>",
                                        f"ldpc::fused_csr_kernel<float, {1 if variant == 'min' else 0}, 6, 0, 0, 1024>"), dec.kernel_name
         if path == "auto":
-            print(f"{NAME} {variant}: LDPC_PATH_AUTO -> {dec.path} ({dec.kernel_name})")
-        bits, its, conv = outs[path]
-        assert np.array_equal(bits[early], ob[early]) and np.array_equal(conv[early], oc[early]) and (its[early] == oi[early]).mean() >= 0.9, path
-        for f in np.flatnonzero(~early):
-            same = np.array_equal(bits[f], ob[f]) and conv[f] == oc[f]
-            assert same or (not conv[f] and np.array_equal(bits[f], hard_in[f])), (path, f)
+            print(f"{NAME} {variant}: LDPC_PATH_AUTO -> {dec.path} ({dec.kernel_name}); frames the oracle decodes after turn 35: {int(late.sum())}, "
+                  f"largest |LLR| handed back {np.abs(outs[path][3]).max():.3g}")
+        bits, its, conv, lam = outs[path]
+        assert np.array_equal(bits, ob) and np.array_equal(conv.astype(bool), oc.astype(bool)), path
+        assert (its == oi).mean() >= 0.9 and np.abs(its.astype(int) - oi).max() <= 1, (path, its, oi)
+        assert np.isfinite(lam).all()
         dec.close()
     assert all(np.array_equal(x, y) for x, y in zip(outs["fused"], outs["flood"]))   # same arithmetic, same order
     # f64: the state (300 KB) does not fit on-chip -> the HBM path; min-sum trajectory bit-exact
@@ -100,7 +100,10 @@ def test_every_path_against_the_oracle(hip, variant):
 @pytest.mark.gpu
 @pytest.mark.parametrize("variant", ["min", "tanh"])
 @pytest.mark.parametrize("path", ["fused", "flood"])
-def test_teacher_forced_llrs_within_1e5(hip, variant, path):
+def test_teacher_forced_llrs_backward_stable_bound(hip, variant, path):
+    """one update from the oracle's states.  NOT the plain 1e-5 bar: on this matrix a column adds 14 or 18 messages of size ~1e4 that
+    cancel to ~1, and float is exact to 2^-24 of the OPERANDS; the assertion is 1e-5 max(1, |lam|) + 2e-6 x (sum of the magnitudes added),
+    and the error against max(1, |lam|) alone is measured and printed (r03: up to 1.12 for min-sum)"""
     c = load(NAME)
     llr = np.concatenate([c.frames(2, db, 3300 + i)[1] for i, db in enumerate((1.0, 2.5))])
     dec = hip.Decoder(c.hip_code(hip), variant, "f32", 32, path=path)

@@ -176,3 +176,31 @@ def test_native_cli_ranks(hip):
     js = [json.loads(l) for l in p.stdout.splitlines() if l.startswith("{")]
     assert len(js) == 1 and js[0]["ranks"] == 2 and js[0]["tally"] == "host" and len(js[0]["per_rank_seconds"]) == 2
     assert js[0]["frames"] == 20000 and str(js[0]["bit_errors"]) == one[0][4] and js[0]["value"] > 0 and js[0]["unit"] == "Mbit/s"
+
+
+def test_config_of_an_older_header_keeps_its_schedule(hip):
+    """ldpc_ctx_create_cfg with the 32-byte structure of the r02 header (struct_size = 32: no sum_order member) and schedule = LAYERED,
+    as haskell/ECC/Code/LDPC/GPU/HIP.hs of that round passed it (allocaBytes 32): the context must be layered, not silently flooding"""
+    import ctypes as C
+
+    class OldCfg(C.Structure):
+        _fields_ = [("struct_size", C.c_size_t), ("device", C.c_int), ("variant", C.c_int), ("dtype", C.c_int), ("max_batch", C.c_int),
+                    ("path", C.c_int), ("schedule", C.c_int)]
+    assert C.sizeof(OldCfg) == 32
+    L = C.CDLL(hip.SO_PATH)                         # (the same loaded library, with prototypes of this test's own)
+    L.ldpc_ctx_create_cfg.restype = C.c_void_p
+    L.ldpc_ctx_create_cfg.argtypes = [C.c_void_p, C.c_void_p]
+    L.ldpc_ctx_schedule.argtypes = [C.c_void_p]
+    L.ldpc_ctx_destroy.argtypes = [C.c_void_p]
+    L.ldpc_ctx_destroy.restype = None
+    L.ldpc_last_error.restype = C.c_char_p
+    c = load("jpl.1024.4.5").hip_code(hip)
+    cfg = OldCfg(32, -1, 1, 0, 4, 0, 1)            # min-sum, f32, 4 frames, PATH_AUTO, LDPC_SCHED_LAYERED
+    ctx = L.ldpc_ctx_create_cfg(C.c_void_p(c._h), C.byref(cfg))
+    assert ctx, L.ldpc_last_error()
+    assert L.ldpc_ctx_schedule(C.c_void_p(ctx)) == 1
+    L.ldpc_ctx_destroy(C.c_void_p(ctx))
+    cfg28 = OldCfg(28, -1, 1, 0, 4, 0, 1)          # a structure that ends before `schedule`: flooding
+    ctx = L.ldpc_ctx_create_cfg(C.c_void_p(c._h), C.byref(cfg28))
+    assert ctx and L.ldpc_ctx_schedule(C.c_void_p(ctx)) == 0
+    L.ldpc_ctx_destroy(C.c_void_p(ctx))

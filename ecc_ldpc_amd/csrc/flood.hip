@@ -723,9 +723,18 @@ __global__ __launch_bounds__(kWave *kLayerWaves) void layered_kernel(FloodDev d,
         }
         const uint32_t f = combine(odd, flip);
         store_trace(n, open);
+        bool stopped = open && !A.step_mode && f == 0u;
+        if constexpr (kVetoesNonFinite<CT, VARIANT> && sizeof(ST) == 4) {
+            if (__any(stopped)) {   // (the same in every wave) a frame whose LLRs left the float range is failed, not "converged" (ldpc_math.h)
+                bool bad = false;
+                if (stopped)
+                    for (int c = wave; c < d.N; c += kLayerWaves) bad |= not_finite(Store<ST>::ld(lam + (size_t)c * d.Bp + b));
+                if (combine(bad, false) & 1u) { if (stopped) done = true; stopped = false; }
+            }
+        }
         if (open) {
             iters = n;
-            if (!A.step_mode && f == 0u) { done = true; conv = true; }
+            if (stopped) { done = true; conv = true; }
         }
         if (A.step_mode) break;
     }

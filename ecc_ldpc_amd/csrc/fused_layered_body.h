@@ -293,7 +293,19 @@ __device__ __forceinline__ void body(const FusedArgs &A, char *lds, const uint32
         });
         const uint32_t moved = frames_with(any);
         trace_row(n);
-        const uint32_t newly = ~moved & ~done & FULL;
+        uint32_t newly = ~moved & ~done & FULL;
+        if (newly != 0u) {   // (workgroup-uniform, once per frame) LLRs that left the float range: failed, not "converged" (ldpc_math.h)
+            LDPC_COLD_PATH();
+            bool nf = false;
+            if ((newly >> my_slot) & 1u)
+                static_for<0, Plan::NBC>([&](auto bcc) {
+                    constexpr int bc = decltype(bcc)::value;
+                    if constexpr ((bc % Plan::NP) == P) nf |= not_finite(lds_ld<float>(lds, p4 + (bc * V * ES)));
+                });
+            const uint32_t veto = frames_with(nf) & newly;
+            done |= veto;        // stops here as a failure: `res` keeps the channel's hard decisions and a clear flag
+            newly &= ~veto;
+        }
         snapshot(n, newly);
         done |= newly;
         if (A.trace || (newly != 0u && done != FULL)) __syncthreads();

@@ -299,7 +299,36 @@ __device__ __forceinline__ void split_body(const FusedArgs &A, char *lds, const 
             const Where w(p4, A.batch);
             if (w.valid && w.r0 == 0 && P == 0) A.st_syn[w.frame] = ((fbits >> w.sub) & 1u) ? 0 : 1;
         } else {
-            const uint32_t newly = ~fbits & ~done & FULL;  // Orig.hs:69: frames whose syndrome is zero now
+            uint32_t newly = ~fbits & ~done & FULL;  // Orig.hs:69: frames whose syndrome is zero now
+            if constexpr (kVetoesNonFinite<CT, VARIANT>) {
+                if (newly != 0u) {   // (workgroup-uniform, once per frame) LLRs that left the float range: failed, not "converged" (ldpc_math.h)
+                    LDPC_COLD_PATH();
+                    bool nf = false;
+                    if ((newly >> ((p4 / ES) % CPW)) & 1u)
+                        static_for<0, Plan::NBC>([&](auto bcc) {
+                            constexpr int bc = decltype(bcc)::value;
+                            if constexpr ((bc % Plan::NP) == P) nf |= not_finite(lds_ld<CT>(lds, p4 + (bc * V * ES)));
+                        });
+                    __syncthreads();   // every wave has read the syndrome flags
+                    const unsigned long long vb = __ballot(nf);
+                    uint32_t vbits = 0;
+#pragma unroll
+                    for (int s2 = 0; s2 < CPW; s2++) {
+                        unsigned long long m = 0;
+                        for (int i = 0; i < 64; i += CPW) m |= 1ull << i;
+                        vbits |= ((vb & (m << s2)) != 0ull) ? (1u << s2) : 0u;
+                    }
+                    if ((tid & 63) == 0) flags[tid >> 6] = vbits;
+                    __syncthreads();
+                    uint32_t veto = 0;
+#pragma unroll
+                    for (int w = 0; w < NW; w++) veto |= flags[w];
+                    veto = __builtin_amdgcn_readfirstlane(veto) & newly;
+                    __syncthreads();   // (the flags are rewritten by the next turn's syndrome)
+                    done |= veto;      // stops here as a failure: `res` keeps the channel's hard decisions and a clear flag
+                    newly &= ~veto;
+                }
+            }
             if ((newly >> ((p4 / ES) % CPW)) & 1u) {
                 LDPC_COLD_PATH();   // once per frame
                 res.converge_at(n);

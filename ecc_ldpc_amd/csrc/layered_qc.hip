@@ -324,6 +324,13 @@ __global__ __launch_bounds__(1024, (DCLASS <= 8 && sizeof(CT) == 4 ? LQC_WAVES_L
         }
         return;
     }
+    if constexpr (kVetoesNonFinite<CT, VARIANT> && sizeof(LT) == 4) {   // (f32 lam; fp16 lam saturates by its own rule)
+        if (conv) {                                       // (uniform) LLRs that left the float range: failed, not "converged" (ldpc_math.h)
+            bool bad = false;
+            for (int i = r; i < g.N; i += blockDim.x) bad |= not_finite(ldlam<CT>(lam, i));
+            if (__syncthreads_or(bad ? 1 : 0)) conv = false;
+        }
+    }
     // ---- result: hard(lam) of a frame that stopped by the rule, the channel's decisions otherwise (as Orig.hs:69-70)
     for (int i = r; i < g.N; i += blockDim.x) {
         const CT v = conv ? ldlam<CT>(lam, i) : lam_round<LT>(load_llr<CT>(A.llr, fN + i, A.llr_fmt));   // (an LLR counts as stored in LT)
@@ -416,6 +423,13 @@ __global__ __launch_bounds__(1024) void flood_qc_kernel(QcLayerDev g, CT *lam_al
                 for (int k = 0; k < deg; k++) A.st_ne_out[frame * (size_t)g.E + (size_t)e0 * g.sz + (size_t)r * deg + k] = (double)msg[(size_t)(e0 + k) * g.sz + r];
         }
         return;
+    }
+    if constexpr (kVetoesNonFinite<CT, VARIANT>) {
+        if (conv) {                                       // (uniform) LLRs that left the float range: failed, not "converged" (ldpc_math.h)
+            bool bad = false;
+            for (int i = r; i < g.N; i += blockDim.x) bad |= not_finite(lam[i]);
+            if (__syncthreads_or(bad ? 1 : 0)) conv = false;
+        }
     }
     for (int i = r; i < g.N; i += blockDim.x) {
         const CT v = conv ? lam[i] : load_llr<CT>(A.llr, fN + i, A.llr_fmt);

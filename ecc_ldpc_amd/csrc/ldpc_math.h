@@ -126,6 +126,15 @@ constexpr float kLamBig = 0x1p60f;        // rescale when a column's new LLR pas
 constexpr int kRescaleExp = 40;           // ... by 2^-40
 constexpr float kRescale = 0x1p-40f;
 template <typename CT, int VARIANT> constexpr bool kRescales = (VARIANT == LDPC_V_MINSUM && sizeof(CT) == 4);
+// The QUASI-CYCLIC f32 min-sum kernels (split / two-wave / run-time specialised, on-chip and HBM layered, flood_qc_kernel) do not
+// rescale -- on the shipped and synthetic QC shapes |lam| stays at 10-17 for hundreds of turns, and their turn loops have no room for
+// it -- but the failure it prevents must not pass silently there either: a frame whose LLRs left the float range (inf - inf = NaN,
+// hard NaN = False, an all-zero "codeword") is examined when its stop rule fires, once per frame, and any LLR that is not finite turns
+// "converged" into "failed" (the channel's hard decisions, the iteration limit as its count): what the reference reports for a frame
+// it cannot decode, never a codeword it did not find.
+template <typename CT, int VARIANT> constexpr bool kVetoesNonFinite = (VARIANT == LDPC_V_MINSUM && sizeof(CT) == 4);
+__device__ __forceinline__ bool not_finite(float v) { return (__float_as_uint(v) & 0x7f800000u) == 0x7f800000u; }
+__device__ __forceinline__ bool not_finite(double v) { return !(fabs(v) <= 1.7976931348623157e308); }
 
 // ---------------------------------------------------------------- check-node update, DEG known
 // t[k] = lam_k - ne_k (the reference's list element is -(t[k]) for min-sum and

@@ -216,8 +216,20 @@ def synthetic(name) -> SyntheticQC:
                 mask[gi * Rg + perm[c] // Cs, c] = True
         assert all(not (mask[gi * Rg + a] & mask[gi * Rg + b]).any() for gi in range(NG) for a in range(Rg) for b in range(a))
         return SyntheticQC(name, sz, _random_offsets(mask, sz, 23 + sz), rate=(nbc * sz // 4, nbc * sz))   # (M >= N here: a nominal rate for the channel)
+    if name == "heavycol-24x8-sz64":
+        # a QC form of what codes/1920.1280.A is: every check of a (3,6)-regular code (4 x 8 blocks) written SIX times -- block-row
+        # weight 6, block-column weight 18, rank that of the 4 x 8 matrix.  The six copies of a check send the same message, so
+        # flooding min-sum multiplies the LLRs of a frame that does not converge by several units per turn: past FLT_MAX well
+        # before turn 50 -- the overflow case of the QC kernels (tests/test_overflow_gpu.py)
+        base = np.ones((4, 8), bool)
+        for b in range(4):
+            base[b, 2 * b] = base[b, 2 * b + 1] = False
+        off4 = _random_offsets(base, 64, 97)
+        return SyntheticQC(name, 64, np.concatenate([off4] * 6), rate=(256, 512))
     raise KeyError(name)
 
 
+# codes whose run-time specialised kernels __graft_entry__.build() also prepares (name -> [(variant, dtype, schedule)])
+EXTRA_JIT = {"heavycol-24x8-sz64": [("min", "f32", "flooding"), ("min", "f32", "layered")]}
 SYNTHETIC_NAMES = ["jpl4096-permuted", "regular36-sz128", "ira-12x24-sz64", "small-2x4-sz32", "irregular-20x30-sz64", "wide-4x40-sz256",
                    "wimax-12x24-sz96", "wifi-12x24-sz27", "dvbs2short-20x45-sz360"]

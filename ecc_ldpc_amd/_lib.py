@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = (os.environ.get("LDPC_SO") or None) or os.path.join(HERE, "libldpc_hip.so")  # LDPC_SO: ablation builds (tools/)
 
 OK, EINVAL, ENOMEM, EHIP, ENODEVICE, EUNSUPPORTED, EDEGREE, EFORMAT, ENOTFOUND = 0, -1, -2, -3, -4, -5, -6, -7, -8
-TANH, MINSUM, TANH_CM = 0, 1, 2
+TANH, MINSUM, TANH_CM, TANH_CUDA32 = 0, 1, 2, 3
 F32, F64, F16, F16PK = 0, 1, 2, 3
 PATH_AUTO, PATH_FLOOD, PATH_FUSED = 0, 1, 2
 SCHED_FLOODING, SCHED_LAYERED = 0, 1
@@ -303,7 +303,7 @@ def init(device: int = 0):
 
 
 _VARIANTS = {"tanh": TANH, "min": MINSUM, "minsum": MINSUM, "min-sum": MINSUM, "cm": TANH_CM, "tanh-cm": TANH_CM, TANH: TANH, MINSUM: MINSUM,
-             TANH_CM: TANH_CM}
+             TANH_CM: TANH_CM, "cuda32": TANH_CUDA32, "cuda-arraylet2": TANH_CUDA32, TANH_CUDA32: TANH_CUDA32}
 _DTYPES = {"f32": F32, "f64": F64, "f16": F16, "f16pk": F16PK, F32: F32, F64: F64, F16: F16, F16PK: F16PK}
 _PATHS = {"auto": PATH_AUTO, "flood": PATH_FLOOD, "fused": PATH_FUSED, 0: 0, 1: 1, 2: 2}
 _SUM_ORDERS = {"reference": SUM_REFERENCE, "arraylet": SUM_ARRAYLET, "sparse": SUM_SPARSE, 0: 0, 1: 1, 2: 2}

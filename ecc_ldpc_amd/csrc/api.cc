@@ -384,7 +384,12 @@ ldpc_ctx *ldpc_ctx_create_cfg(const ldpc_code *code_c, const ldpc_ctx_config *cf
         set_error(LDPC_EUNSUPPORTED, "LDPC_TANH_CM (arraylet-cm numerics) is a parity mode: f64, flooding schedule, flood path (an f32 kernel is 1e-5 away from either tanh flavour)");
         return nullptr;
     }
-    if (!code || max_batch <= 0 || (variant != LDPC_TANH && variant != LDPC_MINSUM && variant != LDPC_TANH_CM) ||
+    if (variant == LDPC_TANH_CUDA32 && (dtype != LDPC_F32 || schedule != LDPC_SCHED_FLOODING || path == LDPC_PATH_FUSED || sum_order != LDPC_SUM_REFERENCE ||
+                                        (code && code->max_row_deg > 32))) {
+        set_error(LDPC_EUNSUPPORTED, "LDPC_TANH_CUDA32 (cuda-arraylet2 numerics) is a parity mode: f32, flooding schedule, flood path, rows up to weight 32");
+        return nullptr;
+    }
+    if (!code || max_batch <= 0 || (variant != LDPC_TANH && variant != LDPC_MINSUM && variant != LDPC_TANH_CM && variant != LDPC_TANH_CUDA32) ||
         (dtype != LDPC_F32 && dtype != LDPC_F64 && dtype != LDPC_F16 && dtype != LDPC_F16PK) ||
         (path != LDPC_PATH_AUTO && path != LDPC_PATH_FLOOD && path != LDPC_PATH_FUSED)) {
         set_error(LDPC_EINVAL, "ldpc_ctx_create: bad arguments (variant=%d dtype=%d max_batch=%d path=%d)", variant, dtype, max_batch, path);
@@ -416,7 +421,7 @@ ldpc_ctx *ldpc_ctx_create_cfg(const ldpc_code *code_c, const ldpc_ctx_config *cf
         if (code->max_row_deg > 32) { set_error(LDPC_EUNSUPPORTED, "layered schedule: check rows above weight 32 (this code has %d)", code->max_row_deg); return nullptr; }
     }
     const bool fused_ok = layered_fused_ok ||
-                          (schedule == LDPC_SCHED_FLOODING && variant != LDPC_TANH_CM && sum_order == LDPC_SUM_REFERENCE && ldpc::fused_supported(*code, variant, dtype));
+                          (schedule == LDPC_SCHED_FLOODING && variant != LDPC_TANH_CM && variant != LDPC_TANH_CUDA32 && sum_order == LDPC_SUM_REFERENCE && ldpc::fused_supported(*code, variant, dtype));
     if ((path == LDPC_PATH_FUSED || dtype == LDPC_F16PK) && !fused_ok) {
         if (schedule == LDPC_SCHED_LAYERED) { set_error(LDPC_EUNSUPPORTED, "no on-chip kernel for the layered schedule on this code / rule / type (%s); LDPC_PATH_FLOOD keeps the state in HBM", ldpc::fused_layered_why_not(*code, variant, dtype)); return nullptr; }
         set_error(LDPC_EUNSUPPORTED, "no fused kernel for this code/variant/dtype (%s)", ldpc::fused_why_not(*code, variant, dtype));
@@ -446,7 +451,7 @@ ldpc_ctx *ldpc_ctx_create_cfg(const ldpc_code *code_c, const ldpc_ctx_config *cf
     d.row_ptr = tabs.row_ptr; d.col_idx = tabs.col_idx; d.col_ptr = tabs.col_ptr; d.csc_edge = tabs.csc_edge;
     d.unsat = nullptr; d.iters = nullptr; d.conv = nullptr; d.done = nullptr;
     d.wide_rows = 0;
-    d.cm_order = variant == LDPC_TANH_CM ? LDPC_SUM_ARRAYLET : sum_order;
+    d.cm_order = variant == LDPC_TANH_CM ? LDPC_SUM_ARRAYLET : (variant == LDPC_TANH_CUDA32 ? 3 : sum_order);   // (3: ((orig + ne_1) + ne_2) + ..., common.h:161-171)
     d.saturate = (variant == LDPC_MINSUM && dtype == LDPC_F32) ? 1 : 0;   // (fp16 storage saturates at +-65504 by its own rule)
     d.big = nullptr; d.kexp = nullptr;
     // ONE predicate for both paths: rows of weight <= 4 take the pair-product form of the tanh rule exactly when the on-chip path of
@@ -459,7 +464,7 @@ ldpc_ctx *ldpc_ctx_create_cfg(const ldpc_code *code_c, const ldpc_ctx_config *cf
     // (the staging buffers of the host-pointer entry points are allocated on first use: a context driven
     //  through ldpc_decode_batch_dev with 65 536 frames would otherwise park 3 GB of HBM)
     const int qc_flooding = schedule == LDPC_SCHED_FLOODING ? 1 : 0;
-    if (ctx->path == LDPC_PATH_FLOOD && sum_order == LDPC_SUM_REFERENCE && !(d.pairs4 && qc_flooding) && ldpc::layered_qc_why_not(*code, variant, dtype, qc_flooding) == nullptr) {
+    if (ctx->path == LDPC_PATH_FLOOD && sum_order == LDPC_SUM_REFERENCE && variant != LDPC_TANH_CUDA32 && !(d.pairs4 && qc_flooding) && ldpc::layered_qc_why_not(*code, variant, dtype, qc_flooding) == nullptr) {
         // QC code, either schedule: one workgroup per frame, state in HBM (a frame stops when ITS rule fires);
         // any other H, fp16 storage and the arraylet-cm parity mode: the batch-major kernels below
         ctx->lqc = ldpc::layered_qc_create(*code, variant, dtype, max_batch, qc_flooding);

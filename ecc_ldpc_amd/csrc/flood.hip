@@ -51,6 +51,16 @@ __device__ __forceinline__ void cn_row_regs(const FloodDev &d, ST *__restrict__ 
 #pragma unroll
         for (int k = 0; k < DEG; k++) t[k] = Store<ST>::ld(msg + (size_t)(ebeg + k) * d.Bp + b);
     }
+    if constexpr (VARIANT == LDPC_V_TANH_CUDA32) {   // the CUDA plug-in's own arithmetic: lam - ne is formed in double inside (ldpc_math.h)
+#pragma unroll
+        for (int k = 0; k < DEG; k++) par ^= hard(l[k]) ? 1u : 0u;
+        if (par) d.unsat[b] = stamp;
+        if (syndrome_only) return;
+        if constexpr (sizeof(CT) == 4) cn_tanh_cuda32<DEG>(l, t, DEG);
+#pragma unroll
+        for (int k = 0; k < DEG; k++) Store<ST>::st(msg + (size_t)(ebeg + k) * d.Bp + b, t[k]);
+        return;
+    }
 #pragma unroll
     for (int k = 0; k < DEG; k++) {
         par ^= hard(l[k]) ? 1u : 0u;
@@ -92,6 +102,17 @@ __device__ __forceinline__ void cn_row_padded(const FloodDev &d, ST *__restrict_
         for (int k = 0; k < DMAX; k++) t[k] = (k < deg) ? Store<ST>::ld(msg + (size_t)(ebeg + k) * d.Bp + b) : CT(0);
     }
     unsigned par = 0;
+    if constexpr (VARIANT == LDPC_V_TANH_CUDA32) {
+#pragma unroll
+        for (int k = 0; k < DMAX; k++) par ^= (k < deg && hard(l[k])) ? 1u : 0u;
+        if (par) d.unsat[b] = stamp;
+        if (syndrome_only) return;
+        if constexpr (sizeof(CT) == 4) cn_tanh_cuda32<DMAX>(l, t, deg);
+#pragma unroll
+        for (int k = 0; k < DMAX; k++)
+            if (k < deg) Store<ST>::st(msg + (size_t)(ebeg + k) * d.Bp + b, t[k]);
+        return;
+    }
 #pragma unroll
     for (int k = 0; k < DMAX; k++) {
         par ^= (k < deg && hard(l[k])) ? 1u : 0u;
@@ -318,6 +339,8 @@ __global__ __launch_bounds__(256) void flood_vn_kernel(FloodDev d, const ST *__r
             CT sum = Store<ST>::ld(msg + (size_t)d.csc_edge[qe - 1] * d.Bp + b);   // (Fast/Arraylet.hs:105-109,185-186; CachedMult.hs:190-194,261-262)
             for (int q = qe - 2; q >= qb; q--) sum = Store<ST>::ld(msg + (size_t)d.csc_edge[q] * d.Bp + b) + sum;
             acc = acc + sum;
+        } else if (d.cm_order == 3) {       // cuda-arraylet2 (cudabits/common.h:161-171): newLam[i] += ... over ascending block rows, from orig
+            for (int q = qb; q < qe; q++) acc = acc + Store<ST>::ld(msg + (size_t)d.csc_edge[q] * d.Bp + b);
         } else if (deg > 0) {               // sparse, sparsemin: lam' = orig + sum (map snd column), a left fold from 0 over ascending rows
             CT sum = CT(0);                 // (Reference/Sparse.hs:112-114, Data/Sparse/Matrix.hs:35-36)
             for (int q = qb; q < qe; q++) sum = sum + Store<ST>::ld(msg + (size_t)d.csc_edge[q] * d.Bp + b);
@@ -934,6 +957,10 @@ static int layered_step_impl(FloodState &s, hipStream_t st, int batch, const dou
 }
 
 #define DISPATCH(FN, ...)                                                                   \
+    if (s.variant == LDPC_TANH_CUDA32) {                                                    \
+        if (s.dtype == LDPC_F32) return FN<float, LDPC_V_TANH_CUDA32>(__VA_ARGS__);         \
+        return set_error(LDPC_EUNSUPPORTED, "the cuda-arraylet2 numerics exist in f32 only"); \
+    }                                                                                       \
     if (s.variant == LDPC_TANH_CM) {                                                        \
         if (s.dtype == LDPC_F64) return FN<double, LDPC_V_TANH_CM>(__VA_ARGS__);            \
         return set_error(LDPC_EUNSUPPORTED, "the arraylet-cm numerics exist in f64 only");  \

@@ -488,7 +488,9 @@ ldpc_ecc *ldpc_ecc_create_replicas(const char *codes_dir, const char *code_name,
             {"min", "hip-minsum", true, -1, LDPC_SUM_REFERENCE},          {"sparsemin", "hip-minsum", true, -1, LDPC_SUM_SPARSE},
             {"arraylet", "hip-tanh", false, -1, LDPC_SUM_ARRAYLET},      {"arraylet-min", "hip-minsum", false, -1, LDPC_SUM_ARRAYLET},
             {"arraylet-cm", "hip-tanh-cm", false, LDPC_F64, LDPC_SUM_REFERENCE},
-            {"cuda-arraylet1", "hip-tanh", false, -1, LDPC_SUM_REFERENCE}, {"cuda-arraylet2", "hip-tanh", false, -1, LDPC_SUM_REFERENCE},
+            // cuda-arraylet2 (the live GPU decoder) selects ITS arithmetic -- float tanh factors, double product, float atanh_ and clamp,
+            // ascending float column sums (LDPC_TANH_CUDA32, a parity mode on the flood path; `hip-tanh` is the fast decoder)
+            {"cuda-arraylet1", "hip-tanh", false, -1, LDPC_SUM_REFERENCE}, {"cuda-arraylet2", "hip-tanh-cuda32", false, LDPC_F32, LDPC_SUM_REFERENCE},
             {"two-arrays", "hip-tanh", false, -1, LDPC_SUM_REFERENCE},     {"cuda-arraylet-cm", "hip-tanh", false, -1, LDPC_SUM_REFERENCE},
         };
         int sum_order = LDPC_SUM_REFERENCE;
@@ -496,6 +498,7 @@ ldpc_ecc *ldpc_ecc_create_replicas(const char *codes_dir, const char *code_name,
             if (dec == a.ref) { dec = a.hip; as_bool = as_bool || a.as_bool; if (a.dtype >= 0) dtype = a.dtype; if (dtype == LDPC_F64) sum_order = a.sum_order; break; }
         if (dec == "hip-tanh") variant = LDPC_TANH;
         else if (dec == "hip-tanh-cm") variant = LDPC_TANH_CM;   // the reference's `arraylet-cm` numerics (f64 parity mode)
+        else if (dec == "hip-tanh-cuda32") variant = LDPC_TANH_CUDA32;   // the reference's `cuda-arraylet2` numerics (f32 parity mode)
         else if (dec == "hip-minsum") variant = LDPC_MINSUM;
         else { set_error(LDPC_ENOTFOUND, "decoder '%s' is not provided by libldpc_hip (hip-tanh, hip-minsum [-layered][-bool][-f32|-f64|-f16], or a reference name: reference, min, sparse, sparsemin, arraylet, arraylet-min, arraylet-cm, cuda-arraylet1/2)", xs[1].c_str()); return nullptr; }
 

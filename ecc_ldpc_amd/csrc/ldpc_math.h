@@ -47,6 +47,7 @@ namespace ldpc { enum { LLR_F32 = 0, LLR_F64 = 1, LLR_F16 = 2 }; }
 #define LDPC_V_TANH 0
 #define LDPC_V_MINSUM 1
 #define LDPC_V_TANH_CM 2   // the reference's `arraylet-cm` numerics (Fast/CachedMult.hs): f64 only, flood path only
+#define LDPC_V_TANH_CUDA32 3   // the reference's `cuda-arraylet2` numerics (cudabits/arraylet2.cu, common.h): f32 only, flood path only
 
 namespace ldpc {
 
@@ -300,6 +301,32 @@ __device__ __forceinline__ void cn_tanh_f32_pairs4(float (&t)[4], int deg) {
     const uint32_t base = X ^ ((deg & 1) ? 0u : 0x80000000u);
 #pragma unroll
     for (int k = 0; k < 4; k++) t[k] = __uint_as_float(__float_as_uint(mag[k]) | (~(base ^ sg[k]) & 0x80000000u));
+}
+
+// ---------------------------------------------------------------- the reference's CUDA plug-in, operation by operation (parity mode)
+// cudabits/arraylet2.cu:43-83 selfProduct + common.h:82-88 atanh_ (float_ty = float): a factor is the DOUBLE tanh of
+// -((double) lam - (double) ne) / 2 stored as a float; the leave-one-out product runs in a double register over the row in ascending
+// block column; atanh_ takes it as a FLOAT -- the clamp fires when the product ROUNDS to +-1 in float -- and is the float atanh
+// otherwise; the message is -2 x that.  l[k], m[k]: the row's LLRs and old messages; m[k] <- the new message.  Slots k >= deg are not
+// touched (an absent block holds the factor 1 in the reference).  Specification: oracle/ldpc_oracle.c ORACLE_CUDA32 (device tanh /
+// atanhf against the C library's: last ulps, teacher-forced 1e-5).
+template <int DMAX>
+__device__ __forceinline__ void cn_tanh_cuda32(const float (&l)[DMAX], float (&m)[DMAX], int deg) {
+    float th[DMAX];
+#pragma unroll
+    for (int k = 0; k < DMAX; k++) th[k] = k < deg ? (float)tanh(-(((double)l[k] - (double)m[k]) / 2.0)) : 1.0f;
+#pragma unroll
+    for (int k = 0; k < DMAX; k++) {
+        if (k < deg) {
+            double r = 1.0;
+#pragma unroll
+            for (int j = 0; j < DMAX; j++)
+                if (j != k && j < deg) r *= (double)th[j];
+            const float x = (float)r;
+            const float y = (x == 1.0f || x == -1.0f) ? (float)((x < 0.0f ? -1.0 : 1.0) * kAtanhClamp) : atanhf(x);
+            m[k] = -2.0f * y;
+        }
+    }
 }
 
 // ---------------------------------------------------------------- padded rows (generic on-chip kernel)

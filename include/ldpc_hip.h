@@ -51,7 +51,13 @@ typedef struct ldpc_ctx ldpc_ctx;   /* one decoder replica: device buffers + str
  * LDPC_TANH_CM: the tanh rule with the roundings of the reference's `arraylet-cm` decoder (Fast/CachedMult.hs:25-56,
  * 233-264: row product cached as a StableDiv, leave-one-out by division, column sum orig + foldr1 (+)) -- the same real
  * function as LDPC_TANH, ~1e-11 apart in double.  Parity mode only: LDPC_F64, flooding schedule, flood path. */
-typedef enum { LDPC_TANH = 0, LDPC_MINSUM = 1, LDPC_TANH_CM = 2 } ldpc_variant;
+/* LDPC_TANH_CUDA32 (r04): the arithmetic of the reference's LIVE GPU decoder `cuda-arraylet2` (GPU/CUDA/Arraylet2.hs:88-331 driving
+ * cudabits/arraylet2.cu:43-83 selfProduct, common.h:82-88 atanh_, :151-178 updateLam; float_ty = float): float state, factors = the
+ * double tanh stored as floats, the leave-one-out product in a double register, atanh_ on its FLOAT value (so the +-18.71 clamp
+ * fires when the product rounds to +-1 in float, |x| > ~17, where Orig.hs's Double goes on to ~37), column sums
+ * ((orig + ne_1) + ne_2) + ... in float over ascending rows.  In the saturation regime a different function from LDPC_TANH.
+ * Parity mode only: LDPC_F32, flooding schedule, flood path, rows up to weight 32 (checker: oracle "cuda32"). */
+typedef enum { LDPC_TANH = 0, LDPC_MINSUM = 1, LDPC_TANH_CM = 2, LDPC_TANH_CUDA32 = 3 } ldpc_variant;
 /* arithmetic / storage type of LLRs and messages on the device.
  * F32: the cudabits kernels' `typedef float float_ty` (cudabits/common.h:1).
  * F64: parity mode, same type as the CPU reference (Double).

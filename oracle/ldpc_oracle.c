@@ -45,6 +45,20 @@
 #define ORACLE_TANH 0
 #define ORACLE_MINSUM 1
 #define ORACLE_TANH_CM 2 /* the reference's `arraylet-cm` numerics (Fast/CachedMult.hs), sparse form only */
+/* The arithmetic of the reference's LIVE GPU decoder, `cuda-arraylet2` (GPU/CUDA/Arraylet2.hs:88-331 driving
+ * cudabits/arraylet2.cu:43-83 selfProduct and cudabits/common.h:82-88 atanh_, :151-178 updateLam; float_ty = float, common.h:1) --
+ * not the Double arithmetic of Orig.hs, in the saturation regime a different function (r04, sparse form only):
+ *   channel LLRs, lam and messages are FLOATS (Arraylet2.hs:153 double2Float);
+ *   a factor is  (float) tanh(-((double) lam - (double) ne) / 2)   (arraylet2.cu:51,56: v is a double, so the tanh is the double one,
+ *       its result stored into the float array smem);
+ *   the leave-one-out product runs in a DOUBLE register over the row's blocks in ascending block column (:73-79; an absent block
+ *       holds 1);
+ *   atanh_ takes it as a FLOAT (common.h:82): the clamp +-18.714973875118524 (rounded to float) fires when the product ROUNDS to +-1
+ *       in float -- far earlier than a Double product does -- and otherwise it is the float atanh (CUDA's atanhf there, the C
+ *       library's here: last ulps); the message is -2 * that, a float;
+ *   a column is  ((orig + ne_1) + ne_2) + ...  in float, ascending block row (common.h:161-171, after copyArray orig -> lam,
+ *       Arraylet2.hs:239);  hard and the loop are the reference's (parity check each turn: :176-196, out of turns -> orig: :165). */
+#define ORACLE_CUDA32 3
 /* The other registered decoders compute the SAME check rule as Orig.hs / Min.hs (product / foldr1 min' over the row in ascending
  * column) but add a column up in their own order -- only the last ulps of a Double differ:
  *   arraylet, arraylet-min (Fast/Arraylet.hs:185-186, Fast/ArrayletMin.hs:191-192):
@@ -209,6 +223,22 @@ static int step_sparse(const graph_t *g, int variant_and_order, const double *or
                 for (int j = 0; j < d; j++) if (j != k) prod = prod * tbuf[j];
                 ne2[b + k] = -2.0 * atanh_clamped(prod);
             }
+        } else if (variant == ORACLE_CUDA32) {
+            float fbuf[4096];
+            for (int k = 0; k < d; k++) {
+                const double v = (double)(float)ne[b + k];                                         /* arraylet2.cu:51 double v = mLet[...] */
+                fbuf[k] = (float)tanh(-(((double)(float)lam[g->col_idx[b + k]] - v) / 2));          /* :56 */
+            }
+            for (int k = 0; k < d; k++) {
+                double r = 1;                                                                      /* :49 */
+                for (int j = 0; j < k; j++) r *= fbuf[j];                                          /* :73-75 */
+                for (int j = k + 1; j < d; j++) r *= fbuf[j];                                      /* :77-79 */
+                const float x = (float)r;                                                          /* atanh_(float_ty x), common.h:82 */
+                float y;
+                if (x == 1 || x == -1) y = (float)((x < 0 ? -1.0f : (x > 0 ? 1.0f : 0.0f)) * 18.714973875118524);   /* :83-85 */
+                else y = atanhf(x);                                                                /* :87 */
+                ne2[b + k] = (double)(-2 * y);                                                     /* arraylet2.cu:81 */
+            }
         } else if (variant == ORACLE_TANH_CM) {
             /* CachedMult.hs:247-259: ne_tanh'mat, then per row  foldr1 smult [lit x | ascending block column]
              * (foldColsMatrixletU, :184-188), then ne' = -2 * atanh' (S `sdiv` x) */
@@ -251,6 +281,12 @@ static int step_sparse(const graph_t *g, int variant_and_order, const double *or
             double acc = ne2[g->csc_edge[q1 - 1]];
             for (int q = q1 - 2; q >= q0; q--) acc = ne2[g->csc_edge[q]] + acc;
             lam2[j] = orig[j] + acc;
+            continue;
+        }
+        if (variant == ORACLE_CUDA32) {            /* common.h:161-171: newLam[i] += newMLet[...] over ascending block rows, in float */
+            float acc = (float)orig[j];
+            for (int q = q0; q < q1; q++) acc = acc + (float)ne2[g->csc_edge[q]];
+            lam2[j] = (double)acc;
             continue;
         }
         if (sum_order == ORACLE_SUM_ARRAYLET) {   /* orig + foldr1 (+): as the arraylet-cm decoder above */

@@ -317,3 +317,77 @@ def ldpc_sparse(H: np.ndarray, variant: str, max_iterations: int, orig_lam, trac
                 s = s + ne2[(m, j)]
             lam2.append(orig[j] + s)
         ne, lam, n = ne2, lam2, n + 1
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The reference's LIVE GPU decoder `cuda-arraylet2`, kernel by kernel, thread by thread (GPU/CUDA/Arraylet2.hs:153-279 driving
+# cudabits/arraylet2.cu:43-83 and cudabits/common.h:82-97,151-247; float_ty = float).  A literal walk over its arrays -- mLet
+# [rowCount][colCount] floats, lam [colCount * sz] floats -- with numpy float32 / float64 scalars standing for the C types.
+def _libm_atanhf():
+    import ctypes
+    import ctypes.util
+    fn = ctypes.CDLL(ctypes.util.find_library("m") or "libm.so.6").atanhf
+    fn.restype, fn.argtypes = ctypes.c_float, [ctypes.c_float]
+    return fn
+
+
+def ldpc_cuda_arraylet2(sz: int, offsets: np.ndarray, max_iterations: int, orig_lam, trace=None):
+    f32, f64 = np.float32, np.float64
+    atanhf = _libm_atanhf()                              # the C library's float atanh, as ldpc_oracle.c calls it (CUDA's differs in last ulps)
+    R, colCount = offsets.shape
+    rowCount = R * sz
+    orig = [f32(v) for v in orig_lam]                   # Arraylet2.hs:153 double2Float
+    lam = list(orig)                                    # :160 poke orig_lam -> lam_dev
+    mLet = [[f32(0)] * colCount for _ in range(rowCount)]   # :166 memset 0
+
+    def lamIndex(i, j):                                 # common.h:90-98
+        off = int(offsets[j // sz, i])
+        return i * sz + (off + j) % sz if off > -1 else -1
+
+    def atanh_(x):                                      # common.h:82-88 (x: float)
+        x = f32(x)
+        if x == 1 or x == -1:
+            return f32(f64(-1 if x < 0 else 1) * f64(18.714973875118524))
+        return f32(atanhf(float(x)))                    # float atanh
+
+    iters = 0
+    while True:
+        if trace is not None:
+            trace.append([float(v) for v in lam])
+        if iters >= max_iterations:                     # Arraylet2.hs:165
+            return np.array([v > 0 for v in orig], np.uint8), iters, False
+        done = 0                                        # parityRowResults, common.h:212-233
+        for j in range(rowCount):
+            count = sum(1 for i in range(colCount) if lamIndex(i, j) > -1 and lam[lamIndex(i, j)] > 0)
+            if count % 2 == 1:
+                done = 1
+        if not done:                                    # Arraylet2.hs:198 `when parity`: otherwise the result is lam
+            return np.array([v > 0 for v in lam], np.uint8), iters, True
+        newMLet = [[f32(0)] * colCount for _ in range(rowCount)]
+        for j in range(rowCount):                       # selfProduct, arraylet2.cu:43-83: one thread per (i, j)
+            smem = [f32(1)] * colCount
+            for i in range(colCount):
+                v = f64(mLet[j][i])                     # :51 double v
+                ix = lamIndex(i, j)
+                if ix > -1:
+                    smem[i] = f32(math.tanh(-((float(lam[ix]) - float(v)) / 2.0)))   # :56: float - double -> double tanh (libm), stored as float
+            for i in range(colCount):
+                if lamIndex(i, j) > -1:
+                    r = f64(1)                          # :49
+                    for k in range(0, i):
+                        r = r * f64(smem[k])            # :73-75
+                    for k in range(i + 1, colCount):
+                        r = r * f64(smem[k])            # :77-79
+                    newMLet[j][i] = f32(-2) * atanh_(r)  # :81
+        lam = list(orig)                                # Arraylet2.hs:239 copyArray orig_lam_dev lam_dev
+        mLet = newMLet                                  # :241 swapRefs
+        for i in range(colCount * sz):                  # updateLam, common.h:151-172
+            blockI = i // sz
+            for j in range(rowCount // sz):
+                if int(offsets[j, blockI]) < 0:         # (:161-167: the guard the C intends -- with off = sz - (-1) its `off > -1` is always true
+                    continue                            #  and an absent block adds the 0 that selfProduct left there: same value)
+                off = sz - int(offsets[j, blockI])
+                localR = (i + off) % sz
+                r = j * sz + localR
+                lam[i] = f32(lam[i] + mLet[r][blockI])
+        iters += 1

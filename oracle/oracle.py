@@ -11,6 +11,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "_build", "libldpc_oracle.so")
 TANH, MINSUM, TANH_CM = 0, 1, 2
+CUDA32 = 3   # the arithmetic of the reference's CUDA plug-in `cuda-arraylet2` (ldpc_oracle.c ORACLE_CUDA32): float state, double products
 SUM_ARRAYLET, SUM_SPARSE = 16, 32   # column-sum orders of the other registered decoders (ldpc_oracle.c)
 _lib = None
 
@@ -54,6 +55,8 @@ def _variant(v):
         return MINSUM
     if v in (TANH_CM, "cm", "tanh-cm", "arraylet-cm"):
         return TANH_CM
+    if v in (CUDA32, "cuda32", "cuda-arraylet2"):
+        return CUDA32
     # the other registered decoders: the same check rule, their own column-sum order (ldpc_oracle.c ORACLE_SUM_*)
     if v == "arraylet":
         return TANH | SUM_ARRAYLET
@@ -83,9 +86,17 @@ class Graph:
         return cls(rp, ci, H.shape[1])
 
 
+def _as_the_variant_stores(a, variant):
+    """float64 array of the values the decoder holds: CUDA32 keeps channel LLRs, LLRs and messages as floats (Arraylet2.hs:153 double2Float)"""
+    a = np.asarray(a, dtype=np.float64)
+    if _variant(variant) == CUDA32:
+        a = a.astype(np.float32).astype(np.float64)
+    return np.ascontiguousarray(a)
+
+
 def decode(g: Graph, variant, max_iters, llr, trace=False):
     """-> dict(bits, iters, converged, lam[, trace_lam (iters+1,N), trace_ne (iters,E)])"""
-    llr = np.ascontiguousarray(llr, dtype=np.float64)
+    llr = _as_the_variant_stores(llr, variant)
     assert llr.shape == (g.N,)
     bits = np.zeros(g.N, np.uint8)
     it, cv = C.c_int(0), C.c_int(0)
@@ -170,9 +181,9 @@ def decode_dense(H, variant, max_iters, llr, trace=False):
 
 
 def step(g: Graph, variant, orig, lam, ne):
-    orig = np.ascontiguousarray(orig, np.float64)
-    lam = np.ascontiguousarray(lam, np.float64)
-    ne = np.ascontiguousarray(ne, np.float64)
+    orig = _as_the_variant_stores(orig, variant)
+    lam = _as_the_variant_stores(lam, variant)
+    ne = _as_the_variant_stores(ne, variant)
     ne2 = np.zeros(g.E, np.float64)
     lam2 = np.zeros(g.N, np.float64)
     sz = C.c_int(0)
@@ -185,7 +196,7 @@ def step(g: Graph, variant, orig, lam, ne):
 
 
 def decode_batch(g: Graph, variant, max_iters, llr, nthreads=1):
-    llr = np.ascontiguousarray(llr, dtype=np.float64)
+    llr = _as_the_variant_stores(llr, variant)
     F = llr.shape[0]
     assert llr.shape == (F, g.N)
     bits = np.zeros((F, g.N), np.uint8)

@@ -33,7 +33,7 @@ ABI_SYMBOLS = [
     "ldpc_code_create_qc", "ldpc_code_create_csr", "ldpc_code_destroy", "ldpc_code_dims", "ldpc_code_csr",
     "ldpc_ctx_create", "ldpc_ctx_create_ex", "ldpc_ctx_destroy", "ldpc_ctx_path", "ldpc_ctx_synchronize",
     "ldpc_decode_one", "ldpc_decode_batch", "ldpc_decode_batch_f64", "ldpc_decode_batch_dev",
-    "ldpc_decode_batch_f16", "ldpc_decode_batch_dev_f16", "ldpc_sim_generate_f16",
+    "ldpc_decode_batch_f16", "ldpc_decode_batch_dev_f16", "ldpc_sim_generate_f16", "ldpc_decode_batch_dev_packed", "ldpc_decode_batch_packed",
     "ldpc_debug_step", "ldpc_decode_trace",
     "ldpc_host_alloc", "ldpc_host_free",
     "ldpc_ctx_set_timing", "ldpc_ctx_kernel_time", "ldpc_ctx_kernel_name", "ldpc_ctx_kernel_geometry", "ldpc_jit_cache_dir", "ldpc_jit_source", "ldpc_jit_prepare", "ldpc_jit_source_for", "ldpc_jit_prepare_for",
@@ -175,6 +175,8 @@ def lib():
     L.ldpc_decode_batch_dev.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp, vp, vp]
     L.ldpc_decode_batch_f16.argtypes = [vp, C.c_int, C.c_int, vp, u8p, i32p, u8p]
     L.ldpc_decode_batch_dev_f16.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp, vp, vp]
+    L.ldpc_decode_batch_dev_packed.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int, vp, vp, vp, vp]
+    L.ldpc_decode_batch_packed.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int, u8p, i32p, u8p]
     L.ldpc_debug_step.argtypes = [vp, C.c_int, f64p, f64p, f64p, f64p, f64p, u8p]
     L.ldpc_decode_trace.argtypes = [vp, C.c_int, C.c_int, f64p, u8p, i32p, u8p, f64p]
     L.ldpc_host_alloc.restype = vp
@@ -449,6 +451,22 @@ class Decoder:
         lam = np.zeros((F, self.code.N), np.float64) if want_lam else None
         check(lib().ldpc_decode_batch_f64(self._h, int(max_iters), F, ptr(llr, C.c_double), ptr(bits, C.c_uint8), ptr(iters, C.c_int32), ptr(conv, C.c_uint8), ptr(lam, C.c_double)))
         return (bits, iters, conv, lam) if want_lam else (bits, iters, conv)
+
+    def decode_batch_packed(self, llr, max_iters):
+        """llr [F][N] float16 or float32 (host) -> packed bits [F][ceil(N/8)] (bit i of a frame: byte i // 8, bit i % 8), iters, converged"""
+        llr = np.ascontiguousarray(llr)
+        assert llr.dtype in (np.float16, np.float32) and llr.shape[1] == self.code.N
+        F = llr.shape[0]
+        packed = np.zeros((F, (self.code.N + 7) // 8), np.uint8)
+        iters = np.zeros(F, np.int32)
+        conv = np.zeros(F, np.uint8)
+        check(lib().ldpc_decode_batch_packed(self._h, int(max_iters), F, llr.ctypes.data_as(C.c_void_p), 1 if llr.dtype == np.float16 else 0,
+                                             ptr(packed, C.c_uint8), ptr(iters, C.c_int32), ptr(conv, C.c_uint8)))
+        return packed, iters, conv
+
+    def decode_batch_dev_packed(self, d_llr_ptr, d_packed_ptr, batch, max_iters, d_iters_ptr=None, d_conv_ptr=None, stream=None, llr_f16=False):
+        """device pointers; d_packed [batch][ceil(N/8)] bytes"""
+        check(lib().ldpc_decode_batch_dev_packed(self._h, int(max_iters), int(batch), d_llr_ptr, 1 if llr_f16 else 0, d_packed_ptr, d_iters_ptr, d_conv_ptr, stream))
 
     def decode_batch_dev(self, d_llr_ptr, d_bits_ptr, batch, max_iters, d_iters_ptr=None, d_conv_ptr=None, stream=None, llr_f16=False):
         """device pointers; d_llr [batch][N] float32, or float16 with llr_f16=True"""

@@ -74,6 +74,8 @@ struct ldpc_ctx {
     void *h_small_in = nullptr, *d_small_in = nullptr;   // its own 16-frame device input: no full-size staging
     uint8_t *h_small_out = nullptr, *d_small_out = nullptr;
     // zero-copy path: outputs the caller gave as pageable memory while llr/bits are page-locked
+    uint8_t *d_unpacked = nullptr;   // packed-result entry points: one byte per bit [max_batch][N], then packed (sim.hip pack_bits)
+    uint8_t *d_packed = nullptr;     // ... and the packed image the host-pointer flavour copies back [max_batch][ceil(N/8)]
     int32_t *d_zc_iters = nullptr;
     uint8_t *d_zc_conv = nullptr;
     ldpc::KernelTimer timer;
@@ -342,7 +344,7 @@ void ldpc_ctx_destroy(ldpc_ctx *ctx) {
     if (ctx->h_small_in) (void)hipHostFree(ctx->h_small_in);
     if (ctx->h_small_out) (void)hipHostFree(ctx->h_small_out);
     (void)hipFree(ctx->d_small_out); (void)hipFree(ctx->d_small_in);
-    (void)hipFree(ctx->d_zc_iters); (void)hipFree(ctx->d_zc_conv);
+    (void)hipFree(ctx->d_zc_iters); (void)hipFree(ctx->d_zc_conv); (void)hipFree(ctx->d_unpacked); (void)hipFree(ctx->d_packed);
     if (ctx->fused) ldpc::fused_destroy(ctx->fused);
     ldpc::layered_qc_destroy(ctx->lqc);
     ctx->timer.destroy();
@@ -766,6 +768,50 @@ int ldpc_decode_batch_dev(ldpc_ctx *ctx, int max_iters, int batch, const float *
 int ldpc_decode_batch_dev_f16(ldpc_ctx *ctx, int max_iters, int batch, const uint16_t *d_llr, uint8_t *d_bits,
                               int32_t *d_iters, uint8_t *d_converged, void *stream) {
     return decode_dev_checked(ctx, max_iters, batch, d_llr, ldpc::LLR_F16, d_bits, d_iters, d_converged, stream);
+}
+
+int ldpc_decode_batch_dev_packed(ldpc_ctx *ctx, int max_iters, int batch, const void *d_llr, int llr_f16, uint8_t *d_packed, int32_t *d_iters,
+                                 uint8_t *d_converged, void *stream) {
+    int rc = check_call(ctx, max_iters, batch);
+    if (rc != LDPC_OK) return rc;
+    if (batch == 0) return LDPC_OK;
+    if (!d_llr || !d_packed) return set_error(LDPC_EINVAL, "null d_llr/d_packed");
+    if (!ctx->d_unpacked) HIPCHK(hipMalloc((void **)&ctx->d_unpacked, (size_t)ctx->max_batch * ctx->code->N));
+    hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+    rc = decode_dev(ctx, st, max_iters, batch, d_llr, llr_f16 ? ldpc::LLR_F16 : ldpc::LLR_F32, ctx->d_unpacked, d_iters, d_converged, nullptr, nullptr);
+    if (rc != LDPC_OK) return rc;
+    return ldpc::pack_bits(st, ctx->d_unpacked, d_packed, batch, ctx->code->N);
+}
+
+int ldpc_decode_batch_packed(ldpc_ctx *ctx, int max_iters, int batch, const void *llr, int llr_f16, uint8_t *packed, int32_t *iters, uint8_t *converged) {
+    int rc = check_call(ctx, max_iters, batch);
+    if (rc != LDPC_OK) return rc;
+    if (batch == 0) return LDPC_OK;
+    if (!llr || !packed) return set_error(LDPC_EINVAL, "null llr/packed");
+    const size_t N = (size_t)ctx->code->N, PB = (N + 7) / 8, es = llr_f16 ? 2 : 4;
+    if ((rc = ensure_staging(ctx, false)) != LDPC_OK) return rc;       // (d_in / d_iters / d_conv of the chunked pipeline; its d_bits slots are not used here)
+    if (!ctx->d_packed) HIPCHK(hipMalloc((void **)&ctx->d_packed, (size_t)ctx->max_batch * PB));
+    hipError_t e = hipSuccess;
+    int slot = 0;
+    // LLRs in chunk by chunk as the byte-per-bit entry point does; an eighth of the bytes back
+    for (int f0 = 0; f0 < batch && rc == LDPC_OK && e == hipSuccess; f0 += ctx->chunk, slot = (slot + 1) % ctx->slots) {
+        const int nb = std::min(ctx->chunk, batch - f0);
+        hipStream_t st = ctx->pstream[slot];
+        e = hipMemcpyAsync(ctx->d_in[slot], (const char *)llr + (size_t)f0 * N * es, (size_t)nb * N * es, hipMemcpyHostToDevice, st);
+        if (e != hipSuccess) break;
+        rc = decode_dev(ctx, st, max_iters, nb, ctx->d_in[slot], llr_f16 ? ldpc::LLR_F16 : ldpc::LLR_F32, ctx->d_bits[slot], ctx->d_iters[slot], ctx->d_conv[slot], nullptr, nullptr);
+        if (rc == LDPC_OK) rc = ldpc::pack_bits(st, ctx->d_bits[slot], ctx->d_packed + (size_t)f0 * PB, nb, (int)N);
+        if (rc != LDPC_OK) break;
+        e = hipMemcpyAsync(packed + (size_t)f0 * PB, ctx->d_packed + (size_t)f0 * PB, (size_t)nb * PB, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess && iters) e = hipMemcpyAsync(iters + f0, ctx->d_iters[slot], sizeof(int32_t) * (size_t)nb, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess && converged) e = hipMemcpyAsync(converged + f0, ctx->d_conv[slot], (size_t)nb, hipMemcpyDeviceToHost, st);
+    }
+    for (int i = 0; i < ctx->slots; i++) {
+        hipError_t es2 = hipStreamSynchronize(ctx->pstream[i]);
+        if (e == hipSuccess) e = es2;
+    }
+    if (rc == LDPC_OK && e != hipSuccess) rc = set_error(LDPC_EHIP, "decode (packed): %s", hipGetErrorString(e));
+    return rc;
 }
 
 int ldpc_debug_step(ldpc_ctx *ctx, int batch, const double *orig, const double *lam, const double *ne, double *ne_out,

@@ -17,4 +17,6 @@ int sim_generate(const SimDev &s, uint32_t *msgw, uint32_t *parw, hipStream_t st
                  double ebn0_db, void *d_out, int out_fmt, uint8_t *d_msg);   // out_fmt: 0 = f32 LLRs [batch][N], 1 = fp16 LLRs, 2 = codeword bytes [batch][n_tx]
 int sim_tally(const SimDev &s, const uint32_t *msgw, hipStream_t st, int batch, const uint8_t *d_bits, const int32_t *d_iters,
               unsigned long long *d_tally);
+// hard bits, one byte each [batch][N] -> packed [batch][ceil(N/8)], bit i of a frame in byte i / 8 at bit i % 8
+int pack_bits(hipStream_t st, const uint8_t *d_bits, uint8_t *d_packed, int batch, int N);
 }  // namespace ldpc

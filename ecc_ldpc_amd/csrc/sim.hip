@@ -293,4 +293,31 @@ int sim_tally(const SimDev &s, const uint32_t *msgw, hipStream_t st, int batch, 
     return LDPC_OK;
 }
 
+// ---- packed result bits (ldpc_decode_batch_dev_packed): eight result bytes -> one byte, LSB first
+__global__ __launch_bounds__(256) void pack_bits_kernel(const uint8_t *__restrict__ bits, uint8_t *__restrict__ packed, int batch, int N, int PB) {
+    const int f = blockIdx.y;
+    const uint8_t *src = bits + (size_t)f * N;
+    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < PB; j += gridDim.x * blockDim.x) {
+        uint32_t b = 0;
+        if ((N & 7) == 0) {                                   // every frame starts on an 8-byte boundary of a 16-byte aligned buffer
+            const uint2 v = *reinterpret_cast<const uint2 *>(src + 8 * (size_t)j);
+            auto nib = [](uint32_t w) { return (w & 1u) | ((w >> 7) & 2u) | ((w >> 14) & 4u) | ((w >> 21) & 8u); };
+            b = nib(v.x) | (nib(v.y) << 4);
+        } else {
+#pragma unroll
+            for (int t = 0; t < 8; t++)
+                if (8 * j + t < N) b |= (uint32_t)(src[8 * (size_t)j + t] & 1u) << t;
+        }
+        packed[(size_t)f * PB + j] = (uint8_t)b;
+    }
+}
+
+int pack_bits(hipStream_t st, const uint8_t *d_bits, uint8_t *d_packed, int batch, int N) {
+    const int PB = (N + 7) / 8;
+    hipLaunchKernelGGL(pack_bits_kernel, dim3((PB + 255) / 256, batch), dim3(256), 0, st, d_bits, d_packed, batch, N, PB);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return set_error(LDPC_EHIP, "pack_bits: %s", hipGetErrorString(e));
+    return LDPC_OK;
+}
+
 }  // namespace ldpc

@@ -55,12 +55,14 @@ sumReference = 0; sumArraylet = 1; sumSparse = 2      -- ldpc_sum_order: whose c
 
 -- | maxThreadCount of these codes (Utils.hs:53): how many Haskell threads may decode at once.  The harness picks the
 -- closure by ThreadId `rem` maxThreadCount (Utils.hs:63-69).
+-- Measured through this call sequence (ecc_ldpc_amd/csrc/batcher.cc, jpl.4096, 50 turns, 16 host cores, callers = batch limit):
+-- 64 threads 338-376 Mbit/s, 128: 408, 256: 467, 512: 339 -- the optimum; the host side sustains ~100 000 calls/s.
 hipThreads :: Int
-hipThreads = 64
+hipThreads = 256
 
 -- | frames the batcher of one GPU collects at most, and how long (microseconds) a lone caller waits for company
 coalesceFrames, coalesceWaitUs :: CInt
-coalesceFrames = 64
+coalesceFrames = 256         -- = hipThreads: a launch can carry every caller that may be waiting (one workgroup per frame: 256 CUs)
 coalesceWaitUs = 200
 
 -- vars of the Code (the CUDA plug-ins keep their CudaAllocations there, Arraylet2.hs:287-293): the number of GPUs and,

@@ -199,6 +199,15 @@ int ldpc_decode_batch_f16(ldpc_ctx *ctx, int max_iters, int batch, const uint16_
                           int32_t *iters, uint8_t *converged);
 int ldpc_decode_batch_dev_f16(ldpc_ctx *ctx, int max_iters, int batch, const uint16_t *d_llr,
                               uint8_t *d_bits, int32_t *d_iters, uint8_t *d_converged, void *stream);
+/* PACKED result bits (r04): ceil(N/8) bytes per frame instead of N -- bit i of a frame is bit (i % 8) of byte i / 8 (LSB first; what
+ * SURVEY.md section 8d's byte model counts as a frame's output) -- an eighth of the bytes back over PCIe or out to the caller's HBM
+ * buffer; the decoded values are those of the unpacked entry points.  llr_f16 != 0: d_llr / llr are IEEE binary16 patterns.  The decode
+ * kernels write one byte per bit into the context's own staging buffer (max_batch x N bytes, allocated on first use) and a second
+ * kernel packs them.  The reference returns `Vector Bool` (Arraylet2.hs:271-273): one value per bit, no counterpart. */
+int ldpc_decode_batch_dev_packed(ldpc_ctx *ctx, int max_iters, int batch, const void *d_llr, int llr_f16, uint8_t *d_packed,
+                                 int32_t *d_iters, uint8_t *d_converged, void *stream);
+int ldpc_decode_batch_packed(ldpc_ctx *ctx, int max_iters, int batch, const void *llr, int llr_f16, uint8_t *packed,
+                             int32_t *iters, uint8_t *converged);
 /* page-locked host memory for the host-pointer entry points.  With llr AND bits buffers from ldpc_host_alloc (or
  * registered with hipHostRegister) ldpc_decode_batch runs zero-copy: the decode kernel itself reads the LLRs and
  * writes the bits over PCIe (10-11 Gbit/s PCIe-inclusive on jpl.4096); pageable buffers go through a chunked

@@ -204,3 +204,33 @@ def test_config_of_an_older_header_keeps_its_schedule(hip):
     ctx = L.ldpc_ctx_create_cfg(C.c_void_p(c._h), C.byref(cfg28))
     assert ctx and L.ldpc_ctx_schedule(C.c_void_p(ctx)) == 0
     L.ldpc_ctx_destroy(C.c_void_p(ctx))
+
+
+def test_packed_result_bits(hip):
+    """ldpc_decode_batch_packed / ldpc_decode_batch_dev_packed: ceil(N/8) bytes per frame, bit i at byte i // 8, bit i % 8 -- after unpacking
+    bit for bit what the byte-per-bit entry points return (on-chip and HBM kernels, N a multiple of 8 and not, more frames than one
+    chunk of the host pipeline, fp16 input)"""
+    import torch
+    for name, variant, F in (("jpl.1024.4.5", "min", 9000), ("moon.7.13", "tanh", 77), ("1920.1280.3.303", "tanh", 300)):
+        c = load(name)
+        _, llr = c.frames(F if F < 400 else 64, 3.0, seed=990)
+        llr = np.tile(llr, ((F + len(llr) - 1) // len(llr), 1))[:F].astype(np.float32)
+        dec = hip.Decoder(c.hip_code(hip), variant, "f32", F)
+        bits, its, conv = dec.decode_batch(llr, 30)
+        packed, pi, pc = dec.decode_batch_packed(llr, 30)
+        assert packed.shape == (F, (c.N + 7) // 8)
+        assert np.array_equal(np.unpackbits(packed, axis=1, bitorder="little")[:, : c.N], bits) and np.array_equal(pi, its) and np.array_equal(pc, conv)
+        p16, _, _ = dec.decode_batch_packed(llr.astype(np.float16), 30)
+        b16, _, _ = dec.decode_batch(llr.astype(np.float16), 30)
+        assert np.array_equal(np.unpackbits(p16, axis=1, bitorder="little")[:, : c.N], b16)
+        # device pointers
+        dev = torch.device("cuda", 0)
+        n = min(F, 256)
+        t_llr = torch.from_numpy(llr[:n]).to(dev)
+        t_pk = torch.zeros((n, (c.N + 7) // 8), dtype=torch.uint8, device=dev)
+        t_it = torch.zeros(n, dtype=torch.int32, device=dev)
+        torch.cuda.synchronize()
+        dec.decode_batch_dev_packed(t_llr.data_ptr(), t_pk.data_ptr(), n, 30, t_it.data_ptr(), None, None)
+        dec.synchronize()
+        assert np.array_equal(np.unpackbits(t_pk.cpu().numpy(), axis=1, bitorder="little")[:, : c.N], bits[:n]) and np.array_equal(t_it.cpu().numpy(), its[:n])
+        dec.close()

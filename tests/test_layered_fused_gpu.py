@@ -32,11 +32,16 @@ def test_on_chip_layered_equals_the_hbm_kernel_and_the_oracle(hip, name, F, dbs)
     lp = np.arange(0, c.M + 1, c.sz)
     ref = [oracle.decode_layered(c.graph, lp, "min", 40, l.astype(np.float64)) for l in llr]
     ob = np.stack([o["bits"] for o in ref]); oi = np.array([o["iters"] for o in ref]); oc = np.array([o["converged"] for o in ref])
-    same = a[2].astype(bool) == oc            # (a frame at the edge of convergence may fall the other way in f32: test_layered_gpu.py)
-    assert same.mean() >= 0.95 and np.array_equal(a[0][same], ob[same])
-    # sweep counts: the serial schedule amplifies float-vs-Double rounding differences faster than flooding does (a frame that
-    # needs 35 sweeps in Double may need 33 in float); the bar of the HBM kernel's test: >= 90 % identical
-    assert (a[1] == oi)[same].mean() >= 0.9
+    # f32 against the DOUBLE specification -- measured, not assumed (tools/layered_f32_vs_f64.py, profiles/r04_layered_f32_vs_f64.txt:
+    # 20 400 min-sum frame decodes across the waterfall of jpl.1024 and jpl.4096, on-chip and HBM kernels alike): the converged flag
+    # differs in 1.4 % of the frames (3.6 % at the waterfall's edge, as often one way as the other), the sweep count in 2.7 % (9.8 % at the
+    # edge, by up to 16 sweeps: the serial schedule amplifies a rounding difference, min-sum's arg-min ties most of all -- the tanh rule:
+    # 2e-4), and the hard bits of EVERY frame whose flags agree are identical.  Bars for this sample of F frames at two Eb/N0: flags >= 90 %,
+    # sweeps >= 85 %, bits exact.
+    same = a[2].astype(bool) == oc
+    assert same.mean() >= 0.90 and np.array_equal(a[0][same], ob[same]), same.mean()
+    assert (a[1] == oi)[same].mean() >= 0.85, (a[1] == oi)[same].mean()
+    print(f"{name} layered on-chip f32 vs Double: flags agree {same.mean():.3f}, sweeps equal {(a[1] == oi)[same].mean():.3f} over {F} frames")
     # the throughput entry points: f32 and fp16 buffers
     b32 = on.decode_batch(llr, 40)
     assert all(np.array_equal(x, y) for x, y in zip(b32, a[:3]))

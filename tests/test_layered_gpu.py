@@ -53,10 +53,12 @@ def test_f32_free_running_and_teacher_forced(hip, name, dbs):
         ref = [oracle.decode_layered(c.graph, lp, variant, 40, l) for l in llr]
         ob = np.stack([o["bits"] for o in ref]); oi = np.array([o["iters"] for o in ref]); oc = np.array([o["converged"] for o in ref])
         # f32 against a double specification: a frame at the edge of convergence may fall the other way (the serial
-        # schedule amplifies rounding differences faster than flooding does); everything else must agree exactly
+        # schedule amplifies rounding differences faster than flooding does).  Measured over 30 600 frame decodes
+        # (profiles/r04_layered_f32_vs_f64.txt): min-sum flags differ in 1.4 % of the frames (3.6 % at the waterfall's edge), sweep counts
+        # in 2.7 % (9.8 %); tanh 2e-4 and 4e-4; the bits of every frame whose flags agree are identical.  Bars for these small samples:
         same = conv.astype(bool) == oc
-        assert same.mean() >= 0.95 and np.array_equal(bits[same], ob[same]), (name, variant, same.mean())
-        assert (its == oi)[same].mean() >= 0.9
+        assert same.mean() >= (0.90 if variant == "min" else 0.97) and np.array_equal(bits[same], ob[same]), (name, variant, same.mean())
+        assert (its == oi)[same].mean() >= (0.85 if variant == "min" else 0.95), (name, variant, (its == oi)[same].mean())
         # one sweep from oracle states
         states = []
         for f in range(4):

@@ -7,12 +7,14 @@
 --   hip-tanh, hip-minsum                    QuasiCyclic Integer H  (.q files; what Fast.Arraylet takes, Fast/Arraylet.hs:68-79)
 --   hip-tanh-bool, hip-minsum-bool          Matrix Bool H          (.alist / .m files; what Reference.Orig takes, Orig.hs:20-31)
 --   hip-minsum-layered                      QuasiCyclic, row-layered schedule (an extension of this library)
+--   hip-tanh-cuda32                         QuasiCyclic, the arithmetic of cuda-arraylet2 itself (float state, double product, float
+--                                           atanh_ and clamp: LDPC_TANH_CUDA32, a parity mode on the flood path; r04)
 -- Every code is built with maxThreadCount = hipThreads replicas (Utils.hs:53): replica i lives on GPU (i mod #GPUs), so
 -- one Haskell process drives every GPU of the node; and the replicas of one GPU share a coalescing batcher
 -- (ldpc_batcher_*): frames that several Haskell threads decode at the same moment go to the device in ONE launch.
 {-# LANGUAGE ForeignFunctionInterface #-}
 module ECC.Code.LDPC.GPU.HIP (codeTanh, codeMinSum, codeTanhBool, codeMinSumBool, codeMinSumLayered, codeMinSumF16PK,
-                              codeTanhArrayletF64, codeTanhSparseF64, hipThreads) where
+                              codeTanhArrayletF64, codeTanhSparseF64, codeTanhCuda32, hipThreads) where
 
 import ECC.Code.LDPC.Utils            (mkLDPC_CodeIO)
 import ECC.Types
@@ -49,7 +51,8 @@ foreign import ccall safe   "ldpc_batcher_create"     c_batcher    :: Ptr LdpcCt
 foreign import ccall safe   "ldpc_batcher_decode_one" c_decodeOne  :: Ptr LdpcBatcher -> CInt -> Ptr Double -> Ptr Word8
                                                                    -> Ptr CInt -> Ptr CInt -> IO CInt
 
-tanhRule, minSumRule, f32, f64, f16pk, flooding, layered, pathAuto, sumReference, sumArraylet, sumSparse :: CInt
+tanhRule, minSumRule, tanhCuda32Rule, f32, f64, f16pk, flooding, layered, pathAuto, sumReference, sumArraylet, sumSparse :: CInt
+tanhCuda32Rule = 3   -- LDPC_TANH_CUDA32
 tanhRule = 0; minSumRule = 1; f32 = 0; f64 = 1; f16pk = 3; flooding = 0; layered = 1; pathAuto = 0
 sumReference = 0; sumArraylet = 1; sumSparse = 2      -- ldpc_sum_order: whose column-sum order the f64 parity modes follow
 
@@ -94,6 +97,9 @@ codeMinSumF16PK   = mkLDPC_CodeIO "hip-minsum-f16pk"   hipThreads E.encoder (dec
 -- Double twins of two of the reference's own decoders, last ulp included: run them next to `arraylet` / `sparse` in one harness
 codeTanhArrayletF64 = mkLDPC_CodeIO "hip-tanh-f64-arraylet"    hipThreads E.encoder (decoderQC   (tanhRule, f64, flooding, sumArraylet)) initialize finalize
 codeTanhSparseF64   = mkLDPC_CodeIO "hip-tanh-bool-f64-sparse" hipThreads O.encoder (decoderBool (tanhRule, f64, flooding, sumSparse))   initialize finalize
+-- the live CUDA plug-in's own arithmetic (cudabits/arraylet2.cu:43-83, common.h:82-88,151-178), for comparing like with like (r04)
+codeTanhCuda32 :: Code
+codeTanhCuda32      = mkLDPC_CodeIO "hip-tanh-cuda32" hipThreads E.encoder (decoderQC (tanhCuda32Rule, f32, flooding, sumReference)) initialize finalize
 
 -- rotation of the single set bit, -1 for an empty block (Fast/Arraylet.hs:68-79)
 offsetsOf :: Q.QuasiCyclic Integer -> [Int32]

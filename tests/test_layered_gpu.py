@@ -245,6 +245,11 @@ def test_fp16_lam_storage_from_hbm(hip, name, F, dbs, monkeypatch):
     for nf in (1, 2, 3):                                                      # small batches
         b1 = dec.decode_batch(llr[:nf], 30)
         assert np.array_equal(b1[0], bits[:nf]) and np.array_equal(b1[1], its[:nf])
+    tb, ti, tc, tr = dec.decode_trace(llr[:5].astype(np.float64), 30)         # per-sweep LLRs (the instance without hand-counted prefetch writes them)
+    assert np.array_equal(tb, bits[:5]) and np.array_equal(ti, its[:5]) and np.array_equal(tr[:, 0], em.r16(llr[:5]).astype(np.float64))
+    for f in range(5):
+        if conv[f]:
+            assert np.array_equal(tr[f, its[f]], lam[f])                      # the row of the sweep it stopped at = the LLRs it returns
     b16 = dec.decode_batch(em.r16(llr).astype(np.float16), 30)                # fp16 input buffer: the same decoder
     assert np.array_equal(b16[0], bits) and np.array_equal(b16[1], its)
     f32 = hip.Decoder(c.hip_code(hip), "min", "f32", F, schedule="layered", path="flood").decode_batch(llr, 30)

@@ -94,20 +94,20 @@ __device__ __forceinline__ uint32_t lds_addr(int A, int thr, int r, uint32_t rb,
 // two-min, new record, lam written back.  Arithmetic of layered_qc.hip qc_row_rec; signs by bit operations as ldpc_math.h
 // cn_update_padded (a zero t makes every message it could change the sign of a zero).  No lane is masked: the idle lanes of the
 // last wave shadow rows of their own wave (same reads in the same instruction, same values written to the same cells).
-// pre: the LDS addresses of the row's (up to 8) cells, computed before the barrier that precedes the row, or null: from LdsDev::tab
+// tb: the row's first 8 circulants already in (scalar) registers, or null: read from LdsDev::tab
 // mid(): called between the gather phase and the write-back phase (the pipelined loop requests the next layer's graph entries there:
 // behind the last wait for an LDS read -- scalar loads return out of order, so any wait on the counter they share with LDS becomes a
 // wait for them too -- and early enough to have landed when the layer's barrier is reached)
 struct NoMid { __device__ __forceinline__ void operator()() const {} };
 template <int DMAX, bool EXACT, bool FIRST, class Mid = NoMid>
 __device__ __forceinline__ void lds_row(const LdsDev &g, const LdsRec &in, LdsRec &out, int e0, int deg, int r, uint32_t rb, uint32_t rw, bool &odd, bool &flip,
-                                        const uint32_t *pre = nullptr, Mid &&mid = Mid()) {
+                                        const int *tb = nullptr, Mid &&mid = Mid()) {
     uint32_t ad[DMAX];
     float l[DMAX], t[DMAX];
 #pragma unroll
     for (int k = 0; k < DMAX; k++) {
         const int kk = (EXACT || k < deg) ? k : 0;
-        if (DMAX <= 8 && pre) ad[k] = pre[kk];
+        if (DMAX <= 8 && tb) ad[k] = lds_addr(tb[2 * kk], tb[2 * kk + 1], r, rb, rw);
         else ad[k] = lds_addr(((ctab_t)g.tab)[2 * (e0 + kk)], ((ctab_t)g.tab)[2 * (e0 + kk) + 1], r, rb, rw);
     }
 #pragma unroll
@@ -157,7 +157,7 @@ __device__ __forceinline__ void lds_row(const LdsDev &g, const LdsRec &in, LdsRe
 }
 
 template <int DCLASS, bool FIRST, class Mid = NoMid>
-__device__ __forceinline__ void lds_layer_at(const LdsDev &g, const LdsRec &in, LdsRec &out, int e0, int deg, const uint32_t *tb, int r, uint32_t rb, uint32_t rw, bool &odd,
+__device__ __forceinline__ void lds_layer_at(const LdsDev &g, const LdsRec &in, LdsRec &out, int e0, int deg, const int *tb, int r, uint32_t rb, uint32_t rw, bool &odd,
                                              bool &flip, Mid &&mid = Mid()) {
     switch (deg) {
         case 2: lds_row<2, true, FIRST>(g, in, out, e0, 2, r, rb, rw, odd, flip, tb, mid); return;
@@ -348,16 +348,12 @@ __global__ __launch_bounds__(lds_max_threads(DCLASS, P)) void layered_lds_kernel
             const uint32_t gstep = (uint32_t)g.gsz * (uint32_t)TL * (uint32_t)sizeof(LdsRec), gend = gstep * (uint32_t)g.ng;
             const uint32_t voff = (uint32_t)sub * (uint32_t)TL * (uint32_t)sizeof(LdsRec) + (uint32_t)tin * (uint32_t)sizeof(LdsRec);
             uint32_t soff = 0, loff = gstep * (uint32_t)P;       // (P < ng)
-            int gi = 0, e0v[2], degv[2];                         // gi: the group being run; this wave's slot is gi * gsz + sub
-            uint32_t adv[2][8];                                  // the LDS addresses of a row's cells, worked out BEFORE the barrier that precedes the row
+            // (forming the NEXT group's LDS addresses before the barrier, from these entries, was measured: 59.9 vs 58.3 ms per 16 384 frames --
+            //  the arithmetic lengthens the slowest wave's way to the barrier instead of hiding behind the other waves' gathers; not kept)
+            int gi = 0, e0v[2], degv[2], tbv[2][16];             // gi: the group being run; this wave's slot is gi * gsz + sub
             bool odd = false, flip = false;
             n = 1;
-            {
-                int tb0[16];
-                load_ltab(ltab0, sub, e0v[0], degv[0], tb0);
-#pragma unroll
-                for (int k = 0; k < 8; k++) adv[0][k] = lds_addr(tb0[2 * k], tb0[2 * k + 1], r, rb, rw);
-            }
+            load_ltab(ltab0, sub, e0v[0], degv[0], tbv[0]);
             auto group_step = [&](auto J) -> bool {     // -> the frame is finished
                 constexpr int j = decltype(J)::value, cur = j & 1, nxt = cur ^ 1;
                 LDPC_TURN_LOOP();
@@ -368,12 +364,9 @@ __global__ __launch_bounds__(lds_max_threads(DCLASS, P)) void layered_lds_kernel
                 rec_load(q[j], voff + loff, wbase);
                 LdsRec out = in;
                 const int deg = __builtin_amdgcn_readfirstlane(degv[cur]);
-                int tbn[16];
-                auto next = [&]() { load_ltab(ltab0, gn * g.gsz + sub, e0v[nxt], degv[nxt], tbn); };
-                if (deg > 0) lds_layer_at<DCLASS, false>(g, in, out, __builtin_amdgcn_readfirstlane(e0v[cur]), deg, adv[cur], r, rb, rw, odd, flip, next);
+                auto next = [&]() { load_ltab(ltab0, gn * g.gsz + sub, e0v[nxt], degv[nxt], tbv[nxt]); };
+                if (deg > 0) lds_layer_at<DCLASS, false>(g, in, out, __builtin_amdgcn_readfirstlane(e0v[cur]), deg, tbv[cur], r, rb, rw, odd, flip, next);
                 else next();                            // (no block row for this wave in this group: it only keeps the counts)
-#pragma unroll
-                for (int k = 0; k < 8; k++) adv[nxt][k] = lds_addr(tbn[2 * k], tbn[2 * k + 1], r, rb, rw);   // (entries past the row's weight: unused)
                 rec_store(u32x3{__float_as_uint(out.c1), __float_as_uint(out.c2), out.meta}, voff + soff, wbase);
                 soff += gstep; soff -= soff >= gend ? gend : 0u;
                 loff += gstep; loff -= loff >= gend ? gend : 0u;

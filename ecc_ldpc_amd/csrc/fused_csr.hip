@@ -631,7 +631,8 @@ static Placement place_for_banks(const ldpc_code &c, int dmax, bool optimise) {
     };
     uint64_t rng = 0x9E3779B97F4A7C15ull;
     auto rnd = [&](int n) { rng ^= rng << 13; rng ^= rng >> 7; rng ^= rng << 17; return (int)(rng % (uint64_t)n); };
-    const long moves = 100L * (M + N);   // 1920.1280.3.303: 679 -> ~330 extra cycles; 4x more moves end at the same cost
+    const char *mm = getenv("LDPC_CSR_PLACE_MOVES");   // search length multiplier (experiments)
+    const long moves = 100L * (M + N) * std::max(1, mm ? atoi(mm) : 1);   // 1920.1280.3.303: 679 -> ~330 extra cycles; 4x more moves end at the same cost
     for (long it = 0; it < moves; it++) {
         // annealing: a worsening by d pairs is accepted with probability 2^-(d / T), T falling linearly to 0
         const double T = 0.6 * (1.0 - (double)it / (double)moves);

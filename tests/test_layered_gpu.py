@@ -312,3 +312,37 @@ def test_fp16_lam_on_chip_long_code(hip):
     both = ec & f32[2].astype(bool)
     assert both.any() and np.array_equal(eb[both], f32[0][both])
     print(f"dvbs2like f16 lam on-chip: sweeps {ei.tolist()} (f32 state {f32[1].tolist()})")
+
+
+def test_fp16_lam_on_chip_edge_cases(hip):
+    """the lam-in-LDS kernel at its edges: a frame length that is not a multiple of 8 (the byte-wise prologue / epilogue), no sweeps allowed,
+    one sweep, a noiseless codeword (stops before the first sweep), an all-zero LLR vector (hard 0 = False: the zero word, 0 sweeps), one frame,
+    more frames than workgroups would need on a small code -- against the emulation"""
+    from oracle import emulate_f16 as em
+    from tests.helpers import SyntheticQC
+    rng = np.random.default_rng(41)
+    mask = np.zeros((6, 11), bool)
+    for br in range(6):
+        mask[br, 5 + br] = True
+        if br:
+            mask[br, 5 + br - 1] = True
+        mask[br, rng.choice(5, 3, replace=False)] = True
+    off = np.where(mask, rng.integers(0, 27, mask.shape), -1).astype(np.int32)
+    c = SyntheticQC("ira-6x11-sz27", 27, off, rate=(135, 297))
+    assert c.N % 8 != 0
+    _, llr = c.frames(300, 3.0, seed=77)
+    llr = llr.astype(np.float32)
+    llr[0] = 9.0 * (2.0 * 0 - 1.0)        # the all-zero codeword, noiseless (LLR < 0 everywhere: hard = 0)
+    llr[1] = 0.0
+    dec = hip.Decoder(c.hip_code(hip), "min", "f16", 300, schedule="layered", path="flood")
+    assert "layered_lds_kernel" in dec.kernel_name
+    for turns in (0, 1, 25):
+        bits, its, conv, lam = dec.decode_batch(llr, turns, want_lam=True)
+        eb, ei, ec, el = em.decode_minsum_f16_layered(c.graph, llr, turns)
+        assert np.array_equal(bits, eb) and np.array_equal(its, ei) and np.array_equal(conv.astype(bool), ec) and np.array_equal(lam, el.astype(np.float64)), turns
+        b2, i2, c2 = dec.decode_batch(llr, turns)                                   # (without the LLR output: the other store path)
+        assert np.array_equal(b2, eb) and np.array_equal(i2, ei)
+        assert its[0] == 0 and conv[0] and its[1] == 0 and conv[1] and not bits[1].any()
+    one = dec.decode_batch(llr[7:8], 25)
+    assert np.array_equal(one[0][0], eb[7]) and one[1][0] == ei[7]
+    dec.close()

@@ -13,7 +13,9 @@ run --steps 3 --warmup 1 --batch 16384 --variant tanh                 # tanh rul
 LDPC_HIP_PATH=flood run --steps 3 --warmup 1 --batch 16384 --variant tanh
 run --steps 6 --warmup 2 --code jpl.1024.4.5                          # configs[1]
 run --steps 3 --warmup 1 --batch 16384 --code jpl.1024.4.5 --variant tanh
-run --steps 3 --warmup 1 --batch 32768 --code dvbs2like.64800.1.2 --rate none --schedule layered --ebn0 2     # configs[4]: DVB-S2-shaped long code, layered
+run --steps 3 --warmup 1 --batch 32768 --code dvbs2like.64800.1.2 --rate none --schedule layered --dtype f16 --ebn0 2   # configs[4]: DVB-S2-shaped long code, layered, fp16 lam ON-CHIP + streamed records (r04)
+run --steps 3 --warmup 1 --batch 32768 --code dvbs2like.64800.1.2 --rate none --schedule layered --dtype f16 --ebn0 3
+run --steps 3 --warmup 1 --batch 32768 --code dvbs2like.64800.1.2 --rate none --schedule layered --ebn0 2     # the same with f32 lam and records in HBM
 run --steps 3 --warmup 1 --batch 8192 --code dvbs2like.64800.1.2 --rate none --ebn0 2                            # the same code, flooding (frame-per-workgroup HBM kernel)
 run --steps 4 --warmup 2 --schedule layered --ebn0 3                                                             # jpl.4096 layered ON-CHIP in the waterfall
 run --steps 4 --warmup 2 --schedule layered --ebn0 2                                                             # ... and below it

@@ -47,6 +47,26 @@ struct CsrArgs {
     const uint32_t *rpack_tab;   // ... and packed row-slot offsets, same layout
 };
 
+// LDS of the batched kernel (bytes): lam[N] | messages [DMAX][M] | +inf | 0 | next-frame cell | (STAGED instances only:) LLRs of
+// the next frame [N] f32, 16-byte aligned | column behind each LDS position [N] u16
+__host__ __device__ constexpr uint32_t csrb_off_stage(int N, int M, int dmax) { return (((uint32_t)(N + dmax * M) + 3u) * 4u + 15u) & ~15u; }
+__host__ __device__ constexpr uint32_t csrb_lds_bytes(int N, int M, int dmax, bool staged) {
+    return staged ? ((csrb_off_stage(N, M, dmax) + (uint32_t)N * 6u + 3u) & ~3u) : ((uint32_t)(N + dmax * M) + 3u) * 4u;
+}
+#ifdef LDPC_CSR_STAMPS
+// debug build only (tools/csr_stamps.py): cycles thread 0 of every workgroup spends in each phase of a frame, summed per WORKGROUP
+// in registers and added to these cells once, when the workgroup ends (an atomic per stamp would be the bottleneck it measures)
+__device__ unsigned long long g_csr_stamps[8];
+#define CSR_STAMP(i) do { if (tid == 0) { const long long now_ = clock64(); acc_[i] += (unsigned long long)(now_ - stamp_); stamp_ = now_; } } while (0)
+extern "C" int ldpc_debug_csr_stamps(unsigned long long *out, int reset) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_csr_stamps), sizeof(g_csr_stamps)) != hipSuccess) return -1;
+    if (reset) { unsigned long long z[8] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_csr_stamps), z, sizeof(z)) != hipSuccess) return -1; }
+    return 0;
+}
+#else
+#define CSR_STAMP(i) do {} while (0)
+#endif
+
 // RPT / CPT > 0: the thread's column indices (RPT rows x DMAX) and message slots (CPT columns x CDMAX)
 // are loaded into registers ONCE before the turn loop; 0: re-read from global memory every turn.
 constexpr int kCdMax = 8;  // column degree bound of the register-cached variant
@@ -252,7 +272,7 @@ __global__ __launch_bounds__(THREADS) void fused_csr_kernel(CsrArgs A) {
 // OSH = 2 (r03, codes/1920.1280.A: 146 KB of state, one 1024-thread workgroup per CU): the 16-bit offsets count DWORDS, so that
 // they reach the whole 160 KB; its 6 rows x 6 slots and 2 columns x 18 slots per thread are gathered in groups of RG rows / CG
 // columns (18 values in flight instead of 36: the instance has to fit 128 VGPRs -- 16 waves on a CU are 4 per SIMD).
-template <typename CT, int VARIANT, int DMAX, int RPT, int CPT, int CD, int THREADS, int OSH = 0>
+template <typename CT, int VARIANT, int DMAX, int RPT, int CPT, int CD, int THREADS, int OSH = 0, bool STAGED = false>
 __global__ __launch_bounds__(THREADS, (DMAX <= 8 ? (THREADS > 512 ? 4 : THREADS > 256 ? 6 : 4) : 1)) void fused_csr_batched_kernel(CsrArgs A) {
     static_assert(sizeof(CT) == 4 && DMAX % 2 == 0 && CD % 2 == 0, "pairs of 16-bit offsets");
     constexpr int RG = (RPT * DMAX > 24 && DMAX <= 8) ? (VARIANT == LDPC_V_TANH ? (RPT + 2) / 3 : (RPT + 1) / 2) : RPT;    // rows gathered together
@@ -334,16 +354,77 @@ __global__ __launch_bounds__(THREADS, (DMAX <= 8 ? (THREADS > 512 ? 4 : THREADS 
     // frames are taken from a shared counter, not by a fixed stride: below the waterfall the turns per frame spread from a
     // few to max_iters, and 85 frames per workgroup do not average that out (measured with a fixed stride at 1 dB: +15 % time)
     int *next_frame = reinterpret_cast<int *>(smem + off_zero + 4u);
-    for (int frame = blockIdx.x; frame < A.batch;) {
+    // STAGED instances (f32 LLRs of a plain decode, room in LDS): the workgroup holds TWO frames -- the one it decodes and the one
+    // it decodes next -- and the next one's LLRs travel HBM -> LDS by LDS-DMA (global_load_lds: no register in between) while the
+    // turns of the current one run; the ticket for the frame after that is taken at the start of a frame by the wave with the
+    // smallest share of rows and columns; the column permutation stays in LDS.  Nothing of a frame's start then waits for memory.
+    // Frames held ahead are frames another workgroup cannot take: over the last kCsrLateZone x gridDim ids of a batch nothing is
+    // claimed ahead any more (the ticket is taken when a frame ends and its LLRs are waited for, as the other instances do), or
+    // the launch would end with most workgroups idle and a few still owning two frames (measured at 1 dB: +2.7 % time).
+    float *stage = reinterpret_cast<float *>(smem + csrb_off_stage(N, M, DMAX));
+    uint16_t *cpos = reinterpret_cast<uint16_t *>(stage + N);
+    auto stage_frame = [&](int f, int thr) {
+        const float *src = reinterpret_cast<const float *>(A.llr) + (size_t)f * N;
+#pragma unroll
+        for (int i = 0; i < CPT; i++) {
+            const int c = thr + i * THREADS;   // file order: a wave's 64 lanes fetch 256 consecutive bytes, landing at stage[c]
+            if (c < N)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + c),
+                                                 (__attribute__((address_space(3))) void *)(stage + (c & ~63)), 4, 0, 0);
+        }
+    };
+    constexpr int kCsrLateZone = 3;
+    // ONE thread: the id after id `f` for this workgroup, into the next-frame cell; -1 = none yet (`ahead`: asked while f is still to be decoded)
+    auto claim = [&](int f, bool ahead) {
+        int id = -1;
+        if (!A.work_counter) id = f + (int)gridDim.x;
+        else if (!ahead || (f >= 0 && f < A.batch - kCsrLateZone * (int)gridDim.x)) id = (int)gridDim.x + atomicAdd(A.work_counter, 1);
+        *next_frame = id;
+    };
+    int frame = blockIdx.x, frame_next = -1;   // frame_next: claimed, its LLRs not asked for yet; -1: nothing held ahead
+    if constexpr (STAGED) {
+        for (int c = tid; c < N; c += THREADS) cpos[c] = (uint16_t)A.col_of_pos[c];
+        if (tid == THREADS - 64) claim(frame, true);
+        if (frame < A.batch) stage_frame(frame, tid);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        frame_next = *next_frame;
+    }
+#ifdef LDPC_CSR_STAMPS
+    long long stamp_ = clock64();
+    unsigned long long acc_[4] = {0, 0, 0, 0};
+#endif
+    while (frame < A.batch) {
     const size_t fN = (size_t)frame * N, fE = (size_t)frame * A.E;
     CT mreg[RPT][DMAX], oreg[CPT];
     int colreg[CPT];   // (re-read per frame, one coalesced load: kept across frames it costs the turn loop four registers)
+    if constexpr (!STAGED) {
 #pragma unroll
     for (int i = 0; i < CPT; i++) colreg[i] = (tid + i * THREADS < N) ? A.col_of_pos[tid + i * THREADS] : 0;
+    }
 #pragma unroll
     for (int i = 0; i < RPT; i++)
 #pragma unroll
         for (int k = 0; k < DMAX; k++) mreg[i][k] = CT(0);   // Orig.hs:64-65
+    if constexpr (STAGED) {
+        // (Tried: the thread index made opaque here and in the epilogue, so that the addresses made from it are worked out per frame
+        // instead of being hoisted out of the frame loop and spilled across the turn loop: 4 dB +3 % more, but the turn loop the
+        // compiler then produced was 2-4 % slower per turn, 1 dB -2.3 %: profiles/r04_csr_stage_ab.txt.  Not kept.)
+        const int tf = tid;
+        // (the DMA that filled the staging area was waited for before the barrier that ended the previous frame)
+#pragma unroll
+        for (int i = 0; i < CPT; i++) {
+            const int c = tf + i * THREADS;
+            oreg[i] = CT(0);
+            if (c < N) {
+                oreg[i] = maybe_round_f16<CT>((CT)stage[cpos[c]], A.llr_round16);
+                lam[c] = oreg[i];
+            }
+        }
+        __syncthreads();   // the staging area has been read: it is the next frame's now
+        if (frame_next >= 0 && frame_next < A.batch) stage_frame(frame_next, tf);
+        if (tid == THREADS - 64) claim(frame_next, true);   // the frame after the one held next
+    } else {
     if (A.step_mode) {
         LDPC_COLD_PATH();
 #pragma unroll
@@ -365,17 +446,20 @@ __global__ __launch_bounds__(THREADS, (DMAX <= 8 ? (THREADS > 512 ? 4 : THREADS 
         }
     }
     __syncthreads();
+    }
+    CSR_STAMP(0);
 
     bool converged = false;
     int n_done = 0;
-    const int turns = A.step_mode ? 1 : A.max_iters;
+    const bool step_mode = STAGED ? false : (A.step_mode != 0);   // (STAGED instances: plain decodes only)
+    const int turns = step_mode ? 1 : A.max_iters;
     constexpr bool kResc = kRescales<CT, VARIANT>;   // min-sum in f32: the frame is rescaled by 2^-40 when an LLR passes 2^60 (ldpc_math.h)
     float osc = 1.0f;                                // the factor the channel LLRs enter a column sum with; the frame's LLRs are 2^kexp x lam
     int kexp = 0;
     if constexpr (RP_MEM) load_pack(A.rpack_tab, rpack, std::integral_constant<int, RPT * (DMAX / 2)>{}, std::integral_constant<int, DMAX / 2>{});
     for (int n = 0;; n++) {
         LDPC_TURN_LOOP();
-        if (A.trace) {
+        if (A.trace) {   // (never set for a STAGED instance; the test stays: without it the compiler's turn loop came out slower)
             LDPC_COLD_PATH();
             for (int c = tid; c < N; c += THREADS) A.trace[((size_t)frame * (A.max_iters + 1) + n) * N + A.col_of_pos[c]] = ldexp((double)lam[c], kexp);
         }
@@ -444,7 +528,7 @@ __global__ __launch_bounds__(THREADS, (DMAX <= 8 ? (THREADS > 512 ? 4 : THREADS 
             load_pack(A.cpack_tab, cpack, std::integral_constant<int, CPT * (CD / 2)>{}, std::integral_constant<int, CD / 2>{});
         }
         const int any_unsat = __syncthreads_or(unsat);  // also: every message written, every lam read
-        if (A.step_mode) {
+        if (step_mode) {
             if (tid == 0) A.st_syn[frame] = any_unsat ? 0 : 1;
         } else if (!any_unsat) {  // Orig.hs:69
             converged = true; n_done = n;
@@ -488,10 +572,11 @@ __global__ __launch_bounds__(THREADS, (DMAX <= 8 ? (THREADS > 512 ? 4 : THREADS 
                 __syncthreads();
             }
         } else __syncthreads();
-        if (A.step_mode) break;
+        if (step_mode) break;
     }
+    CSR_STAMP(1);
 
-    if (A.step_mode) {
+    if (step_mode) {
         for (int c = tid; c < N; c += THREADS) A.final_lam[fN + A.col_of_pos[c]] = ldexp((double)lam[c], kexp);
 #pragma unroll
         for (int i = 0; i < RPT; i++) {
@@ -504,11 +589,12 @@ __global__ __launch_bounds__(THREADS, (DMAX <= 8 ? (THREADS > 512 ? 4 : THREADS 
             }
         }
     } else {
+        const int te = tid;
 #pragma unroll
         for (int i = 0; i < CPT; i++) {
-            const int c = tid + i * THREADS;
+            const int c = te + i * THREADS;
             if (c < N) {
-                const int col = A.col_of_pos[c];
+                const int col = STAGED ? (int)cpos[c] : A.col_of_pos[c];
                 CT vv = converged ? lam[c] : oreg[i];
                 A.bits[fN + col] = vv > CT(0) ? 1 : 0;
                 if (A.final_lam) A.final_lam[fN + col] = converged ? ldexp((double)vv, kexp) : (double)vv;
@@ -519,14 +605,34 @@ __global__ __launch_bounds__(THREADS, (DMAX <= 8 ? (THREADS > 512 ? 4 : THREADS 
             if (A.conv) A.conv[frame] = converged ? 1 : 0;
         }
     }
+    CSR_STAMP(2);
+    if constexpr (STAGED) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this thread's share of the next frame's LLRs has landed
+        __syncthreads();   // ... and everybody's; also: every lam read of this frame is done before the next frame's LLRs are written over it
+        if (frame_next >= 0) { frame = frame_next; frame_next = *next_frame; }
+        else {             // the end of the batch: nothing was held ahead
+            if (tid == THREADS - 64) claim(frame, false);
+            __syncthreads();
+            frame = *next_frame;
+            if (frame < A.batch) stage_frame(frame, tid);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+    } else {
     if (tid == 0) *next_frame = A.work_counter ? (int)gridDim.x + atomicAdd(A.work_counter, 1) : frame + (int)gridDim.x;
     __syncthreads();   // also: every lam read of this frame is done before the next frame's LLRs are written over it
     frame = *next_frame;
     }
+    CSR_STAMP(3);
+    }
+#ifdef LDPC_CSR_STAMPS
+    if (tid == 0) for (int i = 0; i < 4; i++) atomicAdd(&g_csr_stamps[i], acc_[i]);
+#endif
 }
 
 // ------------------------------------------------------------------ host side
 struct CsrState {
+    const void *stage_kern = nullptr; bool stage_ok = false;   // batched kernel: whether the LLR staging area fits without costing a resident workgroup
     int variant = 0, dtype = 0, M = 0, N = 0, E = 0, dmax = 0, cdmax = 0, round16 = 0;
     bool want_batched = true, want_cache = true, want_wide = true;   // A/B switches, read from the environment once, at creation
     int32_t *d_ell = nullptr, *d_csc = nullptr, *d_row_ptr = nullptr;
@@ -822,10 +928,42 @@ static int launch_csr(CsrState &s, hipStream_t st, CsrArgs &a) {
     return LDPC_OK;
 }
 
+template <typename CT, int VARIANT, int DMAX, int RPT, int CPT, int CD, int THREADS, int OSH, bool STAGED>
+static int launch_csr_batched_as(CsrState &s, hipStream_t st, CsrArgs &a);
+
 template <typename CT, int VARIANT, int DMAX, int RPT, int CPT, int CD, int THREADS = kCsrThreads, int OSH = 0>
 static int launch_csr_batched(CsrState &s, hipStream_t st, CsrArgs &a) {
-    auto kern = fused_csr_batched_kernel<CT, VARIANT, DMAX, RPT, CPT, CD, THREADS, OSH>;
-    const size_t lds = ((size_t)s.N + (size_t)DMAX * s.M + 3) * sizeof(CT);   // lam, messages, the +inf and 0 cells, the next-frame cell
+    // the STAGED instance (the next frame's LLRs on their way into LDS while this one is decoded: see the kernel) for f32 LLRs of a
+    // plain decode, where its 6 N bytes of LDS do not cost a resident workgroup (LDPC_CSR_STAGE=0: never, A/B)
+    const char *sz = getenv("LDPC_CSR_STAGE");
+    bool staged = OSH == 0 && !a.step_mode && !a.trace && a.llr_fmt == LLR_F32 && s.N < 65536 && !(sz && !strcmp(sz, "0")) &&
+                  csrb_lds_bytes(s.N, s.M, DMAX, true) <= 160u * 1024u;   // (OSH instances: frames of milliseconds, LDS full)
+    if constexpr (OSH > 0) return launch_csr_batched_as<CT, VARIANT, DMAX, RPT, CPT, CD, THREADS, OSH, false>(s, st, a);
+    else {
+    if (staged) {
+        const void *k1 = (const void *)fused_csr_batched_kernel<CT, VARIANT, DMAX, RPT, CPT, CD, THREADS, OSH, true>;
+        const void *k0 = (const void *)fused_csr_batched_kernel<CT, VARIANT, DMAX, RPT, CPT, CD, THREADS, OSH, false>;
+        if (s.stage_kern != k1) {
+            int with = 0, without = 0;
+            const size_t l1 = csrb_lds_bytes(s.N, s.M, DMAX, true), l0 = csrb_lds_bytes(s.N, s.M, DMAX, false);
+            if (l1 > 64 * 1024) (void)hipFuncSetAttribute(k1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l1);
+            if (l0 > 64 * 1024) (void)hipFuncSetAttribute(k0, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l0);
+            s.stage_ok = hipOccupancyMaxActiveBlocksPerMultiprocessor(&with, k1, THREADS, l1) == hipSuccess &&
+                         hipOccupancyMaxActiveBlocksPerMultiprocessor(&without, k0, THREADS, l0) == hipSuccess && with >= without && with >= 1;
+            (void)hipGetLastError();
+            s.stage_kern = k1;
+        }
+        staged = s.stage_ok;
+    }
+    return staged ? launch_csr_batched_as<CT, VARIANT, DMAX, RPT, CPT, CD, THREADS, OSH, true>(s, st, a)
+                  : launch_csr_batched_as<CT, VARIANT, DMAX, RPT, CPT, CD, THREADS, OSH, false>(s, st, a);
+    }
+}
+
+template <typename CT, int VARIANT, int DMAX, int RPT, int CPT, int CD, int THREADS, int OSH, bool STAGED>
+static int launch_csr_batched_as(CsrState &s, hipStream_t st, CsrArgs &a) {
+    auto kern = fused_csr_batched_kernel<CT, VARIANT, DMAX, RPT, CPT, CD, THREADS, OSH, STAGED>;
+    const size_t lds = csrb_lds_bytes(s.N, s.M, DMAX, STAGED);   // lam, messages, the +inf and 0 cells, the next-frame cell (+ the staging area)
     static size_t attr_set = 0;
     if (lds > 64 * 1024 && lds > attr_set) {
         hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -834,7 +972,7 @@ static int launch_csr_batched(CsrState &s, hipStream_t st, CsrArgs &a) {
     }
     if (!a.step_mode) {
         // (all eight template arguments, as the assembly and rocprofv3 list the instance: bench.py finds its static instruction count by this name)
-        snprintf(s.info.name, sizeof(s.info.name), "ldpc::fused_csr_batched_kernel<%s, %d, %d, %d, %d, %d, %d, %d>", sizeof(CT) == 8 ? "double" : "float", VARIANT, DMAX, RPT, CPT, CD, THREADS, OSH);
+        snprintf(s.info.name, sizeof(s.info.name), "ldpc::fused_csr_batched_kernel<%s, %d, %d, %d, %d, %d, %d, %d, %s>", sizeof(CT) == 8 ? "double" : "float", VARIANT, DMAX, RPT, CPT, CD, THREADS, OSH, STAGED ? "true" : "false");
         s.info.threads = THREADS; s.info.frames_per_wg = 1;
     }
     // persistent workgroups: as many as are resident at once (LDPC_CSR_PERSIST=0: one workgroup per frame)

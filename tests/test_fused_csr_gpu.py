@@ -180,3 +180,33 @@ def test_tiny_circulant_qc_tanh_paths_agree(hip):
     assert all(np.array_equal(x, y) for x, y in zip(a, b)) and len(set(a[1].tolist())) > 2
     ob, oi, oc = oracle.decode_batch(c.graph, "tanh", 30, llr.astype(np.float64), nthreads=4)
     assert np.array_equal(a[0], ob) and np.array_equal(a[2].astype(bool), oc.astype(bool))
+
+
+@pytest.mark.parametrize("variant", ["min", "tanh"])
+def test_staged_instance_changes_nothing_but_speed(hip, monkeypatch, variant):
+    """f32 LLRs of a plain decode run the STAGED instance of the batched kernel: a workgroup holds the frame it decodes and the one
+    it decodes next, whose LLRs travel into LDS by LDS-DMA meanwhile; over the last ids of a batch nothing is held ahead.  Which
+    frame a workgroup takes when never enters the arithmetic: for batches below, at, just above and far above the number of resident
+    workgroups (768 on an MI355X for this code) every output equals that of the other instance (LDPC_CSR_STAGE=0), frame by frame,
+    and the oracle's on the frames compared with it."""
+    c = load("1920.1280.3.303")
+    code = _code(hip, c)
+    base = _frames(c, 20, (1.0, 2.5, 4.0), 4100).astype(np.float32)   # 60 frames
+    ob, oi, oc = oracle.decode_batch(c.graph, variant, 30, base[:24].astype(np.float64), nthreads=8)
+    for batch in (1, 7, 767, 768, 769, 1543, 3 * 768 + 5, 6000):
+        llr = np.tile(base, ((batch + len(base) - 1) // len(base), 1))[:batch]
+        outs = {}
+        for stage in ("1", "0"):
+            monkeypatch.setenv("LDPC_CSR_STAGE", stage)
+            d = hip.Decoder(code, variant, "f32", batch, path="fused")
+            outs[stage] = d.decode_batch(llr, 30)    # (float32 in: the host path that keeps the LLRs' format)
+            assert d.kernel_name.endswith(", 512, 0, true>" if stage == "1" else ", 512, 0, false>"), d.kernel_name
+            outs[stage + "again"] = d.decode_batch(llr, 30)      # the work counter starts over with every launch
+            d.close()
+        for k in ("0", "1again", "0again"):
+            assert all(np.array_equal(x, y) for x, y in zip(outs["1"], outs[k])), (batch, k)
+        n = min(batch, 24)
+        bits, its, conv = outs["1"]
+        assert np.array_equal(bits[:n], ob[:n]) and np.array_equal(conv[:n].astype(bool), oc[:n].astype(bool))
+        if batch > 60:   # the tiled frames repeat: so do their results, wherever in the batch and on whichever workgroup they ran
+            assert np.array_equal(bits[60:120], bits[:60][: len(bits[60:120])]) and np.array_equal(its[60:120], its[:60][: len(its[60:120])])

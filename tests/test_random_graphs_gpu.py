@@ -133,7 +133,7 @@ def test_large_frames_of_row_class_6_on_chip(hip, M, N, seed, variant):
     code = hip.Code.from_dense(H)
     on = hip.Decoder(code, variant, "f32", len(x), path="fused")
     a = on.decode_batch(x, 25)
-    assert on.kernel_name == f"ldpc::fused_csr_batched_kernel<float, {1 if variant == 'min' else 0}, 6, 6, 2, 18, 1024, 2>", on.kernel_name
+    assert on.kernel_name == f"ldpc::fused_csr_batched_kernel<float, {1 if variant == 'min' else 0}, 6, 6, 2, 18, 1024, 2, false>", on.kernel_name
     b = hip.Decoder(code, variant, "f32", len(x), path="flood").decode_batch(x, 25)
     assert all(np.array_equal(p, q) for p, q in zip(a, b))
     ob, oi, oc = oracle.decode_batch(g, variant, 25, x.astype(np.float64), nthreads=8)

@@ -71,7 +71,7 @@ def test_every_path_against_the_oracle(hip, variant):
         dec = hip.Decoder(code, variant, "f32", len(llr), path=path)
         outs[path] = dec.decode_batch(llr.astype(np.float32), 50, want_lam=True)
         if path == "fused":   # row degree class 6: lam + 6M message cells = 146 KB of LDS, one 1024-thread workgroup per CU
-            assert dec.kernel_name in (f"ldpc::fused_csr_batched_kernel<float, {1 if variant == 'min' else 0}, 6, 6, 2, 18, 1024, 2>",
+            assert dec.kernel_name in (f"ldpc::fused_csr_batched_kernel<float, {1 if variant == 'min' else 0}, 6, 6, 2, 18, 1024, 2, false>",
                                        f"ldpc::fused_csr_kernel<float, {1 if variant == 'min' else 0}, 6, 0, 0, 1024>"), dec.kernel_name
         if path == "auto":
             print(f"{NAME} {variant}: LDPC_PATH_AUTO -> {dec.path} ({dec.kernel_name}); frames the oracle decodes after turn 35: {int(late.sum())}, "

@@ -1,5 +1,7 @@
 """ctypes front-end of oracle/ldpc_oracle.c.  TEST INFRASTRUCTURE ONLY -- importable from tests/,
-__graft_entry__.smoke() and bench.py's cpu_baseline leg, never from ecc_ldpc_amd/."""
+__graft_entry__.smoke() and bench.py's cpu_baseline leg, never from ecc_ldpc_amd/.  (Four developer scripts under tools/ are
+checkers of the same kind and use it as tests do: gen_golden.py (SURVEY.md section 7 places it there), fuzz_qc.py (also run by
+tests/test_fuzz_qc_gpu.py), iters_f32_vs_f64.py and layered_f32_vs_f64.py (the measurements the test bars are set from).)"""
 from __future__ import annotations
 
 import ctypes as C

@@ -632,6 +632,7 @@ __global__ __launch_bounds__(THREADS, (DMAX <= 8 ? (THREADS > 512 ? 4 : THREADS 
 
 // ------------------------------------------------------------------ host side
 struct CsrState {
+    const void *attr_kern = nullptr; size_t attr_lds = 0;      // the kernel whose dynamic-LDS limit this context has raised, and to what
     const void *stage_kern = nullptr; bool stage_ok = false;   // batched kernel: whether the LLR staging area fits without costing a resident workgroup
     int variant = 0, dtype = 0, M = 0, N = 0, E = 0, dmax = 0, cdmax = 0, round16 = 0;
     bool want_batched = true, want_cache = true, want_wide = true;   // A/B switches, read from the environment once, at creation
@@ -910,11 +911,12 @@ template <typename CT, int VARIANT, int DMAX, int RPT, int CPT, int THREADS = kC
 static int launch_csr(CsrState &s, hipStream_t st, CsrArgs &a) {
     auto kern = fused_csr_kernel<CT, VARIANT, DMAX, RPT, CPT, THREADS>;
     const size_t lds = ((size_t)2 * s.N + (size_t)DMAX * s.M) * sizeof(CT);
-    static size_t attr_set = 0;
-    if (lds > 64 * 1024 && lds > attr_set) {
+    // (remembered per context, not per process: the attribute belongs to the function ON ONE DEVICE, and a process may hold contexts
+    //  on several -- ecc-ldpc-hip -d0,1,.. runs one thread per GPU)
+    if (lds > 64 * 1024 && (s.attr_kern != (const void *)kern || lds > s.attr_lds)) {
         hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return set_error(LDPC_EHIP, "hipFuncSetAttribute(%zu B LDS): %s", lds, hipGetErrorString(e));
-        attr_set = lds;
+        s.attr_kern = (const void *)kern; s.attr_lds = lds;
     }
     if (!a.step_mode) {
         snprintf(s.info.name, sizeof(s.info.name), "ldpc::fused_csr_kernel<%s, %d, %d, %d, %d, %d>", sizeof(CT) == 8 ? "double" : "float", VARIANT, DMAX, RPT, CPT, THREADS);
@@ -964,11 +966,12 @@ template <typename CT, int VARIANT, int DMAX, int RPT, int CPT, int CD, int THRE
 static int launch_csr_batched_as(CsrState &s, hipStream_t st, CsrArgs &a) {
     auto kern = fused_csr_batched_kernel<CT, VARIANT, DMAX, RPT, CPT, CD, THREADS, OSH, STAGED>;
     const size_t lds = csrb_lds_bytes(s.N, s.M, DMAX, STAGED);   // lam, messages, the +inf and 0 cells, the next-frame cell (+ the staging area)
-    static size_t attr_set = 0;
-    if (lds > 64 * 1024 && lds > attr_set) {
+    // (remembered per context, not per process: the attribute belongs to the function ON ONE DEVICE, and a process may hold contexts
+    //  on several -- ecc-ldpc-hip -d0,1,.. runs one thread per GPU)
+    if (lds > 64 * 1024 && (s.attr_kern != (const void *)kern || lds > s.attr_lds)) {
         hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return set_error(LDPC_EHIP, "hipFuncSetAttribute(%zu B LDS): %s", lds, hipGetErrorString(e));
-        attr_set = lds;
+        s.attr_kern = (const void *)kern; s.attr_lds = lds;
     }
     if (!a.step_mode) {
         // (all eight template arguments, as the assembly and rocprofv3 list the instance: bench.py finds its static instruction count by this name)

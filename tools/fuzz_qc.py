@@ -3,7 +3,7 @@
 flood path on random single-circulant protographs: circulant sizes that are and are not powers of two, 2..16 block rows,
 row weights 2..24, punctured-looking weight-1 columns included.  Both paths implement the same decoder; for f32 they must
 agree bit for bit (hard bits, iteration counts, converged flags); so must the kernels of the row-layered schedule (two from HBM,
-r03: one on-chip), and the packed-fp16 kernels (r03) reproduce their emulation bit for bit.  Usage: python tools/fuzz_qc.py [n_codes] [first_seed]
+r03: one on-chip), and the packed-fp16 kernels (r03) reproduce their emulation bit for bit.  Usage: python tools/fuzz_qc.py [n_codes] [first_seed] [r04 = only the kinds added in round 4]
 Prints one line per (code, rule); exit status 1 on the first disagreement."""
 import os
 import sys
@@ -74,9 +74,43 @@ def fuzz_r03_kinds(c, code, llr, hbm_layered, hbm_result):
     return bad
 
 
+def fuzz_r04_kinds(c, llr):
+    """r04: the code given as a plain CSR graph -- the generic on-chip kernel (its STAGED instance: f32 LLRs travel into LDS a frame
+    ahead) against the batch-major HBM pair, bit for bit; layered min-sum with fp16 lam on-chip and streamed row records against
+    its emulation (oracle/emulate_f16.py decode_minsum_f16_layered) on the first and last frames"""
+    from oracle import emulate_f16 as em
+    bad = 0
+    F = len(llr)
+    plain = E.Code.from_csr(c.graph.row_ptr, c.graph.col_idx, c.N)
+    for rule in ("min", "tanh"):
+        try:
+            on = E.Decoder(plain, rule, "f32", F, path="fused")
+        except E.LdpcError as e:
+            print(f"{'':26s} {rule:4s} as CSR: no on-chip kernel ({str(e)[:50]}...)", flush=True)
+            continue
+        fl = E.Decoder(plain, rule, "f32", F, path="flood")
+        a, b = on.decode_batch(llr, 30), fl.decode_batch(llr, 30)
+        same = all(np.array_equal(x, y) for x, y in zip(a, b))
+        print(f"{'':26s} {rule:4s} as CSR  {on.kernel_name[:66]:66s} vs {fl.kernel_name[:16]:16s} {'ok' if same else 'MISMATCH'}", flush=True)
+        bad += 0 if same else 1
+        del on, fl
+    try:
+        lds = E.Decoder(c.hip_code(E), "min", "f16", F, schedule="layered", path="flood")
+    except E.LdpcError as e:
+        print(f"{'':26s} min  layered f16: no kernel ({str(e)[:60]}...)", flush=True)
+        return bad
+    sub = np.concatenate([llr[:5], llr[-5:]])
+    got = lds.decode_batch(sub, 30)
+    eb, ei, ec, _ = em.decode_minsum_f16_layered(c.graph, sub, 30)
+    same = np.array_equal(got[0], eb) and np.array_equal(got[1], ei) and np.array_equal(got[2].astype(bool), ec)
+    print(f"{'':26s} min  layered f16 {lds.kernel_name[:40]:40s} vs emulation: converged {ec.mean():.2f} mean sweeps {ei.mean():5.1f} {'ok' if same else 'MISMATCH'}", flush=True)
+    return bad + (0 if same else 1)
+
+
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 16
     first = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
+    only_r04 = len(sys.argv) > 3 and sys.argv[3] == "r04"
     E.init(0)
     F, bad = 192, 0
     for seed in range(first, first + n):
@@ -85,6 +119,10 @@ def main():
             continue
         code = c.hip_code(E)
         llr = np.concatenate([c.frames(F // 2, 2.5, seed)[1], c.frames(F // 2, 6.0, seed + 1)[1]]).astype(np.float32)
+        if only_r04:   # (the kernels of r04_kinds are built in: no run-time compilation, hundreds of codes in minutes)
+            print(f"{c.name:26s} rows {c.offsets.shape[0]:2d} max row weight {int((c.offsets >= 0).sum(1).max()):2d}", flush=True)
+            bad += fuzz_r04_kinds(c, llr)
+            continue
         for rule in ("min", "tanh"):
             t0 = time.time()
             try:
@@ -122,6 +160,7 @@ def main():
             if rule == "min":
                 bad += fuzz_r03_kinds(c, code, llr, qc, a)
             del qc
+        bad += fuzz_r04_kinds(c, llr)
     print("fuzz:", "FAILED" if bad else "all equal")
     return 1 if bad else 0
 

@@ -9,11 +9,11 @@ set -o pipefail
 tag=$1; shift
 out=$PWD/gpurun_out/prof_$tag; mkdir -p $out
 export TMPDIR=/tmp
-args="--cpu-seconds 0 --proof 0 --steps 4 --warmup 2 $*"
+args="--cpu-seconds 0 --proof 0 --fp16-leg 0 --steps 4 --warmup 2 $*"   # (--fp16-leg 0: only the workload named, so that "the dominant kernel" is its kernel)
 # one UNPROFILED run first: whatever the workload needs from the tool chain (a run-time specialised kernel's code object,
 # its <kernel>.isa.json) is built and cached now, so no hipcc child is ever started under the profiler's preload
 echo "[profile] warm the caches (unprofiled)" >&2
-python3 bench.py --cpu-seconds 0 --proof 0 --steps 1 --warmup 0 $* > /dev/null 2> $out/warm.log || { tail -5 $out/warm.log; exit 1; }
+python3 bench.py --cpu-seconds 0 --proof 0 --fp16-leg 0 --steps 1 --warmup 0 $* > /dev/null 2> $out/warm.log || { tail -5 $out/warm.log; exit 1; }
 echo "[profile] kernel trace" >&2
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt -o kt -- python3 bench.py $args > $out/${tag}_bench_under_rocprof.json 2> $out/kt.log || { tail -5 $out/kt.log; exit 1; }
 cp $(find $out/kt -name '*kernel_stats.csv' | head -1) $out/${tag}_kernel_stats.csv

@@ -41,9 +41,10 @@ struct LdsDev {
     const int32_t *tab;             // per circulant, block-row-major: {A = 2 * (block column * sz + rotation), thr = sz - rotation}:
                                     // row r reads the half word at byte A + 2 r - (r >= thr ? 2 sz : 0)
     const int32_t *lbeg;            // [nbr + 1] first circulant of each block row
-    // the pipelined instances: consecutive block rows that share no block column form a GROUP and are run together, each by its own
-    // ceil(sz / 64) waves (`tl` threads): their rows touch distinct lam cells, so the result is that of running them one after the
-    // other.  ng groups of up to gsz block rows; slot s = group * gsz + sub.
+    // the pipelined instances: consecutive block rows that share no block column form a GROUP and are run together: their rows touch
+    // distinct lam cells, so the result is that of running them one after the other.  A block row is run by ceil(sz / 64) waves (`tl`
+    // threads, one "sub"); a sub runs RW block rows of a group one after the other WITHOUT a barrier in between (kernel template
+    // argument; the workgroup meets once per group).  ng groups of gsz slots; slot s = group * gsz + sub * RW + w, w < RW.
     int ng, gsz, tl;
     const int32_t *gtab;            // [ng * gsz][kLtab] per slot: {first circulant, weight (0: no block row in this slot), block row, -, the first
                                     // 8 circulants' {A, thr}}; copied to LDS behind lam, read one group ahead of its use
@@ -224,8 +225,13 @@ __device__ __forceinline__ void load_ltab(uint32_t ltab0, int layer, int &e0, in
 // hand-counted wait (ecc_ldpc_amd/build.py refuses a build in which one does).  Rows above weight 8 keep up to 27 addresses, LLRs and
 // differences per lane: those instances are built for at most 512 threads (256 registers per lane).
 constexpr int lds_max_threads(int dclass, int p) { return (p > 0 && dclass > 8) ? 512 : 1024; }
-template <int DCLASS, int P>
+// RW (pipelined instances): block rows of a group per sub.  One barrier per group is the kernel's fixed cost: every wave issues its
+// gathers right behind it and the vector units idle until the first answers are back.  With RW = 2 a group holds twice the rows for
+// the same number of waves, the second row's gathers are issued while the other waves of the SIMD still compute their first, and the
+// barriers per sweep halve.
+template <int DCLASS, int P, int RW = 1>
 __global__ __launch_bounds__(lds_max_threads(DCLASS, P)) void layered_lds_kernel(LdsDev g, LdsRec *rec_all, LdsArgs A) {
+    static_assert(P == 0 ? RW == 1 : P % RW == 0, "a record slot in flight per row of a sub");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     _Float16 *lam = reinterpret_cast<_Float16 *>(smem);
     // [0] next frame; [1..3] "sweep n moved" at 1 + n % 3 (cleared by thread 0 two sweeps before its use: every thread has
@@ -276,7 +282,8 @@ __global__ __launch_bounds__(lds_max_threads(DCLASS, P)) void layered_lds_kernel
         int n = 0;
         {   // syndrome of the hard decisions before the first sweep
             bool odd = false;
-            for (int l = (P > 0 ? sub : 0); l < nslot; l += (P > 0 ? g.gsz : 1)) {     // (P > 0: l runs over this wave's slots)
+            for (int l0 = (P > 0 ? sub * RW : 0); l0 < nslot; l0 += (P > 0 ? g.gsz : 1))     // (P > 0: this wave's slots)
+            for (int l = l0; l < l0 + RW; l++) {
                 bool par = false;
                 if constexpr (P > 0) {      // graph entries from the copy in LDS: eight gathers in flight
                     int e0, deg, tb[16];
@@ -345,17 +352,23 @@ __global__ __launch_bounds__(lds_max_threads(DCLASS, P)) void layered_lds_kernel
             for (int j = 0; j < P; j++) q[j] = u32x3{0u, 0u, 0u};
             static_assert(P % 2 == 0, "the graph entries alternate between two register sets");
             // byte offsets of this wave's record slots inside the workgroup's area: where group gi stores, where group gi + P loads from
-            const uint32_t gstep = (uint32_t)g.gsz * (uint32_t)TL * (uint32_t)sizeof(LdsRec), gend = gstep * (uint32_t)g.ng;
-            const uint32_t voff = (uint32_t)sub * (uint32_t)TL * (uint32_t)sizeof(LdsRec) + (uint32_t)tin * (uint32_t)sizeof(LdsRec);
-            uint32_t soff = 0, loff = gstep * (uint32_t)P;       // (P < ng)
+            const uint32_t rstep = (uint32_t)TL * (uint32_t)sizeof(LdsRec);                  // one slot
+            const uint32_t gstep = (uint32_t)g.gsz * rstep, gend = gstep * (uint32_t)g.ng;   // one group, one sweep
+            const uint32_t voff = (uint32_t)(sub * RW) * rstep + (uint32_t)tin * (uint32_t)sizeof(LdsRec);
+            uint32_t soff = 0, loff = gstep * (uint32_t)(P / RW);       // (P / RW < ng)
             // (forming the NEXT group's LDS addresses before the barrier, from these entries, was measured: 59.9 vs 58.3 ms per 16 384 frames --
             //  the arithmetic lengthens the slowest wave's way to the barrier instead of hiding behind the other waves' gathers; not kept)
+            // (tried with RW = 2: the three waves of a SIMD at three priorities (s_setprio), so that they drift apart and one wave's gathers
+            //  fall behind another's arithmetic -- no difference, 108.7 ms either way: the vector units are busy ~80 % of the launch by the
+            //  counters, what is left is not the waves meeting at the barrier)
             int gi = 0, e0v[2], degv[2], tbv[2][16];             // gi: the group being run; this wave's slot is gi * gsz + sub
             bool odd = false, flip = false;
             n = 1;
-            load_ltab(ltab0, sub, e0v[0], degv[0], tbv[0]);
-            auto group_step = [&](auto J) -> bool {     // -> the frame is finished
+            load_ltab(ltab0, sub * RW, e0v[0], degv[0], tbv[0]);
+            auto group_step = [&](auto J) -> bool {     // one slot of this sub -> the frame is finished
                 constexpr int j = decltype(J)::value, cur = j & 1, nxt = cur ^ 1;
+                constexpr int w = j % RW;               // which of the sub's block rows in the group (P is a multiple of RW)
+                constexpr bool group_done = w == RW - 1;
                 LDPC_TURN_LOOP();
                 const int gn = (gi + 1 == g.ng) ? 0 : gi + 1;
                 rec_wait<2 * P - 1>(q[j]);
@@ -364,22 +377,26 @@ __global__ __launch_bounds__(lds_max_threads(DCLASS, P)) void layered_lds_kernel
                 rec_load(q[j], voff + loff, wbase);
                 LdsRec out = in;
                 const int deg = __builtin_amdgcn_readfirstlane(degv[cur]);
-                auto next = [&]() { load_ltab(ltab0, gn * g.gsz + sub, e0v[nxt], degv[nxt], tbv[nxt]); };
+                auto next = [&]() { load_ltab(ltab0, (group_done ? gn : gi) * g.gsz + sub * RW + (group_done ? 0 : w + 1), e0v[nxt], degv[nxt], tbv[nxt]); };
                 if (deg > 0) lds_layer_at<DCLASS, false>(g, in, out, __builtin_amdgcn_readfirstlane(e0v[cur]), deg, tbv[cur], r, rb, rw, odd, flip, next);
                 else next();                            // (no block row for this wave in this group: it only keeps the counts)
                 rec_store(u32x3{__float_as_uint(out.c1), __float_as_uint(out.c2), out.meta}, voff + soff, wbase);
-                soff += gstep; soff -= soff >= gend ? gend : 0u;
-                loff += gstep; loff -= loff >= gend ? gend : 0u;
-                const bool last = gi == g.ng - 1;
-                if (last && __builtin_amdgcn_ballot_w64(odd || flip) != 0 && (tid & 63) == 0) ctl[1 + n % 3] = 1;
-                lds_barrier();
                 bool fin = false;
-                if (last) {
-                    if (ctl[1 + n % 3] == 0) { conv = true; fin = true; }
-                    else if (n == A.max_iters) fin = true;
-                    else { n++; odd = false; flip = false; if (tid == 0) ctl[1 + (n + 1) % 3] = 0; }   // (that flag was last read a sweep ago)
+                if constexpr (!group_done) {            // the sub's next block row of the same group: no other wave touches its cells
+                    soff += rstep; loff += rstep;
+                } else {
+                    soff += gstep - (uint32_t)(RW - 1) * rstep; soff -= soff >= gend ? gend : 0u;
+                    loff += gstep - (uint32_t)(RW - 1) * rstep; loff -= loff >= gend ? gend : 0u;
+                    const bool last = gi == g.ng - 1;
+                    if (last && __builtin_amdgcn_ballot_w64(odd || flip) != 0 && (tid & 63) == 0) ctl[1 + n % 3] = 1;
+                    lds_barrier();
+                    if (last) {
+                        if (ctl[1 + n % 3] == 0) { conv = true; fin = true; }
+                        else if (n == A.max_iters) fin = true;
+                        else { n++; odd = false; flip = false; if (tid == 0) ctl[1 + (n + 1) % 3] = 0; }   // (that flag was last read a sweep ago)
+                    }
+                    gi = gn;
                 }
-                gi = gn;
                 return fin;
             };
             for (;;) {
@@ -433,7 +450,7 @@ __global__ __launch_bounds__(lds_max_threads(DCLASS, P)) void layered_lds_kernel
 // ------------------------------------------------------------------ host side
 struct LayeredLdsState {
     int max_batch = 0, max_row_deg = 0, threads = 0, nbr = 0, grid = 0, prefetch = 0;   // threads: of ONE block row (tl)
-    int ng = 0, gsz = 1, nslot = 0;                // groups of block rows run together (pipelined instances)
+    int ng = 0, gsz = 1, nslot = 0, rw = 1;        // groups of block rows run together (pipelined instances); rw: block rows of a group per sub
     size_t lds = 0;
     LdsDev g{};
     int32_t *d_tab = nullptr, *d_lbeg = nullptr, *d_ltab = nullptr;
@@ -464,10 +481,11 @@ void layered_lds_destroy(LayeredLdsState *s) {
     delete s;
 }
 
-template <int DCLASS, int P> static const void *kernel_ptr() { return (const void *)layered_lds_kernel<DCLASS, P>; }
-static const void *pick_kernel(int dclass, int p) {
-    if (p == 0) return dclass == 8 ? kernel_ptr<8, 0>() : dclass == 20 ? kernel_ptr<20, 0>() : kernel_ptr<32, 0>();
-    return dclass == 8 ? kernel_ptr<8, 4>() : dclass == 20 ? kernel_ptr<20, 4>() : kernel_ptr<32, 4>();
+template <int DCLASS, int P, int RW> static const void *kernel_ptr() { return (const void *)layered_lds_kernel<DCLASS, P, RW>; }
+static const void *pick_kernel(int dclass, int p, int rw) {
+    if (p == 0) return dclass == 8 ? kernel_ptr<8, 0, 1>() : dclass == 20 ? kernel_ptr<20, 0, 1>() : kernel_ptr<32, 0, 1>();
+    if (rw == 2) return dclass == 8 ? kernel_ptr<8, 4, 2>() : dclass == 20 ? kernel_ptr<20, 4, 2>() : kernel_ptr<32, 4, 2>();
+    return dclass == 8 ? kernel_ptr<8, 4, 1>() : dclass == 20 ? kernel_ptr<20, 4, 1>() : kernel_ptr<32, 4, 1>();
 }
 
 LayeredLdsState *layered_lds_create(const ldpc_code &c, int variant, int dtype, int max_batch) {
@@ -492,9 +510,9 @@ LayeredLdsState *layered_lds_create(const ldpc_code &c, int variant, int dtype, 
         const char *ge = getenv("LDPC_LAYERED_LDS_GROUPS");             // =0: one block row at a time (A/B)
         const int dclass = c.max_row_deg <= 8 ? 8 : (c.max_row_deg <= 20 ? 20 : 32);
         const int tmax = lds_max_threads(dclass, 4);                    // what the pipelined instance of this row class is built for
-        const int gcap = (ge && !strcmp(ge, "0")) ? 1 : std::max(1, std::min(4, tmax / s->threads));
-        std::vector<std::vector<int>> groups;
-        {
+        const bool no_groups = ge && !strcmp(ge, "0");
+        auto groups_of = [&](int gcap) {
+            std::vector<std::vector<int>> groups;
             std::vector<char> used((size_t)c.block_cols, 0);
             for (int br = 0; br < c.block_rows; br++) {
                 bool clash = groups.empty() || (int)groups.back().size() >= gcap;
@@ -503,9 +521,25 @@ LayeredLdsState *layered_lds_create(const ldpc_code &c, int variant, int dtype, 
                 groups.back().push_back(br);
                 for (int bc = 0; bc < c.block_cols; bc++) if (c.offsets[(size_t)br * c.block_cols + bc] >= 0) used[bc] = 1;
             }
+            return groups;
+        };
+        // one block row per sub and as many subs as the threads allow -- or, where that leaves groups of fewer than four, two block
+        // rows per sub (RW = 2: twice the rows between two barriers for the same waves), if the matrix's order then yields a quarter
+        // fewer groups (LDPC_LAYERED_LDS_RW=1|2 forces one form: A/B, tests)
+        const int subs_max = std::max(1, tmax / s->threads);
+        std::vector<std::vector<int>> groups = groups_of(no_groups ? 1 : std::min(4, subs_max));
+        s->rw = 1;
+        {
+            const char *re = getenv("LDPC_LAYERED_LDS_RW");
+            const int want = re ? atoi(re) : 0;
+            if (!no_groups && want != 1 && (subs_max < 4 || want == 2)) {
+                std::vector<std::vector<int>> g2 = groups_of(std::min(4, 2 * subs_max));
+                if (want == 2 || 4 * g2.size() <= 3 * groups.size()) { groups.swap(g2); s->rw = 2; }
+            }
         }
         s->ng = (int)groups.size(); s->gsz = 1;
         for (auto &gr : groups) s->gsz = std::max(s->gsz, (int)gr.size());
+        s->gsz = (s->gsz + s->rw - 1) / s->rw * s->rw;       // whole subs
         s->nslot = s->ng * s->gsz;
         std::vector<int32_t> gtab((size_t)s->nslot * kLtab, 0);
         for (int gi = 0; gi < s->ng; gi++)
@@ -522,16 +556,17 @@ LayeredLdsState *layered_lds_create(const ldpc_code &c, int variant, int dtype, 
         // (more groups than records in flight: the record requested for group gi + P -- of the next sweep when that wraps -- must have been
         //  stored already in this sweep, so gi + P - ng < gi)
         s->prefetch = (s->ng > 4 && lds_pipe <= 160 * 1024 && s->threads <= tmax && !(pe && !strcmp(pe, "0"))) ? 4 : 0;
-        if (s->prefetch) s->lds = lds_pipe; else { s->gsz = 1; s->nslot = c.block_rows; }
-        const void *kern = pick_kernel(dclass, s->prefetch);
+        if (s->prefetch) s->lds = lds_pipe; else { s->gsz = 1; s->rw = 1; s->nslot = c.block_rows; }
+        const int subs = s->gsz / s->rw;                                // threads of a workgroup = subs * threads of a block row
+        const void *kern = pick_kernel(dclass, s->prefetch, s->rw);
         hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->lds);
-        if (e == hipSuccess && s->prefetch) e = hipFuncSetAttribute(pick_kernel(dclass, 0), hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->lds);   // (traces)
+        if (e == hipSuccess && s->prefetch) e = hipFuncSetAttribute(pick_kernel(dclass, 0, 1), hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->lds);   // (traces)
         int per_cu = 0, dev = 0;
         hipDeviceProp_t prop;
         if (e == hipSuccess) e = hipGetDevice(&dev);
         if (e == hipSuccess) e = hipGetDeviceProperties(&prop, dev);
-        if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, s->threads * s->gsz, s->lds);
-        if (e == hipSuccess && per_cu <= 0) { set_error(LDPC_EHIP, "layered_lds: no workgroup of %d threads and %zu B of LDS is resident", s->threads * s->gsz, s->lds); layered_lds_destroy(s); return nullptr; }
+        if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, s->threads * subs, s->lds);
+        if (e == hipSuccess && per_cu <= 0) { set_error(LDPC_EHIP, "layered_lds: no workgroup of %d threads and %zu B of LDS is resident", s->threads * subs, s->lds); layered_lds_destroy(s); return nullptr; }
         if (e == hipSuccess) s->grid = std::min(max_batch, per_cu * prop.multiProcessorCount);
         if (e == hipSuccess) e = hipMalloc((void **)&s->d_tab, sizeof(int32_t) * std::max<size_t>(tab.size(), 2));
         if (e == hipSuccess) e = hipMalloc((void **)&s->d_lbeg, sizeof(int32_t) * lbeg.size());
@@ -548,8 +583,8 @@ LayeredLdsState *layered_lds_create(const ldpc_code &c, int variant, int dtype, 
             return nullptr;
         }
         s->g.tab = s->d_tab; s->g.lbeg = s->d_lbeg; s->g.gtab = s->d_ltab;
-        snprintf(s->info.name, sizeof(s->info.name), "ldpc::layered_lds_kernel<%d, %d>", dclass, s->prefetch);
-        s->info.threads = s->threads * s->gsz; s->info.frames_per_wg = 1;
+        snprintf(s->info.name, sizeof(s->info.name), "ldpc::layered_lds_kernel<%d, %d, %d>", dclass, s->prefetch, s->rw);
+        s->info.threads = s->threads * subs; s->info.frames_per_wg = 1;
         return s;
     } catch (...) { layered_lds_destroy(s); set_error(LDPC_ENOMEM, "out of host memory"); return nullptr; }
 }
@@ -565,12 +600,13 @@ int layered_lds_decode(LayeredLdsState &s, hipStream_t st, int max_iters, int ba
     hipError_t e = hipMemsetAsync(s.d_counter, 0, sizeof(int), st);
     if (e != hipSuccess) return set_error(LDPC_EHIP, "layered_lds: %s", hipGetErrorString(e));
     const bool simple = s.prefetch == 0 || d_trace;      // one block row at a time, waits left to the compiler; writes traces
-    const dim3 grid(std::min(batch, s.grid)), block(simple ? s.threads : s.threads * s.gsz);
+    const dim3 grid(std::min(batch, s.grid)), block(simple ? s.threads : s.threads * (s.gsz / s.rw));
     const int dclass = s.max_row_deg <= 8 ? 8 : (s.max_row_deg <= 20 ? 20 : 32);
     if (s.timer) s.timer->begin(st);
-#define LDS_LAUNCH(D, PF) hipLaunchKernelGGL((layered_lds_kernel<D, PF>), grid, block, s.lds, st, s.g, s.rec, a)
-    if (simple) { if (dclass == 8) LDS_LAUNCH(8, 0); else if (dclass == 20) LDS_LAUNCH(20, 0); else LDS_LAUNCH(32, 0); }
-    else { if (dclass == 8) LDS_LAUNCH(8, 4); else if (dclass == 20) LDS_LAUNCH(20, 4); else LDS_LAUNCH(32, 4); }
+#define LDS_LAUNCH(D, PF, RW) hipLaunchKernelGGL((layered_lds_kernel<D, PF, RW>), grid, block, s.lds, st, s.g, s.rec, a)
+    if (simple) { if (dclass == 8) LDS_LAUNCH(8, 0, 1); else if (dclass == 20) LDS_LAUNCH(20, 0, 1); else LDS_LAUNCH(32, 0, 1); }
+    else if (s.rw == 2) { if (dclass == 8) LDS_LAUNCH(8, 4, 2); else if (dclass == 20) LDS_LAUNCH(20, 4, 2); else LDS_LAUNCH(32, 4, 2); }
+    else { if (dclass == 8) LDS_LAUNCH(8, 4, 1); else if (dclass == 20) LDS_LAUNCH(20, 4, 1); else LDS_LAUNCH(32, 4, 1); }
 #undef LDS_LAUNCH
     if (s.timer) s.timer->end(st);
     e = hipGetLastError();

@@ -203,7 +203,16 @@ def test_staged_instance_changes_nothing_but_speed(hip, monkeypatch, variant):
             assert d.kernel_name.endswith(", 512, 0, true>" if stage == "1" else ", 512, 0, false>"), d.kernel_name
             outs[stage + "again"] = d.decode_batch(llr, 30)      # the work counter starts over with every launch
             d.close()
-        for k in ("0", "1again", "0again"):
+        if batch == 1543:   # the other ways frames are handed out: a fixed stride instead of the work counter, one workgroup per frame
+            monkeypatch.setenv("LDPC_CSR_STAGE", "1")
+            for var in ("LDPC_CSR_DYNAMIC", "LDPC_CSR_PERSIST"):
+                monkeypatch.setenv(var, "0")
+                d = hip.Decoder(code, variant, "f32", batch, path="fused")
+                outs[var] = d.decode_batch(llr, 30)
+                assert d.kernel_name.endswith(", 512, 0, true>")
+                d.close()
+                monkeypatch.delenv(var)
+        for k in outs:
             assert all(np.array_equal(x, y) for x, y in zip(outs["1"], outs[k])), (batch, k)
         n = min(batch, 24)
         bits, its, conv = outs["1"]

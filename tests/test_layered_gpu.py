@@ -240,7 +240,7 @@ def test_fp16_lam_storage_from_hbm(hip, name, F, dbs, monkeypatch):
     monkeypatch.setenv("LDPC_LAYERED_LDS_PREFETCH", "0")                      # records loaded where they are used: the same decoder
     nopf = hip.Decoder(c.hip_code(hip), "min", "f16", F, schedule="layered", path="flood")
     monkeypatch.delenv("LDPC_LAYERED_LDS_PREFETCH")
-    assert nopf.kernel_name.endswith(", 0>") and dec.kernel_name.endswith(", 4>"), (nopf.kernel_name, dec.kernel_name)
+    assert nopf.kernel_name.endswith(", 0, 1>") and ", 4, " in dec.kernel_name, (nopf.kernel_name, dec.kernel_name)
     assert all(np.array_equal(x, y) for x, y in zip(nopf.decode_batch(llr, 30, want_lam=True), (bits, its, conv, lam)))
     for nf in (1, 2, 3):                                                      # small batches
         b1 = dec.decode_batch(llr[:nf], 30)
@@ -285,6 +285,14 @@ def test_fp16_lam_storage_other_shapes(hip, name, monkeypatch):
     assert all(np.array_equal(x, y) for x, y in zip(one.decode_batch(llr, 25, want_lam=True), (bits, its, conv, lam)))
     if name.startswith("latin"):                                              # groups were formed: more threads than one block row has
         assert dec.kernel_geometry[0] > one.kernel_geometry[0], (dec.kernel_geometry, one.kernel_geometry)
+    for rw in ("1", "2"):                                                     # one / two block rows of a group per set of waves: the same results
+        monkeypatch.setenv("LDPC_LAYERED_LDS_RW", rw)
+        d = hip.Decoder(c.hip_code(hip), "min", "f16", F, schedule="layered", path="flood")
+        out = d.decode_batch(llr, 25, want_lam=True)
+        assert d.kernel_name.endswith(f", {rw}>") or d.kernel_name.endswith(", 0, 1>"), d.kernel_name
+        assert all(np.array_equal(x, y) for x, y in zip(out, (bits, its, conv, lam))), (name, rw, d.kernel_name)
+        d.close()
+    monkeypatch.delenv("LDPC_LAYERED_LDS_RW")
     dec.close(); hbm.close(); one.close()
 
 
@@ -295,7 +303,7 @@ def test_fp16_lam_on_chip_long_code(hip):
     from oracle import emulate_f16 as em, channel
     ecc = hip.ECC(CODES, "ldpc/hip-minsum-layered-f16/dvbs2like.64800.1.2/50", max_batch=600)
     dec = ecc.decoder
-    assert dec.schedule == "layered" and dec.path == "flood" and "layered_lds_kernel<8, 4>" in dec.kernel_name, dec.kernel_name
+    assert dec.schedule == "layered" and dec.path == "flood" and "layered_lds_kernel<8, 4, 2>" in dec.kernel_name, dec.kernel_name
     rp, ci = ecc.code.csr()
     g = oracle.Graph(rp, ci, ecc.code.N)
     llr = np.concatenate([channel.frames(np.zeros((3, g.N), np.uint8), db, 32400, 64800, g.N, seed=30 + i) for i, db in enumerate((1.0, 1.5, 2.0))]).astype(np.float32)
@@ -307,7 +315,7 @@ def test_fp16_lam_on_chip_long_code(hip):
     assert np.array_equal(bits, eb[order]) and np.array_equal(its, ei[order]) and np.array_equal(conv.astype(bool), ec[order])
     assert np.array_equal(lam, el[order].astype(np.float64))
     assert 0 < ec.sum() < len(llr)
-    assert dec.kernel_geometry[0] == 768                                       # two block rows (6 waves each) at a time
+    assert dec.kernel_geometry[0] == 768                                       # four block rows at a time: two sets of 6 waves, two rows each
     f32 = hip.Decoder(ecc.code, "min", "f32", 9, schedule="layered").decode_batch(llr, 20)
     both = ec & f32[2].astype(bool)
     assert both.any() and np.array_equal(eb[both], f32[0][both])

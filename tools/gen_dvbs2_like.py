@@ -8,9 +8,9 @@ this container, so the rotations and the placement of the information circulants
 most one circulant per block, 4-cycles between information circulants avoided): same size, degree profile and memory
 behaviour as the real code, NOT its BER.  It is not the standard's matrix and must not be used as such.
 No generator is written (a dense G would be 131 MB); frames are the all-zero codeword.
-r04: the block rows are written in an order in which consecutive PAIRS share no block column (pair_order below), the way layered
-hardware decoders schedule such codes: a layered decoder visits the block rows in the order of the file, and two block rows that
-touch distinct columns can be worked on together without changing any result (csrc/layered_lds.hip does).  Same matrix up to a
+r04: the block rows are written in an order in which runs of FOUR consecutive rows share no block column (group_order below), the
+way layered hardware decoders schedule such codes: a layered decoder visits the block rows in the order of the file, and block rows
+that touch distinct columns can be worked on together without changing any result (csrc/layered_lds.hip does).  Same matrix up to a
 permutation of its rows, same code.
   python tools/gen_dvbs2_like.py [--check]"""
 import os
@@ -72,33 +72,36 @@ def build(seed=0x0D5B2):
     return off.astype(np.int32)
 
 
-def pair_order(off):
-    """permutation of the block rows: as many consecutive pairs (2i, 2i+1) as possible share no block column (greedy matching:
-    the row with the fewest partners left picks its partner with the fewest partners left); unmatched rows go last"""
+def group_order(off, gmax=4):
+    """permutation of the block rows into runs of up to `gmax` consecutive rows that pairwise share no block column (greedy: start a
+    run with the row that has the fewest compatible rows left, extend it with the row compatible with all of the run that has the
+    fewest compatible rows left); full runs first, shorter ones after them"""
     Q = off.shape[0]
     hit = off >= 0
     ok = ~((hit[:, None, :] & hit[None, :, :]).any(axis=2))
     np.fill_diagonal(ok, False)
     free = set(range(Q))
-    pairs = []
-    while True:
-        cand = [(sum(1 for j in free if ok[i, j]), i) for i in free]
-        cand = [(c, i) for c, i in cand if c > 0]
-        if not cand:
-            break
-        _, i = min(cand)
-        j = min((sum(1 for k in free if ok[j, k]), j) for j in free if ok[i, j])[1]
-        pairs.append((min(i, j), max(i, j)))
-        free -= {i, j}
-    order = [r for pr in sorted(pairs) for r in pr] + sorted(free)
-    return np.array(order), len(pairs)
+    runs = []
+    while free:
+        deg = {i: sum(1 for j in free if ok[i, j]) for i in free}
+        run = [min(free, key=lambda i: (deg[i], i))]
+        free.discard(run[0])
+        while len(run) < gmax:
+            cand = [j for j in free if all(ok[i, j] for i in run)]
+            if not cand:
+                break
+            j = min(cand, key=lambda j: (deg[j], j))
+            run.append(j); free.discard(j)
+        runs.append(sorted(run))
+    runs.sort(key=lambda r: (-len(r), r))
+    return np.array([r for run in runs for r in run]), [len(r) for r in runs]
 
 
 def main():
     off = build()
-    order, npairs = pair_order(off)
+    order, sizes = group_order(off)
     off = off[order]
-    print(f"block rows reordered: {npairs} independent consecutive pairs, {off.shape[0] - 2 * npairs} single")
+    print(f"block rows reordered into runs of independent rows: sizes {sorted(set(sizes), reverse=True)} x {[sizes.count(z) for z in sorted(set(sizes), reverse=True)]}")
     out = os.path.join(ROOT, "codes", "dvbs2like.64800.1.2")
     os.makedirs(out, exist_ok=True)
     lines = [str(SZ)]
@@ -109,8 +112,8 @@ def main():
         "SYNTHETIC matrix with the shape of the DVB-S2 rate-1/2 normal-frame LDPC code (n = 64800, k = 32400, period 360).\n"
         "Generated by tools/gen_dvbs2_like.py (fixed seed); NOT the ETSI EN 302 307 matrix -- the standard's address tables are\n"
         "not available here.  No generator matrix: frames are the all-zero codeword.\n"
-        "Block rows are written in an order in which consecutive pairs (2i, 2i+1) share no block column (r04): a layered decoder\n"
-        "visits them in file order and may work on such a pair at once with unchanged results (csrc/layered_lds.hip).\n")
+        "Block rows are written in an order in which runs of four consecutive rows (4i .. 4i+3) share no block column (r04): a layered\n"
+        "decoder visits them in file order and may work on such a run at once with unchanged results (csrc/layered_lds.hip).\n")
     rw = (off >= 0).sum(1)
     cw = (off >= 0).sum(0)
     print(f"wrote {out}/H.q: {off.shape[0]} x {off.shape[1]} blocks of {SZ}: N = {off.shape[1] * SZ}, M = {off.shape[0] * SZ}, "

@@ -29,7 +29,7 @@ class CtxConfig(C.Structure):   # ldpc_ctx_config
 ABI_SYMBOLS = [
     "ldpc_init", "ldpc_shutdown", "ldpc_current_device", "ldpc_ctx_create_on", "ldpc_sim_create_on", "ldpc_ctx_create_cfg", "ldpc_ctx_schedule", "ldpc_ctx_code", "ldpc_ctx_max_batch", "ldpc_ctx_device",
     "ldpc_batcher_create", "ldpc_batcher_destroy", "ldpc_batcher_decode_one", "ldpc_batcher_stats",
-    "ldpc_ecc_create_replicas", "ldpc_ecc_replicas", "ldpc_ecc_ctx_at", "ldpc_ecc_sim_at", "ldpc_ecc_decode_on", "ldpc_ecc_set_coalescing", "ldpc_ecc_coalescing_stats", "ldpc_code_set_layers", "ldpc_code_layers", "ldpc_last_error", "ldpc_last_error_code", "ldpc_abi_version", "ldpc_device_count",
+    "ldpc_ecc_create_replicas", "ldpc_ecc_replicas", "ldpc_ecc_ctx_at", "ldpc_ecc_sim_at", "ldpc_ecc_decode_on", "ldpc_ecc_set_coalescing", "ldpc_ecc_coalescing_stats", "ldpc_code_set_layers", "ldpc_code_layers", "ldpc_qc_layer_order", "ldpc_last_error", "ldpc_last_error_code", "ldpc_abi_version", "ldpc_device_count",
     "ldpc_code_create_qc", "ldpc_code_create_csr", "ldpc_code_destroy", "ldpc_code_dims", "ldpc_code_csr",
     "ldpc_ctx_create", "ldpc_ctx_create_ex", "ldpc_ctx_destroy", "ldpc_ctx_path", "ldpc_ctx_synchronize",
     "ldpc_decode_one", "ldpc_decode_batch", "ldpc_decode_batch_f64", "ldpc_decode_batch_dev",
@@ -162,6 +162,7 @@ def lib():
     L.ldpc_ctx_create_cfg.argtypes = [vp, C.POINTER(CtxConfig)]
     L.ldpc_ctx_schedule.argtypes = [vp]
     L.ldpc_code_set_layers.argtypes = [vp, C.c_int, i32p]
+    L.ldpc_qc_layer_order.argtypes = [C.c_int, C.c_int, i32p, C.c_int, i32p]
     L.ldpc_code_layers.argtypes = [vp, ip, i32p]
     L.ldpc_sim_create_on.restype = vp
     L.ldpc_sim_create_on.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, u8p, C.c_int]
@@ -330,6 +331,17 @@ class Code:
         off = np.ascontiguousarray(offsets, dtype=np.int32)
         assert off.ndim == 2
         return cls(lib().ldpc_code_create_qc(int(sz), off.shape[0], off.shape[1], ptr(off, C.c_int32)))
+
+    @staticmethod
+    def qc_layer_order(offsets, run=4):
+        """-> (perm, full_runs): an order of the block rows in which runs of up to `run` consecutive rows share no block column
+        (ldpc_qc_layer_order; offsets[perm] is the matrix to hand to from_qc for the layered schedule)"""
+        off = np.ascontiguousarray(offsets, dtype=np.int32)
+        perm = np.zeros(off.shape[0], np.int32)
+        n = lib().ldpc_qc_layer_order(off.shape[0], off.shape[1], ptr(off, C.c_int32), int(run), ptr(perm, C.c_int32))
+        if n < 0:
+            raise LdpcError(lib().ldpc_last_error_code(), last_error())
+        return perm, n
 
     @classmethod
     def from_csr(cls, row_ptr, col_idx, N):

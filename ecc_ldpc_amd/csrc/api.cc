@@ -269,6 +269,51 @@ int ldpc_code_dims(const ldpc_code *code, int *M, int *N, int *E) {
     return LDPC_OK;
 }
 
+int ldpc_qc_layer_order(int block_rows, int block_cols, const int32_t *offsets, int run, int32_t *perm) {
+    if (block_rows <= 0 || block_cols <= 0 || !offsets || !perm || run < 1 || run > 8) return set_error(LDPC_EINVAL, "ldpc_qc_layer_order: bad arguments");
+    try {
+        const int Q = block_rows;
+        auto hit = [&](int br, int bc) { return offsets[(size_t)br * block_cols + bc] >= 0; };
+        std::vector<char> ok((size_t)Q * Q, 0);          // ok[i][j]: block rows i and j share no block column
+        for (int i = 0; i < Q; i++)
+            for (int j = i + 1; j < Q; j++) {
+                bool share = false;
+                for (int bc = 0; bc < block_cols && !share; bc++) share = hit(i, bc) && hit(j, bc);
+                ok[(size_t)i * Q + j] = ok[(size_t)j * Q + i] = share ? 0 : 1;
+            }
+        std::vector<char> free_((size_t)Q, 1);
+        std::vector<std::vector<int>> runs;
+        int left = Q;
+        while (left > 0) {
+            // compatible rows still free, per free row; the run starts with the row that has the fewest, ties to the lower index
+            std::vector<int> deg((size_t)Q, 0);
+            for (int i = 0; i < Q; i++) if (free_[i]) for (int j = 0; j < Q; j++) if (free_[j] && ok[(size_t)i * Q + j]) deg[i]++;
+            int first = -1;
+            for (int i = 0; i < Q; i++) if (free_[i] && (first < 0 || deg[i] < deg[first])) first = i;
+            std::vector<int> r{first};
+            free_[first] = 0; left--;
+            while ((int)r.size() < run) {
+                int best = -1;
+                for (int j = 0; j < Q; j++) {
+                    if (!free_[j]) continue;
+                    bool all = true;
+                    for (int i : r) all = all && ok[(size_t)i * Q + j];
+                    if (all && (best < 0 || deg[j] < deg[best])) best = j;
+                }
+                if (best < 0) break;
+                r.push_back(best); free_[best] = 0; left--;
+            }
+            std::sort(r.begin(), r.end());
+            runs.push_back(r);
+        }
+        std::stable_sort(runs.begin(), runs.end(), [](const std::vector<int> &a, const std::vector<int> &b) {
+            return a.size() != b.size() ? a.size() > b.size() : a < b; });
+        int n = 0, full = 0;
+        for (auto &r : runs) { if ((int)r.size() == run) full++; for (int br : r) perm[n++] = br; }
+        return full;
+    } catch (...) { return set_error(LDPC_ENOMEM, "out of host memory"); }
+}
+
 int ldpc_code_set_layers(ldpc_code *code, int n_layers, const int32_t *layer_ptr) {
     if (!code || n_layers <= 0 || !layer_ptr) return set_error(LDPC_EINVAL, "ldpc_code_set_layers: bad arguments");
     {

@@ -140,6 +140,14 @@ int ldpc_code_csr(const ldpc_code *code, int32_t *row_ptr /*M+1*/, int32_t *col_
  * the partition (layer_ptr[0] = 0 < ... < layer_ptr[n_layers] = M; LDPC_EINVAL if two rows of a layer share a column
  * or a context already exists on the code). */
 int ldpc_code_set_layers(ldpc_code *code, int n_layers, const int32_t *layer_ptr);
+/* A row-layered decoder visits the block rows of a quasi-cyclic H in the order they are given; block rows that follow one another
+ * and share no block column can be worked on together with unchanged results, and the long-code kernel (csrc/layered_lds.hip) does so
+ * for runs of up to four.  The order of the rows of H is the caller's to choose (a permutation of H's rows is the same code; the
+ * SCHEDULE, hence the last digits of a BER, changes with it): this helper proposes one -- perm[i] = the block row to put at place i,
+ * runs of up to `run` (1..8) pairwise column-disjoint block rows, full runs first (greedy, deterministic; what
+ * tools/gen_dvbs2_like.py applies to codes/dvbs2like.64800.1.2).  Pure host code, needs no GPU.  Returns the number of full runs,
+ * < 0 on error.  No counterpart in the reference (flooding only). */
+int ldpc_qc_layer_order(int block_rows, int block_cols, const int32_t *offsets, int run, int32_t *perm /* block_rows */);
 int ldpc_code_layers(const ldpc_code *code, int *n_layers, int32_t *layer_ptr /* may be NULL; n_layers+1 entries */);
 
 /* ---- decoder replica -------------------------------------------------------------------------

@@ -60,3 +60,40 @@ def test_header_is_c99_and_a_c_program_links(tmp_path):
     out = subprocess.run([str(exe)], cwd=ROOT, capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, (out.returncode, out.stdout, out.stderr)
     assert out.stdout.strip().endswith("ok")
+
+
+def test_qc_layer_order_proposes_independent_runs():
+    """ldpc_qc_layer_order (host code, no GPU): a permutation of the block rows in which runs of `run` consecutive rows share no block
+    column -- on the shipped DVB-S2-shaped matrix (already written in such an order: 22 runs of four), on its rows shuffled, on an
+    accumulator chain (every row shares a column with the next: pairs 0/2, 1/3 ... exist, fours too), and argument checks."""
+    from oracle import formats
+    from tests.helpers import CODES
+    sz, rows = formats.read_qc(open(os.path.join(CODES, "dvbs2like.64800.1.2", "H.q")).read())
+    off = np.asarray(formats.qc_offsets(sz, rows), dtype=np.int32)
+    assert sz == 360 and off.shape == (90, 180)
+
+    def runs_ok(o, perm, run, full):
+        assert sorted(perm.tolist()) == list(range(o.shape[0]))
+        hit = o[perm] >= 0
+        for i in range(full):
+            blk = hit[i * run:(i + 1) * run]
+            assert blk.sum(0).max() <= 1, i
+
+    for run in (2, 4):
+        perm, full = E.Code.qc_layer_order(off, run)
+        assert full >= (45 if run == 2 else 22)
+        runs_ok(off, perm, run, full)
+    shuffled = off[np.random.default_rng(1).permutation(90)]
+    perm, full = E.Code.qc_layer_order(shuffled, 4)
+    assert full >= 20
+    runs_ok(shuffled, perm, 4, full)
+    chain = -np.ones((12, 16), np.int32)                     # information part: a private column per row; accumulator: i and i - 1
+    for i in range(12):
+        chain[i, i % 4] = 1 + i; chain[i, 4 + i] = 0
+        if i:
+            chain[i, 4 + i - 1] = 0
+    perm, full = E.Code.qc_layer_order(chain, 2)
+    runs_ok(chain, perm, 2, full)
+    assert full == 6
+    with pytest.raises(E.LdpcError):
+        E.Code.qc_layer_order(chain, 9)

@@ -354,3 +354,31 @@ def test_fp16_lam_on_chip_edge_cases(hip):
     one = dec.decode_batch(llr[7:8], 25)
     assert np.array_equal(one[0][0], eb[7]) and one[1][0] == ei[7]
     dec.close()
+
+
+def test_layer_order_helper_feeds_the_long_code_kernel(hip):
+    """ldpc_qc_layer_order on a matrix in accumulator order (every block row shares a parity column with the next: the lam-on-chip kernel
+    must take them one at a time): the proposed order is a permutation of the rows (same code), gives the kernel runs of independent block
+    rows to work on together (its two-rows-per-set-of-waves instance), both orders are bit for bit their own emulation, and frames both
+    decode come out as the same codewords."""
+    from oracle import emulate_f16 as em
+    from tests.helpers import SyntheticQC
+    c = synthetic("dvbs2short-20x45-sz360")
+    perm, full = hip.Code.qc_layer_order(c.offsets, 2)      # (rows of weight up to 13: one set of six waves per workgroup, pairs)
+    assert sorted(perm.tolist()) == list(range(20)) and full == 10
+    c2 = SyntheticQC("dvbs2short-reordered", 360, c.offsets[perm])
+    assert np.array_equal(c2.H, c.H.reshape(20, 360, -1)[perm].reshape(c.H.shape))          # the same checks, another order
+    F = 12
+    _, llr = c.frames(F, 3.0, seed=812)
+    llr = llr.astype(np.float32)
+    outs = []
+    for code, want in ((c, ", 1>"), (c2, ", 2>")):
+        d = hip.Decoder(code.hip_code(hip), "min", "f16", F, schedule="layered", path="flood")
+        bits, its, conv = d.decode_batch(llr, 30)
+        assert "layered_lds_kernel" in d.kernel_name and d.kernel_name.endswith(want), d.kernel_name
+        eb, ei, ec, _ = em.decode_minsum_f16_layered(code.graph, llr, 30)
+        assert np.array_equal(bits, eb) and np.array_equal(its, ei) and np.array_equal(conv.astype(bool), ec)
+        outs.append((bits, conv.astype(bool)))
+        d.close()
+    both = outs[0][1] & outs[1][1]
+    assert both.sum() >= F // 2 and np.array_equal(outs[0][0][both], outs[1][0][both])

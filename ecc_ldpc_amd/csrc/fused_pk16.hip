@@ -8,6 +8,12 @@
 // 78 packed messages + 24 packed channel LLRs per thread as in the f32 split kernel, but the leave-one-out minimum of a
 // weight-18 row wants ~36 transient registers (magnitudes, suffix minima) where the f32 (min1, min2) form wants 18: at 4 waves
 // per SIMD (128 VGPRs) the compiler spills 150-210 registers, at 3 (168 VGPRs; 160-162 used) none.
+// r04, the verdict's route to 4 waves tried at compile time: the 24 round-0 copies of the channel LLRs moved from registers into a
+// lane-private area of LDS (read back chunk by chunk in round 0 like the columns of the other rounds).  The kernel then wants 137
+// VGPRs -- still 9 above the 128 of four waves ("failed to meet occupancy target") -- and 50 KB of LDS per workgroup (22.5 KB of
+// lam + 27 KB of LLR copies), of which only three fit a CU: the LDS left over by four workgroups (17 KB each) holds 17 of the 24
+// copies, i.e. 143 registers.  Four waves need the leave-one-out minimum of the weight-18 rows to get by with ~25 fewer transient
+// registers as well, which is the diet r03 measured at +13 % instructions.  Not pursued.
 #ifndef PK16_WAVES_PER_EU
 #define PK16_WAVES_PER_EU 3
 #endif

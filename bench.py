@@ -48,9 +48,13 @@ def main():
     ap.add_argument("--seed", type=lambda s: int(s, 0), default=0x5EEDC0DE)
     ap.add_argument("--fp16-leg", type=int, default=1, help="0: skip the extra, separately labelled measurements of the same workload (packed-fp16 decoder; layered schedule f32 / packed fp16) "
                     "(BASELINE configs[3]; reported next to the f32 headline as `fp16_packed`, never as `value`)")
+    ap.add_argument("--live-traffic", type=int, default=-1, help="1: measure roofline.traffic in this run (two short child runs of this workload under "
+                    "rocprofv3 --pmc, N = 1 only); 0: take it from the committed PMC pass; default: 1 for a full run, 0 when --cpu-seconds 0 trims it")
     ap.add_argument("--proof", type=int, default=1, help="0: skip the untimed proof-of-work sample (tools/profile.sh does, so that the "
                     "kernel-trace average covers full-size launches only)")
     args = ap.parse_args()
+    if args.live_traffic < 0:
+        args.live_traffic = 1 if args.cpu_seconds > 0 else 0
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # `python3 bench.py --gpus N` by itself: this parent starts one child process per GPU and relays rank 0's line.
@@ -165,7 +169,7 @@ def main():
         torch.cuda.synchronize()
         sum_iters_buf.append(int(iters_t.sum().item()))
     turns_timed = sum(sum_iters_buf[(args.warmup + i) % nbuf] for i in range(args.steps))   # frame-turns of this rank
-    roofline, roofline_hbm = rooflines(args, dec, B, Eg, N, n_tx, k, s_bytes, launches, kernel_ms, turns_timed)
+    roofline, roofline_hbm = rooflines(args, dec, B, Eg, N, n_tx, k, s_bytes, launches, kernel_ms, turns_timed, live=(rank == 0))
     pow_obj = proof_of_work(args, E, ecc, dec, sim, llr[0], msg[0], bits, iters_t, conv_t, sp, f16) if (rank == 0 and args.proof) else None
 
     out = None
@@ -396,6 +400,52 @@ PROFILE_TAGS = {   # committed rocprofv3 PMC passes (tools/profile.sh): (code, v
     ("1920.1280.A", "minsum", "f32", "fused"): ("1920A_f32_minsum", 16384)}
 
 
+def live_traffic(args, dec, B):
+    """HBM bytes per launch of the dominant kernel MEASURED IN THIS RUN: the same workload twice more, a few steps each, as child
+    processes under `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` (separate passes, nothing else traced, as the guide's HBM
+    section prescribes; FETCH_SIZE doubled: gfx950 tallies 128-byte read requests at 64).  Counters cannot be read from inside the
+    process that is being timed; the children run after the timed region, one at a time, while this process only waits.
+    -> (bytes, source) or (None, None): no rocprofv3, a child failed or took too long, more than one rank, or this IS such a child."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    from collections import defaultdict
+    if not args.live_traffic or os.environ.get("LDPC_BENCH_CHILD") or args.gpus != 1 or int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        return None, None
+    exe = shutil.which("rocprofv3")
+    if not exe:
+        return None, None
+    key = dec.kernel_name.strip().rstrip(",").strip()
+    child = [sys.executable or "python3", os.path.abspath(__file__), "--gpus", "1", "--steps", "2", "--warmup", "1", "--code", args.code, "--rate", args.rate,
+             "--variant", args.variant, "--dtype", args.dtype, "--iters", str(args.iters), "--ebn0", str(args.ebn0), "--batch", str(B), "--path", args.path,
+             "--schedule", args.schedule, "--cpu-seconds", "0", "--seed", hex(args.seed), "--fp16-leg", "0", "--proof", "0", "--live-traffic", "0"]
+    env = dict(os.environ, LDPC_BENCH_CHILD="1", TMPDIR="/tmp")
+    got = {}
+    for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="ldpc_pmc_", dir="/tmp")
+        try:
+            subprocess.run([exe, "--pmc", ctr, "--output-format", "csv", "-d", d, "-o", "pmc", "--"] + child, cwd="/tmp", env=env,
+                           stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240, check=True)
+            per = defaultdict(float)     # dispatch -> counter summed over its dimensions (XCDs)
+            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                for r in csv.DictReader(open(f)):
+                    if key in r["Kernel_Name"] and r["Counter_Name"] == ctr:
+                        per[r["Dispatch_Id"]] += float(r["Counter_Value"])
+            if not per:
+                return None, None
+            got[ctr] = (sum(per.values()) / len(per) * 1024.0, len(per))      # the counter is in KB
+        except Exception:
+            return None, None
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    total = 2.0 * got["FETCH_SIZE"][0] + got["WRITE_SIZE"][0]
+    return int(total), (f"measured in this run: child runs under rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), mean over "
+                        f"{got['FETCH_SIZE'][1]} / {got['WRITE_SIZE'][1]} launches of {B} frames; read side doubled (gfx950 counts 128-byte requests at 64): "
+                        f"{int(2 * got['FETCH_SIZE'][0])} B read + {int(got['WRITE_SIZE'][0])} B written")
+
+
 def committed_traffic(args, dec, B):
     """HBM bytes per launch of the dominant kernel from a COMMITTED rocprofv3 PMC pass (profiles/*_pmc.json:
     FETCH_SIZE and WRITE_SIZE collected in separate --pmc runs of this same command, FETCH_SIZE doubled as the
@@ -460,7 +510,7 @@ def isa_entry(kernel_name, code=None, variant="min"):
     return hits[0]
 
 
-def rooflines(args, dec, B, Eg, N, n_tx, k, s_bytes, launches, kernel_ms, turns_timed):
+def rooflines(args, dec, B, Eg, N, n_tx, k, s_bytes, launches, kernel_ms, turns_timed, live=False):
     """-> (roofline, second object or None).
     On-chip (fused) kernels keep the BP state in LDS/registers: HBM sees the LLRs in and the bits out, so the bound is
     VALU issue.  achieved = VALU wave-instructions per second = (VALU instructions one wave issues per ordinary turn of
@@ -479,7 +529,10 @@ def rooflines(args, dec, B, Eg, N, n_tx, k, s_bytes, launches, kernel_ms, turns_
            "bytes_model": "sum_frames(iters_f)*(3E+3N)*s + frames*(N*s + n_tx*s + ceil(k/8)) -- SURVEY.md section 8d priced with the iterations run",
            "algorithmic_bytes_timed": model_bytes, "mean_iters_timed": round(turns_timed / frames_timed, 3)}
     hbm["frac"] = round(hbm["achieved"] / HBM_PEAK_GBS, 4)
-    traffic, tsrc = committed_traffic(args, dec, B)
+    traffic, tsrc = live_traffic(args, dec, B) if live else (None, None)
+    if traffic is None:
+        traffic, tsrc = committed_traffic(args, dec, B)
+        tsrc = tsrc
     if dec.path != "fused" and dec.schedule == "layered":
         # layered schedule from HBM: ONE launch is the whole decode of the batch; per sweep every edge reads and writes its
         # lam cell and its message (4E*s), plus the syndrome pass before the first sweep (E*s); priced with the sweeps run
@@ -495,7 +548,7 @@ def rooflines(args, dec, B, Eg, N, n_tx, k, s_bytes, launches, kernel_ms, turns_
             bytes_timed = turns_timed * per_sweep + frames_timed * Eg * s_bytes
         ach = bytes_timed / (kernel_ms * 1e-3) / 1e9 if kernel_ms else 0.0
         r = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
-             "traffic": traffic, "traffic_source": tsrc and f"{tsrc} (committed PMC pass, not measured in this run)",
+             "traffic": traffic, "traffic_source": tsrc,
              "kernel": dec.kernel_name, "launches": launches, "avg_launch_ms": round(avg_ms, 4),
              "algorithmic_bytes_timed": bytes_timed, "algorithmic_bytes_per_launch": bytes_timed // steps, "frame_sweeps_timed": turns_timed,
              "bytes_model": ("sum_frames(sweeps_f)*24M - frames*12M + frames*(N*llr_bytes + N): one 12-byte record per row read+written per sweep (lam stays in LDS as fp16), LLRs in, bits out"
@@ -507,7 +560,7 @@ def rooflines(args, dec, B, Eg, N, n_tx, k, s_bytes, launches, kernel_ms, turns_
         # flooding from HBM, one workgroup per frame, ONE launch per batch: the contract's byte model is exactly this
         # kernel's algorithmic traffic -- (3E+3N)*s per frame and turn run, the LLRs in, the bits out
         r = dict(hbm)
-        r.update({"traffic": traffic, "traffic_source": tsrc and f"{tsrc} (committed PMC pass, not measured in this run)", "kernel": dec.kernel_name,
+        r.update({"traffic": traffic, "traffic_source": tsrc, "kernel": dec.kernel_name,
                   "launches": launches, "avg_launch_ms": round(avg_ms, 4), "frame_turns_timed": turns_timed,
                   "algorithmic_bytes_per_launch": model_bytes // steps})
         return r, None
@@ -523,7 +576,7 @@ def rooflines(args, dec, B, Eg, N, n_tx, k, s_bytes, launches, kernel_ms, turns_
     threads, fpw = dec.kernel_geometry
     ent = isa_entry(dec.kernel_name, dec.code, "min" if args.variant == "minsum" else "tanh")
     r = {"bound": "valu", "unit": "G wave-instr/s", "peak": round(VALU_PEAK / 1e9, 1), "kernel": dec.kernel_name, "launches": launches,
-         "avg_launch_ms": round(avg_ms, 4), "traffic": traffic, "traffic_source": tsrc and f"{tsrc} (committed PMC pass, not measured in this run)",
+         "avg_launch_ms": round(avg_ms, 4), "traffic": traffic, "traffic_source": tsrc,
          "frame_turns_timed": turns_timed, "threads_per_workgroup": threads, "frames_per_workgroup": fpw}
     if ent is None or not threads or not fpw or not kernel_ms:
         r.update({"achieved": None, "frac": None, "note": "no static instruction count for this kernel instance (build/isa_stats.json)"})

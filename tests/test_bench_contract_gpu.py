@@ -38,7 +38,13 @@ def test_one_json_line_with_roofline_and_cpu_baseline():
     assert r["bound"] == "valu" and r["peak"] == 1228.8 and r["launches"] == 2 and "fused_split_kernel<float, 1" in r["kernel"]
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and 0.2 < r["frac"] <= 1.0 and 0.2 < r["valu_pipe_busy_frac"] <= 1.0
     assert r["frame_turns_timed"] == 2 * 2048 * 50 and 900 < r["valu_instr_per_wave_turn"] < 1100 and r["waves_per_frame"] == 4
-    assert r["traffic"] is None or (r["traffic"] > 0 and "committed" in r["traffic_source"])
+    # HBM bytes per launch: measured in this very run (child runs under rocprofv3 --pmc) where the profiler is there, else the committed pass
+    assert r["traffic"] is None or (r["traffic"] > 0 and ("committed" in r["traffic_source"] or "measured in this run" in r["traffic_source"]))
+    import shutil
+    if shutil.which("rocprofv3"):
+        assert "measured in this run" in r["traffic_source"], r["traffic_source"]
+        # on-chip state: the LLRs in (4 bytes per bit), a byte per bit out, byte-granular writes -- between one and three times that
+        assert 2048 * 5632 * 5 <= r["traffic"] <= 3 * 2048 * 5632 * 5, r["traffic"]
     # the contract's HBM byte model rides along, priced with the same iteration sum
     h = d["roofline_hbm_model"]
     assert h["bound"] == "hbm" and h["unit"] == "GB/s" and h["peak"] == 8000.0 and h["mean_iters_timed"] == 50.0

@@ -9,7 +9,7 @@ set -o pipefail
 tag=$1; shift
 out=$PWD/gpurun_out/prof_$tag; mkdir -p $out
 export TMPDIR=/tmp
-args="--cpu-seconds 0 --proof 0 --fp16-leg 0 --steps 4 --warmup 2 $*"   # (--fp16-leg 0: only the workload named, so that "the dominant kernel" is its kernel)
+args="--cpu-seconds 0 --proof 0 --fp16-leg 0 --live-traffic 0 --steps 4 --warmup 2 $*"   # (--fp16-leg 0: only the workload named, so that "the dominant kernel" is its kernel)
 # one UNPROFILED run first: whatever the workload needs from the tool chain (a run-time specialised kernel's code object,
 # its <kernel>.isa.json) is built and cached now, so no hipcc child is ever started under the profiler's preload
 echo "[profile] warm the caches (unprofiled)" >&2

@@ -417,6 +417,8 @@ def live_traffic(args, dec, B):
     exe = shutil.which("rocprofv3")
     if not exe:
         return None, None
+    if "rocprof" in os.environ.get("LD_PRELOAD", "") or any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ):
+        return None, None                # this process is being profiled itself: no profiler inside a profiler
     key = dec.kernel_name.strip().rstrip(",").strip()
     child = [sys.executable or "python3", os.path.abspath(__file__), "--gpus", "1", "--steps", "2", "--warmup", "1", "--code", args.code, "--rate", args.rate,
              "--variant", args.variant, "--dtype", args.dtype, "--iters", str(args.iters), "--ebn0", str(args.ebn0), "--batch", str(B), "--path", args.path,
@@ -427,7 +429,7 @@ def live_traffic(args, dec, B):
         d = tempfile.mkdtemp(prefix="ldpc_pmc_", dir="/tmp")
         try:
             subprocess.run([exe, "--pmc", ctr, "--output-format", "csv", "-d", d, "-o", "pmc", "--"] + child, cwd="/tmp", env=env,
-                           stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240, check=True)
+                           stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=150, check=True)
             per = defaultdict(float)     # dispatch -> counter summed over its dimensions (XCDs)
             for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
                 for r in csv.DictReader(open(f)):

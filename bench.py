@@ -400,12 +400,16 @@ PROFILE_TAGS = {   # committed rocprofv3 PMC passes (tools/profile.sh): (code, v
     ("1920.1280.A", "minsum", "f32", "fused"): ("1920A_f32_minsum", 16384)}
 
 
-def live_traffic(args, dec, B):
-    """HBM bytes per launch of the dominant kernel MEASURED IN THIS RUN: the same workload twice more, a few steps each, as child
-    processes under `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` (separate passes, nothing else traced, as the guide's HBM
-    section prescribes; FETCH_SIZE doubled: gfx950 tallies 128-byte read requests at 64).  Counters cannot be read from inside the
-    process that is being timed; the children run after the timed region, one at a time, while this process only waits.
-    -> (bytes, source) or (None, None): no rocprofv3, a child failed or took too long, more than one rank, or this IS such a child."""
+_LIVE = {}      # kernel name -> per-launch means of the counters measured in this run (live_counters)
+
+
+def live_counters(args, dec, B):
+    """Per-launch means of hardware counters of the dominant kernel MEASURED IN THIS RUN: the same workload three more times, a few steps
+    each, as child processes under `rocprofv3 --pmc ...` -- FETCH_SIZE and WRITE_SIZE in passes of their own, as the guide's HBM section
+    prescribes, then the shader counters that say how busy the vector pipes were; nothing else is traced in those runs.  Counters cannot
+    be read from inside the process that is being timed; the children run after the timed region, one at a time, while this process only
+    waits.  -> {counter: mean, "launches": n} or None: no rocprofv3, a child failed or took too long, more than one rank, this IS such a
+    child, or this process is itself being profiled."""
     import csv
     import glob
     import shutil
@@ -413,39 +417,72 @@ def live_traffic(args, dec, B):
     import tempfile
     from collections import defaultdict
     if not args.live_traffic or os.environ.get("LDPC_BENCH_CHILD") or args.gpus != 1 or int(os.environ.get("WORLD_SIZE", "1")) > 1:
-        return None, None
+        return None
+    key = dec.kernel_name.strip().rstrip(",").strip()
+    if key in _LIVE:
+        return _LIVE[key]
     exe = shutil.which("rocprofv3")
     if not exe:
-        return None, None
+        return None
     if "rocprof" in os.environ.get("LD_PRELOAD", "") or any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ):
-        return None, None                # this process is being profiled itself: no profiler inside a profiler
-    key = dec.kernel_name.strip().rstrip(",").strip()
+        return None                # this process is being profiled itself: no profiler inside a profiler
     child = [sys.executable or "python3", os.path.abspath(__file__), "--gpus", "1", "--steps", "2", "--warmup", "1", "--code", args.code, "--rate", args.rate,
              "--variant", args.variant, "--dtype", args.dtype, "--iters", str(args.iters), "--ebn0", str(args.ebn0), "--batch", str(B), "--path", args.path,
              "--schedule", args.schedule, "--cpu-seconds", "0", "--seed", hex(args.seed), "--fp16-leg", "0", "--proof", "0", "--live-traffic", "0"]
     env = dict(os.environ, LDPC_BENCH_CHILD="1", TMPDIR="/tmp")
     got = {}
-    for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+    for ctrs in (["FETCH_SIZE"], ["WRITE_SIZE"], ["SQ_ACTIVE_INST_VALU", "GRBM_GUI_ACTIVE", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY"]):
         d = tempfile.mkdtemp(prefix="ldpc_pmc_", dir="/tmp")
         try:
-            subprocess.run([exe, "--pmc", ctr, "--output-format", "csv", "-d", d, "-o", "pmc", "--"] + child, cwd="/tmp", env=env,
+            subprocess.run([exe, "--pmc"] + ctrs + ["--output-format", "csv", "-d", d, "-o", "pmc", "--"] + child, cwd="/tmp", env=env,
                            stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=150, check=True)
-            per = defaultdict(float)     # dispatch -> counter summed over its dimensions (XCDs)
+            per = defaultdict(float)     # (dispatch, counter) -> value summed over its dimensions (XCDs, SEs)
             for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
                 for r in csv.DictReader(open(f)):
-                    if key in r["Kernel_Name"] and r["Counter_Name"] == ctr:
-                        per[r["Dispatch_Id"]] += float(r["Counter_Value"])
-            if not per:
-                return None, None
-            got[ctr] = (sum(per.values()) / len(per) * 1024.0, len(per))      # the counter is in KB
+                    if key in r["Kernel_Name"] and r["Counter_Name"] in ctrs:
+                        per[(r["Dispatch_Id"], r["Counter_Name"])] += float(r["Counter_Value"])
+            for c in ctrs:
+                v = [x for (_, cn), x in per.items() if cn == c]
+                if not v:
+                    raise RuntimeError(c)
+                got[c] = sum(v) / len(v)
+                got["launches"] = len(v)
         except Exception:
-            return None, None
+            if "FETCH_SIZE" in got and "WRITE_SIZE" in got:
+                break                    # the byte counters are in: keep them, do without the shader counters
+            _LIVE[key] = None
+            return None
         finally:
             shutil.rmtree(d, ignore_errors=True)
-    total = 2.0 * got["FETCH_SIZE"][0] + got["WRITE_SIZE"][0]
-    return int(total), (f"measured in this run: child runs under rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), mean over "
-                        f"{got['FETCH_SIZE'][1]} / {got['WRITE_SIZE'][1]} launches of {B} frames; read side doubled (gfx950 counts 128-byte requests at 64): "
-                        f"{int(2 * got['FETCH_SIZE'][0])} B read + {int(got['WRITE_SIZE'][0])} B written")
+    _LIVE[key] = got
+    return got
+
+
+def live_traffic(args, dec, B):
+    """-> (HBM bytes per launch measured in this run, what it is) or (None, None); FETCH_SIZE doubled: gfx950 tallies 128-byte read
+    requests at 64 (MI355X_MICROARCH.md, HBM / rocprofv3 section); the counters are in KB"""
+    got = live_counters(args, dec, B)
+    if not got:
+        return None, None
+    rd, wr = 2.0 * got["FETCH_SIZE"] * 1024.0, got["WRITE_SIZE"] * 1024.0
+    return int(rd + wr), (f"measured in this run: child runs under rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), mean over "
+                          f"{got['launches']} launches of {B} frames; read side doubled (gfx950 counts 128-byte requests at 64): "
+                          f"{int(rd)} B read + {int(wr)} B written")
+
+
+def live_pipe_busy(args, dec, B):
+    """-> {"valu_pipe_busy": ..., "waves_waiting": ...} from the shader counters of live_counters, or None.  SQ_ACTIVE_INST_VALU counts
+    quad-cycles a wave had a VALU instruction in flight (every instruction rounded up to one), summed over the device: x 4 clk / 1024
+    SIMDs against the launch's cycles (GRBM_GUI_ACTIVE is summed over the 8 XCDs).  Near or above 1 = saturated."""
+    got = live_counters(args, dec, B)
+    if not got or "SQ_ACTIVE_INST_VALU" not in got or not got.get("GRBM_GUI_ACTIVE"):
+        return None
+    cyc = got["GRBM_GUI_ACTIVE"] / 8.0
+    return {"valu_pipe_busy": round(got["SQ_ACTIVE_INST_VALU"] * 4.0 / N_SIMD / cyc, 3),
+            "waves_waiting": round(got["SQ_WAIT_ANY"] / got["SQ_WAVE_CYCLES"], 3) if got.get("SQ_WAVE_CYCLES") else None,
+            "source": "measured in this run: child run under rocprofv3 --pmc SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY; "
+                      "valu_pipe_busy = SQ_ACTIVE_INST_VALU x 4 clk / 1024 SIMDs / (GRBM_GUI_ACTIVE / 8 XCDs); the counter rounds every instruction "
+                      "up to a quad-cycle, so ~1 means saturated"}
 
 
 def committed_traffic(args, dec, B):
@@ -580,6 +617,9 @@ def rooflines(args, dec, B, Eg, N, n_tx, k, s_bytes, launches, kernel_ms, turns_
     r = {"bound": "valu", "unit": "G wave-instr/s", "peak": round(VALU_PEAK / 1e9, 1), "kernel": dec.kernel_name, "launches": launches,
          "avg_launch_ms": round(avg_ms, 4), "traffic": traffic, "traffic_source": tsrc,
          "frame_turns_timed": turns_timed, "threads_per_workgroup": threads, "frames_per_workgroup": fpw}
+    busy = live_pipe_busy(args, dec, B) if live else None
+    if busy:
+        r["counters"] = busy
     if ent is None or not threads or not fpw or not kernel_ms:
         r.update({"achieved": None, "frac": None, "note": "no static instruction count for this kernel instance (build/isa_stats.json)"})
         return r, hbm

@@ -45,6 +45,8 @@ def test_one_json_line_with_roofline_and_cpu_baseline():
         assert "measured in this run" in r["traffic_source"], r["traffic_source"]
         # on-chip state: the LLRs in (4 bytes per bit), a byte per bit out, byte-granular writes -- between one and three times that
         assert 2048 * 5632 * 5 <= r["traffic"] <= 3 * 2048 * 5632 * 5, r["traffic"]
+        # ... and how busy the vector pipes were, by the shader counters of a third child run (2 048 frames: 8 workgroups per CU's worth of work)
+        assert 0.1 < r["counters"]["valu_pipe_busy"] < 1.5 and 0.0 < r["counters"]["waves_waiting"] < 1.0, r["counters"]
     # the contract's HBM byte model rides along, priced with the same iteration sum
     h = d["roofline_hbm_model"]
     assert h["bound"] == "hbm" and h["unit"] == "GB/s" and h["peak"] == 8000.0 and h["mean_iters_timed"] == 50.0

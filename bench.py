@@ -283,8 +283,21 @@ def long_code_leg(args, E, torch, dev, sp, B=16384, code="dvbs2like.64800.1.2"):
                         "bytes_model": "sum_frames(sweeps_f)*24M - frames*12M + frames*(2N + N): one 12-byte record per row read + written per sweep, fp16 LLRs in, bits out"},
            "matrix": "SYNTHETIC, DVB-S2 rate-1/2 normal-frame shape (tools/gen_dvbs2_like.py); frames = all-zero codeword + AWGN",
            "checked_by": "tests/test_layered_gpu.py: bit-exact with oracle/emulate_f16.py decode_minsum_f16_layered"}
+    name_of_kernel = dec.kernel_name
     ecc.close()
     del llr, bits, its, conv
+    torch.cuda.empty_cache()
+    # HBM bytes per launch and vector-pipe occupancy of THIS workload, measured now (child runs under rocprofv3 --pmc, as for the headline)
+    import types
+    a2 = types.SimpleNamespace(**vars(args))
+    a2.code, a2.rate, a2.variant, a2.dtype, a2.path, a2.schedule = code, "none", "minsum", "f16", "auto", "layered"
+    holder = types.SimpleNamespace(kernel_name=name_of_kernel)
+    traffic, tsrc = live_traffic(a2, holder, B)
+    if traffic is not None:
+        res["roofline"].update({"traffic": traffic, "traffic_source": tsrc, "traffic_over_algorithmic": round(traffic / (alg / steps), 3)})
+        busy = live_pipe_busy(a2, holder, B)
+        if busy:
+            res["roofline"]["counters"] = busy
     return res
 
 

@@ -443,6 +443,10 @@ def live_counters(args, dec, B):
              "--variant", args.variant, "--dtype", args.dtype, "--iters", str(args.iters), "--ebn0", str(args.ebn0), "--batch", str(B), "--path", args.path,
              "--schedule", args.schedule, "--cpu-seconds", "0", "--seed", hex(args.seed), "--fp16-leg", "0", "--proof", "0", "--live-traffic", "0"]
     env = dict(os.environ, LDPC_BENCH_CHILD="1", TMPDIR="/tmp")
+    for k in list(env):              # a child is a plain one-process run, whatever launched this one
+        if k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "GROUP_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "ROLE_RANK",
+                 "ROLE_WORLD_SIZE", "ROLE_NAME") or k.startswith(("TORCHELASTIC_", "TORCH_NCCL_", "NCCL_ASYNC")):
+            del env[k]
     got = {}
     for ctrs in (["FETCH_SIZE"], ["WRITE_SIZE"], ["SQ_ACTIVE_INST_VALU", "GRBM_GUI_ACTIVE", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY"]):
         d = tempfile.mkdtemp(prefix="ldpc_pmc_", dir="/tmp")

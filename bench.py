@@ -347,8 +347,21 @@ def fp16_packed_leg(args, E, torch, dev, sp, B):
         res.update({"valu_instr_per_wave_turn": round(valu, 1), "waves_per_frame": waves_per_frame,
                     "valu_frac": round(valu * waves_per_frame * turns / (kernel_ms * 1e-3) / VALU_PEAK, 4),
                     "valu_pipe_busy_frac": round(clk * waves_per_frame * turns / (N_SIMD * CLOCK_HZ * kernel_ms * 1e-3), 4)})
+    kname = dec.kernel_name
     ecc.close()
     del llr, msg, bits, its
+    torch.cuda.empty_cache()
+    # HBM bytes per launch and vector-pipe occupancy of THIS workload, measured now (child runs under rocprofv3 --pmc, as for the headline)
+    import types
+    a2 = types.SimpleNamespace(**vars(args))
+    a2.dtype = "f16pk"
+    holder = types.SimpleNamespace(kernel_name=kname)
+    traffic, tsrc = live_traffic(a2, holder, B)
+    if traffic is not None:
+        res.update({"traffic": traffic, "traffic_source": tsrc})
+        busy = live_pipe_busy(a2, holder, B)
+        if busy:
+            res["counters"] = busy
     return res
 
 

@@ -464,8 +464,21 @@ def live_counters(args, dec, B):
     for ctrs in (["FETCH_SIZE"], ["WRITE_SIZE"], ["SQ_ACTIVE_INST_VALU", "GRBM_GUI_ACTIVE", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY"]):
         d = tempfile.mkdtemp(prefix="ldpc_pmc_", dir="/tmp")
         try:
-            subprocess.run([exe, "--pmc"] + ctrs + ["--output-format", "csv", "-d", d, "-o", "pmc", "--"] + child, cwd="/tmp", env=env,
-                           stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=150, check=True)
+            # (its own process group: on a time-out the profiler AND the run it started are ended, by that group's id -- nothing is left behind)
+            pr = subprocess.Popen([exe, "--pmc"] + ctrs + ["--output-format", "csv", "-d", d, "-o", "pmc", "--"] + child, cwd="/tmp", env=env,
+                                  stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
+            try:
+                rc = pr.wait(timeout=150)
+            except subprocess.TimeoutExpired:
+                import signal
+                try:
+                    os.killpg(pr.pid, signal.SIGKILL)
+                except OSError:
+                    pass
+                pr.wait()
+                raise
+            if rc != 0:
+                raise RuntimeError(f"rocprofv3 exited with {rc}")
             per = defaultdict(float)     # (dispatch, counter) -> value summed over its dimensions (XCDs, SEs)
             for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
                 for r in csv.DictReader(open(f)):

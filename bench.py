@@ -204,6 +204,10 @@ def main():
             # BASELINE configs[4]: the DVB-S2-shaped n = 64 800 code (a SYNTHETIC matrix of that shape: the ETSI tables are not available),
             # layered min-sum with early termination -- lam on-chip in fp16, row records streamed from HBM (csrc/layered_lds.hip, r04)
             out["long_code_layered"] = long_code_leg(args, E, torch, dev, sp)
+            # BASELINE configs[1] (jpl.1024.4.5 min-sum f32) and configs[2] (1920.1280.3.303 tanh f32, the 1-4 dB sweep): labelled measurements too
+            if args.code == "jpl.4096.4.5":
+                out["configs1_jpl1024_minsum"] = other_config_leg(args, E, torch, dev, sp, B, "jpl.1024.4.5", "4/5", "minsum", [args.ebn0])
+                out["configs2_mackay_tanh_sweep"] = other_config_leg(args, E, torch, dev, sp, B, "1920.1280.3.303", "none", "tanh", [1.0, 2.0, 3.0, 4.0], live_db=1.0)
         print(json.dumps(out), flush=True)
     # release the device objects in a known order before interpreter teardown
     torch.cuda.synchronize()
@@ -244,6 +248,70 @@ def layered_leg(args, E, torch, dev, sp, B, f16pk, ebn0):
            "checked_by": "tests/test_pk16_gpu.py (emulation, bit for bit)" if f16pk else "tests/test_layered_fused_gpu.py (HBM layered kernel bit for bit; oracle_decode_layered hard bits)"}
     ecc.close()
     del llr, msg, bits, its
+    return res
+
+
+def other_config_leg(args, E, torch, dev, sp, B, code, rate, variant, dbs, live_db=None):
+    """BASELINE.json configs[1] / configs[2] next to the headline: another shipped matrix through the same entry points, f32, flooding, the
+    same number of timed steps per Eb/N0 point; HIP-event kernel time; BER / FER against the transmitted messages (the all-zero word
+    where the matrix ships without a generator).  `live_db`: the point whose HBM traffic and pipe occupancy are measured in the run."""
+    name = f"ldpc/hip-{'minsum' if variant == 'minsum' else 'tanh'}/{code}/{args.iters}"
+    if rate not in ("", "none"):
+        x, y = rate.split("/")
+        name += f"/{x}/{y}"
+    try:
+        ecc = E.ECC(os.path.join(ROOT, "codes"), name, max_batch=B)
+    except E.LdpcError as e:
+        return {"code_name": name, "error": str(e)}
+    dec, sim, k, N = ecc.decoder, ecc.sim, ecc.message_length, ecc.code.N
+    llr = torch.empty((B, N), dtype=torch.float32, device=dev)
+    msg = torch.zeros((B, k), dtype=torch.uint8, device=dev)
+    bits = torch.empty((B, N), dtype=torch.uint8, device=dev)
+    its = torch.empty((B,), dtype=torch.int32, device=dev)
+    has_g = ecc.sim.encoder != "none"
+    steps = max(1, min(args.steps, 4))
+    points = []
+    for db in dbs:
+        sim.generate(args.seed, 0, B, db, llr.data_ptr(), msg.data_ptr() if has_g else None, sp)
+        step = lambda: dec.decode_batch_dev(llr.data_ptr(), bits.data_ptr(), B, args.iters, its.data_ptr(), None, sp)
+        step()
+        torch.cuda.synchronize()
+        dec.set_timing(True)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        launches, kernel_ms = dec.kernel_time()
+        dec.set_timing(False)
+        wrong = (bits[:, :k] != msg).sum(dim=1)
+        pt = {"ebn0_db": db, "value": round(steps * B * k / dt / 1e6, 2), "unit": "Mbit/s", "ms_per_step": round(dt / steps * 1e3, 3),
+              "avg_launch_ms": round(kernel_ms / max(launches, 1), 4), "ber": float(wrong.sum().item()) / (B * k), "fer": float((wrong > 0).sum().item()) / B,
+              "mean_iters": float(its.float().mean().item())}
+        ent = isa_entry(dec.kernel_name, dec.code, "min" if variant == "minsum" else "tanh")
+        threads, fpw = dec.kernel_geometry
+        if ent is not None and kernel_ms and threads and fpw:
+            loops = ent["loops"]
+            valu = sum(lp["hot_turn"]["units"].get("valu", 0) for lp in loops) / len(loops)
+            pt["valu_frac"] = round(valu * (threads / 64.0 / fpw) * float(its.sum().item()) * steps / (kernel_ms * 1e-3) / VALU_PEAK, 4)
+        points.append(pt)
+    res = {"code_name": name, "frames": B, "steps": steps, "path": dec.path, "kernel": dec.kernel_name, "points": points,
+           "checked_by": "tests/test_fused_gpu.py, tests/test_fused_csr_gpu.py, tests/test_golden.py: hard bits, flags and iteration counts against the oracle"}
+    kname = dec.kernel_name
+    ecc.close()
+    del llr, msg, bits, its
+    torch.cuda.empty_cache()
+    if live_db is not None:
+        import types
+        a2 = types.SimpleNamespace(**vars(args))
+        a2.code, a2.rate, a2.variant, a2.dtype, a2.path, a2.schedule, a2.ebn0 = code, rate, variant, "f32", "auto", "flooding", live_db
+        holder = types.SimpleNamespace(kernel_name=kname)
+        traffic, tsrc = live_traffic(a2, holder, B)
+        if traffic is not None:
+            res.update({"traffic_at_db": live_db, "traffic": traffic, "traffic_source": tsrc})
+            busy = live_pipe_busy(a2, holder, B)
+            if busy:
+                res["counters"] = busy
     return res
 
 

@@ -206,6 +206,9 @@ def main():
             out["long_code_layered"] = long_code_leg(args, E, torch, dev, sp)
             # BASELINE configs[1] (jpl.1024.4.5 min-sum f32) and configs[2] (1920.1280.3.303 tanh f32, the 1-4 dB sweep): labelled measurements too
             if args.code == "jpl.4096.4.5":
+                # (configs[0] is the reference's own CPU-runnable plumbing case, the toy moon.7.13 code with the tanh rule and 20 turns: here it
+                #  goes through the generic on-chip kernel like any other H)
+                out["configs0_moon_tanh"] = other_config_leg(args, E, torch, dev, sp, B, "moon.7.13", "none", "tanh", [args.ebn0, 6.0], iters=20)
                 out["configs1_jpl1024_minsum"] = other_config_leg(args, E, torch, dev, sp, B, "jpl.1024.4.5", "4/5", "minsum", [args.ebn0])
                 out["configs2_mackay_tanh_sweep"] = other_config_leg(args, E, torch, dev, sp, B, "1920.1280.3.303", "none", "tanh", [1.0, 2.0, 3.0, 4.0], live_db=1.0)
         print(json.dumps(out), flush=True)
@@ -251,10 +254,14 @@ def layered_leg(args, E, torch, dev, sp, B, f16pk, ebn0):
     return res
 
 
-def other_config_leg(args, E, torch, dev, sp, B, code, rate, variant, dbs, live_db=None):
+def other_config_leg(args, E, torch, dev, sp, B, code, rate, variant, dbs, live_db=None, iters=None):
     """BASELINE.json configs[1] / configs[2] next to the headline: another shipped matrix through the same entry points, f32, flooding, the
     same number of timed steps per Eb/N0 point; HIP-event kernel time; BER / FER against the transmitted messages (the all-zero word
     where the matrix ships without a generator).  `live_db`: the point whose HBM traffic and pipe occupancy are measured in the run."""
+    if iters is not None:
+        import types
+        args = types.SimpleNamespace(**vars(args))
+        args.iters = iters
     name = f"ldpc/hip-{'minsum' if variant == 'minsum' else 'tanh'}/{code}/{args.iters}"
     if rate not in ("", "none"):
         x, y = rate.split("/")

@@ -60,6 +60,13 @@ def test_one_json_line_with_roofline_and_cpu_baseline():
     assert d["value"] > 100 * c["value"]
     # value = frames * k / time
     assert abs(d["value"] - 2 * 2048 * 4096 / (d["ms_per_step"] * 2e-3) / 1e6) / d["value"] < 0.02
+    # the other BASELINE configurations ride along as labelled measurements (never as `value`)
+    assert "fused_pk16_kernel" in d["fp16_packed"]["kernel"] and "layered_lds_kernel" in d["long_code_layered"]["kernel"]
+    assert d["configs0_moon_tanh"]["code_name"] == "ldpc/hip-tanh/moon.7.13/20" and len(d["configs0_moon_tanh"]["points"]) == 2
+    assert "fused_split_kernel" in d["configs1_jpl1024_minsum"]["kernel"] and d["configs1_jpl1024_minsum"]["points"][0]["value"] > 0
+    sweep = d["configs2_mackay_tanh_sweep"]
+    assert [p_["ebn0_db"] for p_ in sweep["points"]] == [1.0, 2.0, 3.0, 4.0] and sweep["kernel"].endswith(", true>")
+    assert sweep["points"][0]["mean_iters"] > sweep["points"][3]["mean_iters"] and sweep["points"][3]["ber"] < sweep["points"][0]["ber"]
 
 
 def test_two_ranks_rehearsal_aggregates_over_ranks():
